@@ -1,0 +1,302 @@
+/*
+ * moondream_hip.h -- C ABI of libmoondream_hip.so, the MI355X (gfx950) compute
+ * library behind the Moondream inference seam.
+ *
+ * The reference isolates its accelerated path behind four bound methods that
+ * it rebinds itself in compile() (reference: moondream/torch/moondream.py:168-204):
+ *
+ *     _vis_enc(x)                           moondream.py:168-169  -> md_vit_encode
+ *     _vis_proj(g, r)                       moondream.py:171-172  -> md_vision_project
+ *     _prefill(x, attn_mask, pos_ids, lora) moondream.py:174-181  -> md_text_forward
+ *     _decode_one_tok(x, mask, pos, lora)   moondream.py:183-192  -> md_text_forward + md_lm_head
+ *
+ * Conventions
+ *   - plain C: device pointers travel as void*, the HIP stream as void*
+ *     (a hipStream_t); no torch / C++ types cross this boundary.
+ *   - the caller owns every buffer (weights, KV slabs, activations, workspace);
+ *     nothing here allocates, frees or synchronises.  All work is enqueued on
+ *     the caller's stream, so calls are hipGraph-capturable.
+ *   - bf16 tensors are raw 16-bit words, row-major, with an explicit leading
+ *     dimension in ELEMENTS.
+ *   - every entry point returns an md_status; 0 is success.  There is no CPU
+ *     fallback: without a gfx950 device the launches fail and say so.
+ */
+#ifndef MOONDREAM_HIP_H
+#define MOONDREAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_ABI_VERSION 1
+
+typedef int md_status;
+enum {
+  MD_OK = 0,
+  MD_ERR_INVALID_ARG = 1, /* shape / alignment / null-pointer contract violated */
+  MD_ERR_LAUNCH = 2,      /* the HIP runtime rejected a launch (no gfx950 device, ...) */
+  MD_ERR_WORKSPACE = 3,   /* workspace smaller than md_*_workspace_bytes() */
+  MD_ERR_UNSUPPORTED = 4  /* a shape outside what the kernels are built for */
+};
+
+int md_abi_version(void);
+const char* md_status_string(md_status s);
+
+/* ------------------------------------------------------------------ *
+ * Dense layers                                                        *
+ * ------------------------------------------------------------------ */
+
+/* y = x W^T + b in the nn.Linear layout (reference: layers.py:34-35).
+ * w: bf16 [n_pad][k_pad] row-major, packed once by the host: k_pad = k rounded
+ * up to 64 with zero fill; rows n..n_pad-1 (n_pad = n rounded up to 64) zero.
+ * b: bf16 [n_pad] (zero-filled tail) or NULL. */
+typedef struct {
+  const void* w;
+  const void* b;
+  int32_t n;     /* logical out features */
+  int32_t k;     /* logical in features  */
+  int32_t n_pad; /* allocated rows       */
+  int32_t k_pad; /* allocated row length = leading dimension */
+} md_linear;
+
+/* LayerNorm affine parameters, bf16 [dim] (reference: layers.py:118-119). */
+typedef struct {
+  const void* w;
+  const void* b;
+} md_layernorm;
+
+enum {
+  MD_EPI_BIAS = 0,     /* c = bf16(acc + b)                                       */
+  MD_EPI_GELU = 1,     /* c = bf16(gelu_tanh(bf16(acc + b)))    layers.py:129-138 */
+  MD_EPI_RESIDUAL = 2  /* c = bf16(r + bf16(acc + b))           vision.py:68,70-71, text.py:158 */
+};
+
+/* C[m, n] = epilogue(A[m, :k_pad] . W[n, :k_pad] + b[n]), fp32 accumulate on
+ * MFMA, one bf16 rounding of (acc + bias) and one more for the epilogue op --
+ * the reference's rounding points.  A must have lda >= k_pad with columns
+ * k..k_pad-1 readable and ZERO.  r (MD_EPI_RESIDUAL) is read at row
+ * (res_row_mod ? row % res_row_mod : row); it may alias c.  Columns n..n_pad-1
+ * of C are written (zeros through the zero weight rows) when ldc >= n_pad,
+ * which is what lets a padded activation feed the next layer's k_pad. */
+typedef struct {
+  const void* a;
+  int64_t lda;
+  md_linear lin;
+  void* c;
+  int64_t ldc;
+  const void* r;
+  int64_t ldr;
+  int32_t res_row_mod;
+  int32_t m;
+  int32_t epilogue;
+  int32_t store_pad_cols; /* 1: also store columns [n, n_pad) */
+} md_gemm_args;
+
+md_status md_gemm_bf16(const md_gemm_args* args, void* stream);
+
+/* y[r, :dim] = LN(x[r, :dim]) * w + b, fp32 statistics, eps as given
+ * (reference: layers.py:118-119, default eps 1e-5).  dim % 8 == 0, dim <= 4096. */
+md_status md_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const md_layernorm* p,
+                            int32_t rows, int32_t dim, float eps, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Vision front end                                                    *
+ * ------------------------------------------------------------------ */
+
+/* uint8 HWC crops [n][crop][crop][3] -> bf16 patch rows [n*grid*grid][ld_out]
+ * with feature order (c, py, px), columns >= 3*patch*patch zero-filled.  lut is
+ * the 256-entry bf16 table of the reference's pixel normalisation
+ * (vision.py:33-40 followed by create_patches, vision.py:44-61). */
+md_status md_patchify_u8(const void* crops_u8, const void* lut_bf16, void* out, int64_t ld_out,
+                         int32_t n_crops, int32_t crop, int32_t patch, void* stream);
+
+/* same from the already-normalised bf16 CHW tensor the reference's _vis_enc
+ * receives (moondream.py:168-169; create_patches vision.py:44-61). */
+md_status md_patchify_bf16(const void* crops_bf16_chw, void* out, int64_t ld_out, int32_t n_crops,
+                           int32_t crop, int32_t patch, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Attention                                                           *
+ * ------------------------------------------------------------------ */
+
+/* Tiled (flash-style) softmax attention on MFMA for a block of queries:
+ *   ViT encoder, no mask (layers.py:163) and the decoder prefill with the
+ *   prefix-LM rule (text.py:48-50 with the mask of moondream.py:138-146):
+ *   key j is visible to the query at position p iff j <= p or (p < prefix and
+ *   j < prefix); only keys [0, kv_len) exist.
+ * Element (b, t, h, d) of q/o lives at base + b*bs + t*ts + h*hs + d; k/v alike
+ * (strides in elements).  head_dim is 64 or 72.  q_pos0[b] (device int32, or
+ * NULL for 0) is the position of query row 0; kv_len[b] (device int32, or NULL
+ * for kv_len_all) the number of valid keys. */
+typedef struct {
+  const void* q;
+  int64_t q_bs, q_ts, q_hs;
+  const void* k;
+  int64_t k_bs, k_ts, k_hs;
+  const void* v;
+  int64_t v_bs, v_ts, v_hs;
+  void* o;
+  int64_t o_bs, o_ts, o_hs;
+  int32_t batch, n_heads, n_kv_heads, head_dim;
+  int32_t q_len;      /* query rows per batch element */
+  int32_t kv_len_all; /* used when kv_len == NULL */
+  const int32_t* q_pos0;
+  const int32_t* kv_len;
+  int32_t prefix_len; /* bidirectional prefix; >= kv_len disables the causal rule */
+  float scale;        /* 1/sqrt(head_dim) */
+} md_attn_args;
+
+md_status md_attention_prefill(const md_attn_args* args, void* stream);
+
+/* One query per (batch, head) against the KV slab: the decode step
+ * (text.py:48-50 with the [1,1,2048] mask of moondream.py:472-474 == keys
+ * [0, pos]).  q, o: [batch][n_heads*64]; slabs [batch][n_kv_heads][ctx][64];
+ * kv_len[b] valid keys (device int32). */
+md_status md_attention_decode(const void* q, int64_t ldq, void* o, int64_t ldo, const void* k_slab,
+                              const void* v_slab, int64_t slab_batch_stride, int32_t ctx, const int32_t* kv_len,
+                              int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
+                              float scale, void* stream);
+
+/* Partial RoPE + KV-cache write (reference: rope.py:20-48, text.py:42-46,
+ * moondream.py:74-78).  qkv: bf16 [batch*q_len][ld] rows laid out q|k|v.  The
+ * first rot_dim features of every q and k head are read half-split, rotated in
+ * fp32 with the fp32 table freqs[pos][rot_dim/2][2] (cos, sin) and written
+ * INTERLEAVED; q is rewritten in place, rotated k and v go to
+ * slab[b][h][pos][:].  pos = pos0[b] + t (pos0 device int32 [batch]). */
+md_status md_rope_kv_write(void* qkv, int64_t ld, const float* freqs, const int32_t* pos0,
+                           void* k_slab, void* v_slab, int64_t slab_batch_stride, int32_t ctx,
+                           int32_t batch, int32_t q_len, int32_t n_heads, int32_t n_kv_heads,
+                           int32_t head_dim, int32_t rot_dim, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Small ops                                                           *
+ * ------------------------------------------------------------------ */
+
+/* out[i, :dim] = table[ids[i], :dim]  (reference: text.py:12-13). */
+md_status md_embed_tokens(const int32_t* ids, const void* table, int64_t ld_table, void* out,
+                          int64_t ld_out, int32_t n, int32_t dim, void* stream);
+
+/* next[b] = argmax_v logits[b, v] with logits[b, suppress_id] treated as -inf
+ * when suppress_id >= 0 (reference: moondream.py:517,521-524); ties -> lowest
+ * index (torch.argmax on CPU). */
+md_status md_argmax_bf16(const void* logits, int64_t ld, int32_t batch, int32_t vocab,
+                         int32_t suppress_id, int32_t* next, void* stream);
+
+/* Overlap-crop stitch + adaptive average pool + concat with the global crop's
+ * features (reference: moondream.py:213-226, image_crops.py:170-231 with
+ * patch_size=1, vision.py:83-88).  feats: bf16 [1 + th*tw][g*g][dim] for ONE
+ * image (crop 0 = global).  out: bf16 [g*g][ld_out] = [global | pooled]. */
+md_status md_stitch_pool_concat(const void* feats, void* out, int64_t ld_out, int32_t dim,
+                                int32_t grid, int32_t margin, int32_t tiles_h, int32_t tiles_w,
+                                void* stream);
+
+/* ------------------------------------------------------------------ *
+ * The seam: whole-stage entry points                                  *
+ * ------------------------------------------------------------------ */
+
+typedef struct {
+  md_layernorm ln1;
+  md_linear qkv, proj;
+  md_layernorm ln2;
+  md_linear fc1, fc2;
+} md_vit_block;
+
+typedef struct {
+  int32_t dim, n_heads, n_layers, ff_dim;
+  int32_t patch, crop;     /* 14, 378 */
+  md_linear patch_emb;
+  const void* pos_emb;     /* bf16 [grid*grid][dim] */
+  const md_vit_block* blocks; /* host array of n_layers */
+  md_layernorm post_ln;
+  md_linear proj_fc1, proj_fc2; /* vision projector MLP (vision.py:77-89) */
+  const void* pixel_lut;   /* bf16 [256] */
+} md_vit_model;
+
+enum { MD_CROPS_U8_HWC = 0, MD_CROPS_BF16_CHW = 1 };
+
+size_t md_vit_workspace_bytes(const md_vit_model* m, int32_t n_crops);
+
+/* vision_encoder (reference: vision.py:64-74 behind moondream.py:168-169):
+ * crops -> out bf16 [n_crops][grid*grid][dim]. */
+md_status md_vit_encode(const md_vit_model* m, const void* crops, int32_t crops_kind,
+                        int32_t n_crops, void* out, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+size_t md_vision_project_workspace_bytes(const md_vit_model* m, int32_t n_images);
+
+/* vision_projection for n_images images that all share one tiling
+ * (reference: vision.py:77-89 behind moondream.py:171-172, plus the stitch of
+ * moondream.py:213-226).  feats: [n_images][1 + th*tw][g*g][dim];
+ * out: bf16 [n_images][g*g][ld_out] (proj_out_dim columns). */
+md_status md_vision_project(const md_vit_model* m, const void* feats, int32_t n_images,
+                            int32_t tiles_h, int32_t tiles_w, int32_t margin, void* out,
+                            int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The seam form of the same stage: _vis_proj(g, r) with r the ALREADY stitched
+ * [H][W][dim] grid, exactly what the reference passes (moondream.py:171-172,
+ * vision.py:77-89).  global_feats: [g*g][dim]; out: [g*g][ld_out].  Workspace:
+ * md_vision_project_workspace_bytes(m, 1). */
+md_status md_vision_project_grid(const md_vit_model* m, const void* global_feats,
+                                 const void* grid_feats, int32_t H, int32_t W, void* out,
+                                 int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct {
+  md_layernorm ln;
+  md_linear qkv, proj, fc1, fc2;
+} md_text_block;
+
+typedef struct {
+  int32_t dim, n_heads, n_kv_heads, n_layers, ff_dim, vocab, max_context, prefix_len, rot_dim;
+  const md_text_block* blocks; /* host array of n_layers */
+  md_layernorm post_ln;
+  md_linear lm_head;
+  const void* wte;       /* bf16 [vocab][dim] */
+  const float* freqs;    /* fp32 [max_context][rot_dim/2][2] */
+} md_text_model;
+
+/* KV slabs: layer l's keys at k + l*layer_stride, element (b,h,p,d) at
+ * b*batch_stride + (h*ctx + p)*64 + d (the reference's [1,H,2048,64] slab per
+ * sequence, moondream.py:62-72, batched on a leading axis). */
+typedef struct {
+  void* k;
+  void* v;
+  int64_t layer_stride, batch_stride; /* elements */
+  int32_t ctx;
+} md_kv_cache;
+
+size_t md_text_workspace_bytes(const md_text_model* m, int32_t batch, int32_t q_len);
+
+/* text_decoder over a block of q_len new tokens per sequence (reference:
+ * text.py:128-160 behind moondream.py:174-192): x bf16 [batch*q_len][dim]
+ * (embeddings) -> hidden bf16 [batch*q_len][dim]; writes K,V at positions
+ * pos0[b] .. pos0[b]+q_len-1 of every layer's slab.  x may alias hidden. */
+md_status md_text_forward(const md_text_model* m, const void* x, void* hidden, int32_t batch,
+                          int32_t q_len, const int32_t* pos0, const md_kv_cache* kv,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+size_t md_lm_head_workspace_bytes(const md_text_model* m, int32_t batch);
+
+/* lm_head on the LAST token of each sequence (reference: text.py:163-167):
+ * hidden [batch*q_len][dim] -> logits bf16 [batch][ld_logits]. */
+md_status md_lm_head(const md_text_model* m, const void* hidden, int32_t batch, int32_t q_len,
+                     void* logits, int64_t ld_logits, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* One greedy decode step for the whole batch, device-resident (the body of the
+ * reference's generator loop, moondream.py:512-530, without its per-token host
+ * sync): embed tokens[b] -> decoder at pos[b] -> lm_head -> suppress
+ * suppress_id -> argmax -> next[b]; pos[b] += 1.  done[b] != 0 sequences are
+ * still computed (lockstep) but keep their token. */
+md_status md_decode_step(const md_text_model* m, const int32_t* tokens, int32_t* next, int32_t* pos,
+                         int32_t batch, const md_kv_cache* kv, int32_t suppress_id, void* logits,
+                         int64_t ld_logits, void* workspace, size_t workspace_bytes, void* stream);
+
+size_t md_decode_workspace_bytes(const md_text_model* m, int32_t batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOONDREAM_HIP_H */

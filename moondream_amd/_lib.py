@@ -1,0 +1,196 @@
+"""ctypes binding of libmoondream_hip.so (C ABI: include/moondream_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc,
+--offload-arch=gfx950).  There is deliberately NO fallback: if the shared object
+is missing, or a launch fails, callers get an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
+SOURCES = ["gemm_bf16.hip", "attention.hip", "elementwise.hip", "api.hip"]
+
+MD_OK = 0
+MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
+MD_CROPS_U8_HWC, MD_CROPS_BF16_CHW = 0, 1
+
+c_void_p, c_int32, c_int64, c_size_t, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+
+
+class MdLinear(C.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("n", c_int32), ("k", c_int32), ("n_pad", c_int32), ("k_pad", c_int32)]
+
+
+class MdLayerNorm(C.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p)]
+
+
+class MdGemmArgs(C.Structure):
+    _fields_ = [
+        ("a", c_void_p), ("lda", c_int64), ("lin", MdLinear), ("c", c_void_p), ("ldc", c_int64),
+        ("r", c_void_p), ("ldr", c_int64), ("res_row_mod", c_int32), ("m", c_int32),
+        ("epilogue", c_int32), ("store_pad_cols", c_int32),
+    ]
+
+
+class MdAttnArgs(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("q_bs", c_int64), ("q_ts", c_int64), ("q_hs", c_int64),
+        ("k", c_void_p), ("k_bs", c_int64), ("k_ts", c_int64), ("k_hs", c_int64),
+        ("v", c_void_p), ("v_bs", c_int64), ("v_ts", c_int64), ("v_hs", c_int64),
+        ("o", c_void_p), ("o_bs", c_int64), ("o_ts", c_int64), ("o_hs", c_int64),
+        ("batch", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32),
+        ("q_len", c_int32), ("kv_len_all", c_int32), ("q_pos0", c_void_p), ("kv_len", c_void_p),
+        ("prefix_len", c_int32), ("scale", c_float),
+    ]
+
+
+class MdVitBlock(C.Structure):
+    _fields_ = [("ln1", MdLayerNorm), ("qkv", MdLinear), ("proj", MdLinear), ("ln2", MdLayerNorm),
+                ("fc1", MdLinear), ("fc2", MdLinear)]
+
+
+class MdVitModel(C.Structure):
+    _fields_ = [
+        ("dim", c_int32), ("n_heads", c_int32), ("n_layers", c_int32), ("ff_dim", c_int32),
+        ("patch", c_int32), ("crop", c_int32), ("patch_emb", MdLinear), ("pos_emb", c_void_p),
+        ("blocks", C.POINTER(MdVitBlock)), ("post_ln", MdLayerNorm), ("proj_fc1", MdLinear),
+        ("proj_fc2", MdLinear), ("pixel_lut", c_void_p),
+    ]
+
+
+class MdTextBlock(C.Structure):
+    _fields_ = [("ln", MdLayerNorm), ("qkv", MdLinear), ("proj", MdLinear), ("fc1", MdLinear), ("fc2", MdLinear)]
+
+
+class MdTextModel(C.Structure):
+    _fields_ = [
+        ("dim", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("n_layers", c_int32),
+        ("ff_dim", c_int32), ("vocab", c_int32), ("max_context", c_int32), ("prefix_len", c_int32),
+        ("rot_dim", c_int32), ("blocks", C.POINTER(MdTextBlock)), ("post_ln", MdLayerNorm),
+        ("lm_head", MdLinear), ("wte", c_void_p), ("freqs", c_void_p),
+    ]
+
+
+class MdKvCache(C.Structure):
+    _fields_ = [("k", c_void_p), ("v", c_void_p), ("layer_stride", c_int64), ("batch_stride", c_int64), ("ctx", c_int32)]
+
+
+# name -> (restype, argtypes): every symbol include/moondream_hip.h declares
+P = C.POINTER
+SIGNATURES = {
+    "md_abi_version": (C.c_int, []),
+    "md_status_string": (C.c_char_p, [C.c_int]),
+    "md_gemm_bf16": (C.c_int, [P(MdGemmArgs), c_void_p]),
+    "md_layernorm_bf16": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_float, c_void_p]),
+    "md_patchify_u8": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "md_patchify_bf16": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "md_attention_prefill": (C.c_int, [P(MdAttnArgs), c_void_p]),
+    "md_attention_decode": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                                      c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "md_rope_kv_write": (C.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "md_embed_tokens": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "md_argmax_bf16": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "md_stitch_pool_concat": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "md_vit_workspace_bytes": (c_size_t, [P(MdVitModel), c_int32]),
+    "md_vit_encode": (C.c_int, [P(MdVitModel), c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "md_vision_project_workspace_bytes": (c_size_t, [P(MdVitModel), c_int32]),
+    "md_vision_project": (C.c_int, [P(MdVitModel), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
+                                    c_void_p, c_size_t, c_void_p]),
+    "md_vision_project_grid": (C.c_int, [P(MdVitModel), c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                         c_void_p, c_size_t, c_void_p]),
+    "md_text_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32, c_int32]),
+    "md_text_forward": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_int32, c_int32, c_void_p, P(MdKvCache),
+                                  c_void_p, c_size_t, c_void_p]),
+    "md_lm_head_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32]),
+    "md_lm_head": (C.c_int, [P(MdTextModel), c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "md_decode_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32]),
+    "md_decode_step": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_void_p, c_int32, P(MdKvCache), c_int32,
+                                 c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+}
+
+
+class MoondreamHipError(RuntimeError):
+    pass
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    """Compile csrc/*.hip for gfx950 into moondream_amd/libmoondream_hip.so."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "md_common.hpp"), os.path.join(REPO, "include", "moondream_hip.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+    procs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc_path(), *flags, "-c", s, "-o", o]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise MoondreamHipError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise MoondreamHipError("link failed:\n" + r.stdout.decode())
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and type every entry point.  Raises if it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise MoondreamHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the Moondream hot path)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
+        fn.restype = res
+        fn.argtypes = args
+    if lib.md_abi_version() != 1:
+        raise MoondreamHipError("libmoondream_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != MD_OK:
+        msg = load().md_status_string(status).decode()
+        raise MoondreamHipError(f"{what or 'libmoondream_hip'}: status {status}: {msg}")
+
+
+def exported_symbols() -> List[str]:
+    return sorted(SIGNATURES)

@@ -1,0 +1,361 @@
+// Whole-stage entry points of the C ABI: the four seam functions of the
+// reference (moondream.py:168-192) expressed as launch sequences of the kernels
+// in this library.  Nothing here allocates or synchronises; every buffer,
+// including the workspace, belongs to the caller.
+#include "md_common.hpp"
+
+md_status md_argmax_advance(const void* logits, int64_t ld, int32_t batch, int32_t vocab,
+                            int32_t suppress_id, int32_t* next, int32_t* pos, hipStream_t stream);
+md_status md_stitch_pool_batched(const void* feats, void* out, int64_t ld_out, int64_t out_img_stride,
+                                 int32_t n_images, int32_t dim, int32_t grid, int32_t margin,
+                                 int32_t tiles_h, int32_t tiles_w, hipStream_t stream);
+
+md_status md_pool_grid_concat(const void* global_feats, const void* grid_feats, int32_t H, int32_t W,
+                              void* out, int64_t ld_out, int32_t dim, int32_t grid, hipStream_t stream);
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Arena {
+  char* base;
+  size_t off;
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  }
+};
+
+#define MD_TRY(expr)               \
+  do {                             \
+    md_status _s = (expr);         \
+    if (_s != MD_OK) return _s;    \
+  } while (0)
+
+md_status gemm(const void* a, int64_t lda, const md_linear& lin, void* c, int64_t ldc, int m, int epi,
+               const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s) {
+  md_gemm_args g;
+  g.a = a;
+  g.lda = lda;
+  g.lin = lin;
+  g.c = c;
+  g.ldc = ldc;
+  g.r = r;
+  g.ldr = ldr;
+  g.res_row_mod = res_row_mod;
+  g.m = m;
+  g.epilogue = epi;
+  g.store_pad_cols = store_pad;
+  return md_gemm_bf16(&g, s);
+}
+
+struct VitWs {
+  void *patches, *x, *h, *qkv, *ff;
+  size_t total;
+};
+
+VitWs vit_layout(const md_vit_model* m, int n_crops, void* base) {
+  const size_t g = m->crop / m->patch, M = (size_t)n_crops * g * g;
+  Arena a{(char*)base, 0};
+  VitWs w;
+  w.patches = a.take(M * m->patch_emb.k_pad * 2);
+  w.x = a.take(M * m->dim * 2);
+  w.h = a.take(M * m->blocks[0].qkv.k_pad * 2);  // GEMM A operand: padded leading dim, zero pad
+  w.qkv = a.take(M * 3 * m->dim * 2);
+  w.ff = a.take(M * m->blocks[0].fc1.n_pad * 2);
+  w.total = a.off;
+  return w;
+}
+
+// zero an A-operand buffer whose leading dimension is padded beyond its logical width
+md_status zero_if_padded(void* p, size_t rows, int ld, int width, hipStream_t s) {
+  if (ld == width) return MD_OK;
+  return hipMemsetAsync(p, 0, rows * (size_t)ld * 2, s) == hipSuccess ? MD_OK : MD_ERR_LAUNCH;
+}
+
+struct TextWs {
+  void *h, *qkv, *att, *ff, *pos_kv;
+  size_t total;
+};
+
+TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
+  const size_t M = (size_t)batch * q_len;
+  const size_t hd = m->dim / m->n_heads;
+  Arena a{(char*)base, 0};
+  TextWs w;
+  w.h = a.take(M * m->blocks[0].qkv.k_pad * 2);
+  w.qkv = a.take(M * (m->n_heads + 2 * m->n_kv_heads) * hd * 2);
+  w.att = a.take(M * m->blocks[0].proj.k_pad * 2);
+  w.ff = a.take(M * m->blocks[0].fc1.n_pad * 2);
+  w.pos_kv = a.take((size_t)batch * 4);
+  w.total = a.off;
+  return w;
+}
+
+__global__ void kv_len_kernel(const int32_t* pos0, int32_t* kv_len, int q_len, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) kv_len[i] = pos0[i] + q_len;
+}
+
+}  // namespace
+
+extern "C" int md_abi_version(void) { return MD_ABI_VERSION; }
+
+extern "C" const char* md_status_string(md_status s) {
+  switch (s) {
+    case MD_OK: return "ok";
+    case MD_ERR_INVALID_ARG: return "invalid argument (shape / alignment / null pointer)";
+    case MD_ERR_LAUNCH: return "HIP launch failed (is a gfx950 device visible?)";
+    case MD_ERR_WORKSPACE: return "workspace too small";
+    case MD_ERR_UNSUPPORTED: return "unsupported shape";
+    default: return "unknown status";
+  }
+}
+
+// ------------------------------------------------------------------ vision
+extern "C" size_t md_vit_workspace_bytes(const md_vit_model* m, int32_t n_crops) {
+  if (!m || !m->blocks || n_crops <= 0) return 0;
+  return vit_layout(m, n_crops, nullptr).total;
+}
+
+// reference: vision.py:64-74
+extern "C" md_status md_vit_encode(const md_vit_model* m, const void* crops, int32_t crops_kind,
+                                   int32_t n_crops, void* out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  MD_CHECK_ARG(m && crops && out && workspace && m->blocks && n_crops > 0);
+  MD_CHECK_ARG(m->dim % m->n_heads == 0 && m->crop % m->patch == 0);
+  const int hd = m->dim / m->n_heads;
+  if (hd != 72 && hd != 64) return MD_ERR_UNSUPPORTED;
+  const VitWs w = vit_layout(m, n_crops, workspace);
+  if (workspace_bytes < w.total) return MD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = m->crop / m->patch, T = g * g, M = n_crops * T, D = m->dim;
+  const int64_t kp = m->patch_emb.k_pad;
+  const int Dp = m->blocks[0].qkv.k_pad;  // == round_up(D, 64) for every consumer of h
+  MD_CHECK_ARG(Dp >= D && m->blocks[0].proj.k_pad == Dp && m->blocks[0].fc1.k_pad == Dp);
+  MD_TRY(zero_if_padded(w.h, M, Dp, D, s));
+
+  if (crops_kind == MD_CROPS_U8_HWC) {
+    MD_CHECK_ARG(m->pixel_lut != nullptr);
+    MD_TRY(md_patchify_u8(crops, m->pixel_lut, w.patches, kp, n_crops, m->crop, m->patch, s));
+  } else {
+    MD_TRY(md_patchify_bf16(crops, w.patches, kp, n_crops, m->crop, m->patch, s));
+  }
+  // x = patch_emb(patches) + pos_emb          (vision.py:67-68)
+  MD_TRY(gemm(w.patches, kp, m->patch_emb, w.x, D, M, MD_EPI_RESIDUAL, m->pos_emb, D, T, 0, s));
+
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const md_vit_block& b = m->blocks[l];
+    // x = x + attn(ln1(x))                    (vision.py:70, layers.py:155-166)
+    MD_TRY(md_layernorm_bf16(w.x, D, w.h, Dp, &b.ln1, M, D, 1e-5f, s));
+    MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, 3 * D, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));
+    md_attn_args a;
+    const bf16_t* qkv = (const bf16_t*)w.qkv;
+    a.q = qkv;
+    a.k = qkv + D;
+    a.v = qkv + 2 * D;
+    a.o = w.h;
+    a.q_bs = a.k_bs = a.v_bs = (int64_t)T * 3 * D;
+    a.q_ts = a.k_ts = a.v_ts = 3 * D;
+    a.q_hs = a.k_hs = a.v_hs = hd;
+    a.o_bs = (int64_t)T * Dp;
+    a.o_ts = Dp;
+    a.o_hs = hd;
+    a.batch = n_crops;
+    a.n_heads = a.n_kv_heads = m->n_heads;
+    a.head_dim = hd;
+    a.q_len = T;
+    a.kv_len_all = T;
+    a.q_pos0 = nullptr;
+    a.kv_len = nullptr;
+    a.prefix_len = T;  // everything visible: no mask
+    a.scale = scale;
+    MD_TRY(md_attention_prefill(&a, s));
+    MD_TRY(gemm(w.h, Dp, b.proj, w.x, D, M, MD_EPI_RESIDUAL, w.x, D, 0, 0, s));
+    // x = x + mlp(ln2(x))                     (vision.py:71, layers.py:129-146)
+    MD_TRY(md_layernorm_bf16(w.x, D, w.h, Dp, &b.ln2, M, D, 1e-5f, s));
+    MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, b.fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s));
+    MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad);
+    MD_TRY(gemm(w.ff, b.fc1.n_pad, b.fc2, w.x, D, M, MD_EPI_RESIDUAL, w.x, D, 0, 0, s));
+  }
+  return md_layernorm_bf16(w.x, D, out, D, &m->post_ln, M, D, 1e-5f, s);  // vision.py:72
+}
+
+extern "C" size_t md_vision_project_workspace_bytes(const md_vit_model* m, int32_t n_images) {
+  if (!m || n_images <= 0) return 0;
+  const size_t g = m->crop / m->patch, M = (size_t)n_images * g * g;
+  return align_up(M * m->proj_fc1.k_pad * 2) + align_up(M * m->proj_fc1.n_pad * 2);
+}
+
+// reference: moondream.py:213-228 + vision.py:77-89
+extern "C" md_status md_vision_project(const md_vit_model* m, const void* feats, int32_t n_images,
+                                       int32_t tiles_h, int32_t tiles_w, int32_t margin, void* out,
+                                       int64_t ld_out, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  MD_CHECK_ARG(m && feats && out && workspace && n_images > 0 && tiles_h > 0 && tiles_w > 0);
+  if (workspace_bytes < md_vision_project_workspace_bytes(m, n_images)) return MD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = m->crop / m->patch, T = g * g, D = m->dim, M = n_images * T;
+  MD_CHECK_ARG(m->proj_fc1.k == 2 * D && g > 2 * margin);
+  MD_CHECK_ARG(m->proj_fc2.k_pad == m->proj_fc1.n_pad && ld_out >= m->proj_fc2.n);
+  const int Cp = m->proj_fc1.k_pad;
+  Arena a{(char*)workspace, 0};
+  void* cat = a.take((size_t)M * Cp * 2);
+  void* ff = a.take((size_t)M * m->proj_fc1.n_pad * 2);
+  MD_TRY(zero_if_padded(cat, M, Cp, 2 * D, s));
+  MD_TRY(md_stitch_pool_batched(feats, cat, Cp, (int64_t)T * Cp, n_images, D, g, margin, tiles_h,
+                                tiles_w, s));
+  MD_TRY(gemm(cat, Cp, m->proj_fc1, ff, m->proj_fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s));
+  return gemm(ff, m->proj_fc1.n_pad, m->proj_fc2, out, ld_out, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
+}
+
+// the seam form: _vis_proj(g, r) with r already stitched (moondream.py:171-172, vision.py:77-89)
+extern "C" md_status md_vision_project_grid(const md_vit_model* m, const void* global_feats,
+                                            const void* grid_feats, int32_t H, int32_t W, void* out,
+                                            int64_t ld_out, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  MD_CHECK_ARG(m && global_feats && grid_feats && out && workspace && H > 0 && W > 0);
+  if (workspace_bytes < md_vision_project_workspace_bytes(m, 1)) return MD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = m->crop / m->patch, T = g * g, D = m->dim;
+  MD_CHECK_ARG(m->proj_fc1.k == 2 * D && m->proj_fc2.k_pad == m->proj_fc1.n_pad && ld_out >= m->proj_fc2.n);
+  const int Cp = m->proj_fc1.k_pad;
+  Arena a{(char*)workspace, 0};
+  void* cat = a.take((size_t)T * Cp * 2);
+  void* ff = a.take((size_t)T * m->proj_fc1.n_pad * 2);
+  MD_TRY(zero_if_padded(cat, T, Cp, 2 * D, s));
+  MD_TRY(md_pool_grid_concat(global_feats, grid_feats, H, W, cat, Cp, D, g, s));
+  MD_TRY(gemm(cat, Cp, m->proj_fc1, ff, m->proj_fc1.n_pad, T, MD_EPI_GELU, nullptr, 0, 0, 1, s));
+  return gemm(ff, m->proj_fc1.n_pad, m->proj_fc2, out, ld_out, T, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
+}
+
+// -------------------------------------------------------------------- text
+extern "C" size_t md_text_workspace_bytes(const md_text_model* m, int32_t batch, int32_t q_len) {
+  if (!m || !m->blocks || batch <= 0 || q_len <= 0) return 0;
+  return text_layout(m, batch, q_len, nullptr).total;
+}
+
+// reference: text.py:128-160 (text_decoder) with text.py:16-60 (attn)
+extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, void* hidden,
+                                     int32_t batch, int32_t q_len, const int32_t* pos0,
+                                     const md_kv_cache* kv, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  MD_CHECK_ARG(m && x_in && hidden && pos0 && kv && kv->k && kv->v && workspace && m->blocks);
+  MD_CHECK_ARG(batch > 0 && q_len > 0 && m->dim % m->n_heads == 0);
+  const int hd = m->dim / m->n_heads;
+  if (hd != 64) return MD_ERR_UNSUPPORTED;
+  const TextWs w = text_layout(m, batch, q_len, workspace);
+  if (workspace_bytes < w.total) return MD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->dim, M = batch * q_len;
+  const int qkv_w = (m->n_heads + 2 * m->n_kv_heads) * hd;
+  const int Dp = m->blocks[0].qkv.k_pad;
+  MD_CHECK_ARG(Dp >= D && m->blocks[0].proj.k_pad == Dp && m->blocks[0].fc1.k_pad == Dp);
+  MD_TRY(zero_if_padded(w.h, M, Dp, D, s));
+  MD_TRY(zero_if_padded(w.att, M, Dp, D, s));
+  bf16_t* x = (bf16_t*)hidden;
+  if (x_in != hidden) {
+    if (hipMemcpyAsync(hidden, x_in, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return MD_ERR_LAUNCH;
+  }
+  int32_t* kv_len = (int32_t*)w.pos_kv;
+  hipLaunchKernelGGL(kv_len_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pos0, kv_len, q_len, batch);
+  const float scale = 1.0f / sqrtf((float)hd);
+
+  for (int l = 0; l < m->n_layers; ++l) {
+    const md_text_block& b = m->blocks[l];
+    bf16_t* kl = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
+    bf16_t* vl = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
+    // l_in = ln(x)                                            (text.py:145)
+    MD_TRY(md_layernorm_bf16(x, D, w.h, Dp, &b.ln, M, D, 1e-5f, s));
+    // qkv, rope(q), rope(k), cache update                      (text.py:30-46)
+    MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));
+    MD_TRY(md_rope_kv_write(w.qkv, qkv_w, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
+                            q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
+    // attention over the slab                                   (text.py:48-51)
+    if (q_len == 1) {
+      MD_TRY(md_attention_decode(w.qkv, qkv_w, w.att, Dp, kl, vl, kv->batch_stride, kv->ctx, kv_len, batch,
+                                 m->n_heads, m->n_kv_heads, hd, scale, s));
+    } else {
+      md_attn_args a;
+      a.q = w.qkv;
+      a.q_bs = (int64_t)q_len * qkv_w;
+      a.q_ts = qkv_w;
+      a.q_hs = hd;
+      a.k = kl;
+      a.v = vl;
+      a.k_bs = a.v_bs = kv->batch_stride;
+      a.k_ts = a.v_ts = hd;
+      a.k_hs = a.v_hs = (int64_t)kv->ctx * hd;
+      a.o = w.att;
+      a.o_bs = (int64_t)q_len * Dp;
+      a.o_ts = Dp;
+      a.o_hs = hd;
+      a.batch = batch;
+      a.n_heads = m->n_heads;
+      a.n_kv_heads = m->n_kv_heads;
+      a.head_dim = hd;
+      a.q_len = q_len;
+      a.kv_len_all = 0;
+      a.q_pos0 = pos0;
+      a.kv_len = kv_len;
+      a.prefix_len = m->prefix_len;
+      a.scale = scale;
+      MD_TRY(md_attention_prefill(&a, s));
+    }
+    // x = (x + proj(att)) + fc2(gelu(fc1(l_in)))               (text.py:53,157-158)
+    MD_TRY(gemm(w.att, Dp, b.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
+    MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, b.fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s));
+    MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad);
+    MD_TRY(gemm(w.ff, b.fc1.n_pad, b.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
+  }
+  return MD_OK;
+}
+
+extern "C" size_t md_lm_head_workspace_bytes(const md_text_model* m, int32_t batch) {
+  if (!m || batch <= 0) return 0;
+  return align_up((size_t)batch * m->lm_head.k_pad * 2);
+}
+
+// reference: text.py:163-167
+extern "C" md_status md_lm_head(const md_text_model* m, const void* hidden, int32_t batch, int32_t q_len,
+                                void* logits, int64_t ld_logits, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  MD_CHECK_ARG(m && hidden && logits && workspace && batch > 0 && q_len > 0);
+  if (workspace_bytes < md_lm_head_workspace_bytes(m, batch)) return MD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->dim;
+  const bf16_t* last = (const bf16_t*)hidden + (int64_t)(q_len - 1) * D;
+  const int Dp = m->lm_head.k_pad;
+  MD_TRY(zero_if_padded(workspace, batch, Dp, D, s));
+  MD_TRY(md_layernorm_bf16(last, (int64_t)q_len * D, workspace, Dp, &m->post_ln, batch, D, 1e-5f, s));
+  return gemm(workspace, Dp, m->lm_head, logits, ld_logits, batch, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
+}
+
+extern "C" size_t md_decode_workspace_bytes(const md_text_model* m, int32_t batch) {
+  if (!m || !m->blocks || batch <= 0) return 0;
+  return align_up((size_t)batch * m->dim * 2) + md_lm_head_workspace_bytes(m, batch) +
+         text_layout(m, batch, 1, nullptr).total;
+}
+
+// reference: the generator loop body of moondream.py:512-530, device resident
+extern "C" md_status md_decode_step(const md_text_model* m, const int32_t* tokens, int32_t* next,
+                                    int32_t* pos, int32_t batch, const md_kv_cache* kv,
+                                    int32_t suppress_id, void* logits, int64_t ld_logits,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  MD_CHECK_ARG(m && tokens && next && pos && kv && logits && workspace && batch > 0);
+  if (workspace_bytes < md_decode_workspace_bytes(m, batch)) return MD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  Arena a{(char*)workspace, 0};
+  void* x = a.take((size_t)batch * m->dim * 2);
+  void* lmws = a.take(md_lm_head_workspace_bytes(m, batch));
+  void* tws = a.take(0);
+  const size_t tws_bytes = workspace_bytes - a.off;
+  MD_TRY(md_embed_tokens(tokens, m->wte, m->dim, x, m->dim, batch, m->dim, s));
+  MD_TRY(md_text_forward(m, x, x, batch, 1, pos, kv, tws, tws_bytes, s));
+  MD_TRY(md_lm_head(m, x, batch, 1, logits, ld_logits, lmws, md_lm_head_workspace_bytes(m, batch), s));
+  return md_argmax_advance(logits, ld_logits, batch, m->vocab, suppress_id, next, pos, s);
+}

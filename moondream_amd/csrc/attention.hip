@@ -1,0 +1,369 @@
+// Softmax attention kernels.
+//
+//  attn_prefill_kernel<HD>  tiled (flash-style) attention for a block of query
+//     rows on the matrix cores: the ViT encoder (729 x 729, head_dim 72, no
+//     mask; reference layers.py:163) and the decoder prefill against the KV
+//     slab with the prefix-LM visibility rule (reference text.py:48-50, mask of
+//     moondream.py:138-146).
+//  attn_decode_kernel       one query per (sequence, head) over keys [0, kv_len)
+//     of the KV slab: the decode step (reference moondream.py:472-474 +
+//     text.py:48-50); HBM-bandwidth-bound, no matrix cores.
+//
+// Layout of the prefill kernel (wave64, v_mfma_f32_32x32x16_bf16):
+//   workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32
+//   rows.  Keys/values stream through LDS in tiles of 64.
+//   S^T = K Q^T is computed with K as the first MFMA operand, so a lane holds ONE
+//   query row (lane & 31) and 16 of every 32 keys: row max / sum are in-register
+//   plus a single lane^32 exchange, and the per-row rescale factors are per-lane
+//   scalars for both S and the output accumulator.
+//   O^T = V^T P^T: P goes straight from the S accumulator registers into the B
+//   operand (registers 8u..8u+7 of a 32-key block become one bf16x8); the
+//   K-slot -> key permutation this implies (slot (hi, j) <-> key 16u + 4hi +
+//   (j&3) + 8(j>>2)) is applied to the V^T operand's LDS addresses instead of
+//   shuffling P between lanes.
+//   head_dim 72 is handled by LDS-side zero padding only: 80 for the QK^T
+//   contraction (5 K-steps), 96 (3 x 32 rows of V^T) for PV; HBM layouts stay
+//   dense.
+#include "md_common.hpp"
+
+namespace {
+
+struct AttnK {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  bf16_t* o;
+  int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
+  int q_len, kv_len_all, prefix, kv_group;  // kv_group = n_heads / n_kv_heads
+  const int32_t* q_pos0;
+  const int32_t* kv_len;
+  float scale_log2;  // scale * log2(e)
+};
+
+template <int HD>
+struct Cfg {
+  static constexpr int HDP = (HD + 15) / 16 * 16;  // QK^T contraction length (zero padded)
+  static constexpr int KSTEPS = HDP / 16;
+  static constexpr int ND = (HD + 31) / 32;        // 32-row blocks of V^T / O^T
+  static constexpr int KSTR = HDP + 8;             // K tile row stride (elements): 16-B slots rotate by 11 (HD 72) / 9 (HD 64) per row -> conflict-free b128
+  static constexpr int VSTR = 68;                  // V^T row stride: 8-B slots rotate by 17 per row
+  static constexpr int CPR = HD / 8;               // 16-byte chunks per global row
+  static constexpr int K_BYTES = 64 * KSTR * 2;
+  static constexpr int V_BYTES = ND * 32 * VSTR * 2;
+  static constexpr int O_BYTES = 4 * 32 * KSTR * 2;
+  static constexpr int LDS = (K_BYTES + V_BYTES) > O_BYTES ? (K_BYTES + V_BYTES) : O_BYTES;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
+  using C = Cfg<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+  char* Ks = smem;
+  char* Vt = smem + C::K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y, hk = h / p.kv_group;
+  const int q_pos0 = p.q_pos0 ? p.q_pos0[b] : 0;
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.kv_len_all;
+
+  const int q_blk0 = blockIdx.x * 128;
+  const int q_row0 = q_blk0 + wave * 32;
+  const int q_row = min(q_row0 + l31, p.q_len - 1);  // clamp: padding rows replay a valid row
+  const int qpos = q_pos0 + q_row;
+
+  // keys any row of this workgroup may see
+  const int blk_qpos_hi = q_pos0 + min(q_blk0 + 127, p.q_len - 1);
+  const int blk_vis = (blk_qpos_hi < p.prefix) ? max(blk_qpos_hi + 1, p.prefix) : blk_qpos_hi + 1;
+  const int kv_end = min(kv_len, blk_vis);
+  // per-wave bounds for skipping the mask arithmetic on fully visible tiles
+  const int w_qpos_lo = q_pos0 + min(q_row0, p.q_len - 1);
+  const int w_qpos_hi = q_pos0 + min(q_row0 + 31, p.q_len - 1);
+
+  // ---- Q fragments (B operand: column = query row, K-slot = 8 hi + j) ------
+  bf16x8 qf[C::KSTEPS];
+  {
+    const bf16_t* qrow = p.q + (int64_t)b * p.q_bs + (int64_t)q_row * p.q_ts + (int64_t)h * p.q_hs;
+#pragma unroll
+    for (int s = 0; s < C::KSTEPS; ++s) {
+      const int col = 16 * s + 8 * hi;
+      bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[s] = (col < HD) ? *(const bf16x8*)(qrow + col) : z;
+    }
+  }
+
+  // zero the LDS padding that tile loads never touch
+  if (C::HDP > HD) {
+    for (int r = tid; r < 64; r += 256) *(u32x4*)(Ks + r * C::KSTR * 2 + HD * 2) = u32x4{0, 0, 0, 0};
+  }
+  for (int i = tid; i < (C::ND * 32 - HD) * (C::VSTR / 2); i += 256)
+    *(uint32_t*)(Vt + HD * C::VSTR * 2 + i * 4) = 0u;
+
+  f32x16 oacc[C::ND];
+#pragma unroll
+  for (int d = 0; d < C::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const bf16_t* kbase = p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const bf16_t* vbase = p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
+
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K (row-major, padded stride) and V (transposed) -------------
+    for (int c = tid; c < 64 * C::CPR; c += 256) {
+      const int row = c / C::CPR, ch = c % C::CPR;
+      const int j = kv0 + row;
+      u32x4 kq = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
+      if (j < kv_len) {
+        kq = *(const u32x4*)(kbase + (int64_t)j * p.k_ts + ch * 8);
+        vq = *(const u32x4*)(vbase + (int64_t)j * p.v_ts + ch * 8);
+      }
+      *(u32x4*)(Ks + row * C::KSTR * 2 + ch * 16) = kq;
+      bf16_t* vt = (bf16_t*)Vt + (ch * 8) * C::VSTR + row;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vt[(2 * e) * C::VSTR] = (bf16_t)(vq[e] & 0xffffu);
+        vt[(2 * e + 1) * C::VSTR] = (bf16_t)(vq[e] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : two 32-key blocks ------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C::KSTEPS; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + (32 * sub + l31) * C::KSTR * 2 + (16 * s + 8 * hi) * 2);
+        sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[sub], 0, 0, 0);
+      }
+    }
+
+    // ---- scale, mask, online softmax (per lane = per query row) ------------
+    const bool full_vis = (kv0 + 63 <= w_qpos_lo) || (w_qpos_hi < p.prefix && kv0 + 64 <= p.prefix);
+    const bool need_mask = !(full_vis && kv0 + 64 <= kv_len);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = sacc[sub][r] * p.scale_log2;
+        if (need_mask) {
+          const int j = kv0 + 32 * sub + 8 * (r >> 2) + 4 * hi + (r & 3);
+          const bool ok = (j < kv_len) && (j <= qpos || (qpos < p.prefix && j < p.prefix));
+          s = ok ? s : -INFINITY;
+        }
+        sacc[sub][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    // m_new is finite from the first tile on: key 0 is visible to every query
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p0 = __builtin_amdgcn_exp2f(sacc[sub][8 * u + 2 * e] - m_new);
+          const float p1 = __builtin_amdgcn_exp2f(sacc[sub][8 * u + 2 * e + 1] - m_new);
+          psum += p0 + p1;
+          w[e] = pack_bf16x2(p0, p1);
+        }
+        pf[sub][u] = __builtin_bit_cast(bf16x8, w);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < C::ND; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T ------------------------------------------------------
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kcol = 32 * sub + 16 * u + 4 * hi;
+#pragma unroll
+        for (int d = 0; d < C::ND; ++d) {
+          const char* vrow = Vt + (32 * d + l31) * C::VSTR * 2 + kcol * 2;
+          const u32x2 lo = *(const u32x2*)(vrow);
+          const u32x2 hi8 = *(const u32x2*)(vrow + 16);
+          const u32x4 vv = {lo[0], lo[1], hi8[0], hi8[1]};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[sub][u],
+                                                            oacc[d], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- finalize: O / l, transpose through LDS, coalesced row stores ---------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  __syncthreads();
+  char* ot = smem + wave * 32 * C::KSTR * 2;
+#pragma unroll
+  for (int d = 0; d < C::ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 32 * d + 8 * g + 4 * hi;
+      if (col < HD) {
+        u32x2 w;
+        w[0] = pack_bf16x2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+        w[1] = pack_bf16x2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+        *(u32x2*)(ot + l31 * C::KSTR * 2 + col * 2) = w;
+      }
+    }
+  bf16_t* obase = p.o + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs;
+  for (int idx = lane; idx < 32 * C::CPR; idx += 64) {
+    const int row = idx / C::CPR, ch = idx % C::CPR;
+    if (q_row0 + row < p.q_len) {
+      const u32x4 v = *(const u32x4*)(ot + row * C::KSTR * 2 + ch * 16);
+      *(u32x4*)(obase + (int64_t)(q_row0 + row) * p.o_ts + ch * 8) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// decode: one query row per (sequence, head)
+// ---------------------------------------------------------------------------
+// 8 lanes cover one 128-byte key/value row (8 x 16 B); a wave covers 8 rows per
+// load instruction, the 4 waves of the workgroup interleave rows mod 32.
+// Pass 1 streams K (scores -> LDS, running max), pass 2 streams V.
+constexpr int DEC_MAX_CTX = 2048;
+
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                          bf16_t* __restrict__ o, int64_t ldo,
+                                                          const bf16_t* __restrict__ kslab,
+                                                          const bf16_t* __restrict__ vslab,
+                                                          int64_t slab_bs, int ctx, const int32_t* kv_len_p,
+                                                          int n_heads, int kv_group, float scale_log2) {
+  __shared__ float sc[DEC_MAX_CTX];
+  __shared__ float red[4][8][64 + 1];
+  __shared__ float red_m[4], red_l[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 3, c = lane & 7;
+  const int b = blockIdx.y, h = blockIdx.x, hk = h / kv_group;
+  const int kv_len = kv_len_p[b];
+
+  float qv[8];
+  {
+    const u32x4 qq = *(const u32x4*)(q + (int64_t)b * ldq + h * 64 + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qv[2 * e] = lo_bf(qq[e]) * scale_log2;
+      qv[2 * e + 1] = hi_bf(qq[e]) * scale_log2;
+    }
+  }
+  const bf16_t* kb = kslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
+  const bf16_t* vb = vslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
+
+  // ---- pass 1: scores --------------------------------------------------------
+  float mx = -INFINITY;
+  for (int j = wave * 8 + g; j < kv_len; j += 32) {
+    const u32x4 kq = *(const u32x4*)(kb + (int64_t)j * 64 + c * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += qv[2 * e] * lo_bf(kq[e]) + qv[2 * e + 1] * hi_bf(kq[e]);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (c == 0) sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red_m[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+
+  // ---- pass 2: probabilities and P.V ----------------------------------------
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float l = 0.f;
+  for (int j = wave * 8 + g; j < kv_len; j += 32) {
+    const float pj = __builtin_amdgcn_exp2f(sc[j] - mx);
+    l += pj;
+    const float pr = bf2f(f2bf(pj));  // probabilities enter the second contraction as bf16
+    const u32x4 vq = *(const u32x4*)(vb + (int64_t)j * 64 + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[2 * e] += pr * lo_bf(vq[e]);
+      acc[2 * e + 1] += pr * hi_bf(vq[e]);
+    }
+  }
+  // every lane of a row group added the same p: count it once (lanes c == 0)
+  l = (c == 0) ? l : 0.f;
+  l = wave_sum(l);
+  if (lane == 0) red_l[wave] = l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][g][c * 8 + e] = acc[e];
+  __syncthreads();
+  if (tid < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) s += red[w][gg][tid];
+    const float lt = red_l[0] + red_l[1] + red_l[2] + red_l[3];
+    o[(int64_t)b * ldo + h * 64 + tid] = f2bf(lt > 0.f ? s / lt : 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
+  MD_CHECK_ARG(a && a->q && a->k && a->v && a->o);
+  MD_CHECK_ARG(a->batch > 0 && a->n_heads > 0 && a->n_kv_heads > 0 && a->q_len > 0);
+  MD_CHECK_ARG(a->n_heads % a->n_kv_heads == 0);
+  MD_CHECK_ARG(a->head_dim == 64 || a->head_dim == 72);
+  const int64_t strides[] = {a->q_bs, a->q_ts, a->q_hs, a->k_bs, a->k_ts, a->k_hs,
+                             a->v_bs, a->v_ts, a->v_hs, a->o_bs, a->o_ts, a->o_hs};
+  for (int64_t s : strides) MD_CHECK_ARG(s % 8 == 0);
+  MD_CHECK_ARG((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o) & 15) == 0);
+  AttnK k;
+  k.q = (const bf16_t*)a->q;
+  k.k = (const bf16_t*)a->k;
+  k.v = (const bf16_t*)a->v;
+  k.o = (bf16_t*)a->o;
+  k.q_bs = a->q_bs; k.q_ts = a->q_ts; k.q_hs = a->q_hs;
+  k.k_bs = a->k_bs; k.k_ts = a->k_ts; k.k_hs = a->k_hs;
+  k.v_bs = a->v_bs; k.v_ts = a->v_ts; k.v_hs = a->v_hs;
+  k.o_bs = a->o_bs; k.o_ts = a->o_ts; k.o_hs = a->o_hs;
+  k.q_len = a->q_len;
+  k.kv_len_all = a->kv_len_all;
+  k.prefix = a->prefix_len;
+  k.kv_group = a->n_heads / a->n_kv_heads;
+  k.q_pos0 = a->q_pos0;
+  k.kv_len = a->kv_len;
+  k.scale_log2 = a->scale * 1.4426950408889634f;
+  dim3 grid((a->q_len + 127) / 128, a->n_heads, a->batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->head_dim == 72)
+    hipLaunchKernelGGL(attn_prefill_kernel<72>, grid, dim3(256), 0, s, k);
+  else
+    hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, s, k);
+  return md_launch_status();
+}
+
+extern "C" md_status md_attention_decode(const void* q, int64_t ldq, void* o, int64_t ldo,
+                                         const void* k_slab, const void* v_slab,
+                                         int64_t slab_batch_stride, int32_t ctx, const int32_t* kv_len,
+                                         int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                                         int32_t head_dim, float scale, void* stream) {
+  MD_CHECK_ARG(q && o && k_slab && v_slab && kv_len);
+  MD_CHECK_ARG(head_dim == 64 && ctx <= DEC_MAX_CTX && batch > 0 && n_heads % n_kv_heads == 0);
+  MD_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && ldq >= n_heads * 64 && ldo >= n_heads * 64);
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (const bf16_t*)k_slab, (const bf16_t*)v_slab,
+                     slab_batch_stride, ctx, kv_len, n_heads, n_heads / n_kv_heads,
+                     scale * 1.4426950408889634f);
+  return md_launch_status();
+}

@@ -1,0 +1,395 @@
+// HBM-bound helpers around the GEMMs: LayerNorm, patch extraction, partial RoPE
+// + KV-slab write, token embedding gather, greedy argmax, crop stitch + pool.
+// All of them move 16 bytes per lane per access (8 bf16) and do their
+// arithmetic in fp32 with exactly one rounding to bf16 per reference op.
+#include "md_common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row lives in registers between the two
+// reductions (reference: layers.py:118-119 -> F.layer_norm; biased variance).
+// ---------------------------------------------------------------------------
+template <int NCH>  // 16-byte chunks per lane; covers dim <= 512 * NCH
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                        bf16_t* __restrict__ y, int64_t ldy,
+                                                        const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ bia, int rows,
+                                                        int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = dim >> 3;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    u32x4 q = {0, 0, 0, 0};
+    if (ch < nchunk) q = *(const u32x4*)(xr + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][2 * e] = lo_bf(q[e]);
+      v[i][2 * e + 1] = hi_bf(q[e]);
+      sum += v[i][2 * e] + v[i][2 * e + 1];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)dim;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)dim + eps);
+  bf16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+      const u32x4 wq = *(const u32x4*)(w + ch * 8);
+      const u32x4 bq = *(const u32x4*)(bia + ch * 8);
+      u32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = (v[i][2 * e] - mean) * rstd * lo_bf(wq[e]) + lo_bf(bq[e]);
+        const float c = (v[i][2 * e + 1] - mean) * rstd * hi_bf(wq[e]) + hi_bf(bq[e]);
+        out[e] = pack_bf16x2(a, c);
+      }
+      *(u32x4*)(yr + ch * 8) = out;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Patch extraction.  One workgroup per patch row of the GEMM operand:
+// out[(n*G*G + gy*G + gx)][c*P*P + py*P + px]   (reference: vision.py:44-61)
+// ---------------------------------------------------------------------------
+template <bool FROM_U8>
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ src,
+                                                       const bf16_t* __restrict__ lut,
+                                                       bf16_t* __restrict__ out, int64_t ld_out,
+                                                       int crop, int patch, int grid) {
+  const int prow = blockIdx.x;
+  const int n = prow / (grid * grid), gy = (prow / grid) % grid, gx = prow % grid;
+  const int pp = patch * patch, feat = 3 * pp;
+  bf16_t* o = out + (int64_t)prow * ld_out;
+  for (int f = threadIdx.x; f < ld_out; f += 256) {
+    bf16_t val = 0;
+    if (f < feat) {
+      const int c = f / pp, py = (f % pp) / patch, px = f % patch;
+      const int y = gy * patch + py, xx = gx * patch + px;
+      if (FROM_U8) {
+        const uint8_t* s = (const uint8_t*)src;
+        val = lut[s[(((int64_t)n * crop + y) * crop + xx) * 3 + c]];
+      } else {
+        const bf16_t* s = (const bf16_t*)src;
+        val = s[(((int64_t)n * 3 + c) * crop + y) * crop + xx];
+      }
+    }
+    o[f] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Partial RoPE + KV write.  One workgroup per token row of the fused qkv
+// activation.  (reference: rope.py:20-48, text.py:35-46, moondream.py:74-78)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kv_kernel(bf16_t* __restrict__ qkv, int64_t ld,
+                                                      const float* __restrict__ freqs,
+                                                      const int32_t* __restrict__ pos0,
+                                                      bf16_t* __restrict__ kslab,
+                                                      bf16_t* __restrict__ vslab, int64_t slab_bs,
+                                                      int ctx, int q_len, int n_heads,
+                                                      int n_kv_heads, int hd, int rot) {
+  const int tok = blockIdx.x;
+  const int b = tok / q_len, t = tok % q_len;
+  const int pos = pos0[b] + t;
+  bf16_t* row = qkv + (int64_t)tok * ld;
+  const int half = rot >> 1;
+  const float* fr = freqs + (int64_t)pos * half * 2;
+  const int n_rot_heads = n_heads + n_kv_heads;
+
+  // rotated pairs: thread -> (head, j).  Input is half-split (re = x[j],
+  // im = x[half + j]); output is interleaved (x'[2j], x'[2j+1]).  All inputs of
+  // a head are read before any output is written: the unit of work is a whole
+  // head per group of `half` consecutive threads and the barrier below
+  // separates the phases.
+  const int items = n_rot_heads * half;
+  float o_re[4], o_im[4];  // up to 4 items per thread (items <= 1024 checked on the host)
+
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int it = threadIdx.x + 256 * u;
+    if (it >= items) break;
+    const int head = it / half, j = it % half;
+    const bf16_t* hp = row + head * hd;
+    const float re = bf2f(hp[j]), im = bf2f(hp[half + j]);
+    const float c = fr[2 * j], s = fr[2 * j + 1];
+    // separate fp32 roundings, as torch evaluates mul, mul, sub / add
+    o_re[u] = __fsub_rn(__fmul_rn(re, c), __fmul_rn(im, s));
+    o_im[u] = __fadd_rn(__fmul_rn(re, s), __fmul_rn(im, c));
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int it = threadIdx.x + 256 * u;
+    if (it >= items) break;
+    const int head = it / half, j = it % half;
+    const uint32_t w = pack_bf16x2(o_re[u], o_im[u]);
+    if (head < n_heads) {
+      *(uint32_t*)(row + head * hd + 2 * j) = w;  // q stays in the activation, rotated in place
+    } else {
+      const int hk = head - n_heads;
+      *(uint32_t*)(kslab + (int64_t)b * slab_bs + ((int64_t)hk * ctx + pos) * hd + 2 * j) = w;
+    }
+  }
+  // pass-through half of k, and all of v, in 16-byte chunks
+  const int cpk = (hd - rot) >> 3, cpv = hd >> 3;
+  for (int it = threadIdx.x; it < n_kv_heads * cpk; it += 256) {
+    const int hk = it / cpk, ch = it % cpk;
+    const u32x4 q = *(const u32x4*)(row + (n_heads + hk) * hd + rot + ch * 8);
+    *(u32x4*)(kslab + (int64_t)b * slab_bs + ((int64_t)hk * ctx + pos) * hd + rot + ch * 8) = q;
+  }
+  for (int it = threadIdx.x; it < n_kv_heads * cpv; it += 256) {
+    const int hk = it / cpv, ch = it % cpv;
+    const u32x4 q = *(const u32x4*)(row + (n_heads + n_kv_heads + hk) * hd + ch * 8);
+    *(u32x4*)(vslab + (int64_t)b * slab_bs + ((int64_t)hk * ctx + pos) * hd + ch * 8) = q;
+  }
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
+                                                    const bf16_t* __restrict__ table, int64_t ldt,
+                                                    bf16_t* __restrict__ out, int64_t ldo, int dim) {
+  const int i = blockIdx.x;
+  const bf16_t* src = table + (int64_t)ids[i] * ldt;
+  bf16_t* dst = out + (int64_t)i * ldo;
+  for (int ch = threadIdx.x; ch < (dim >> 3); ch += 256)
+    *(u32x4*)(dst + ch * 8) = *(const u32x4*)(src + ch * 8);
+}
+
+// greedy argmax, ties -> lowest index; optionally bumps pos[b]
+__global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t ld,
+                                                     int vocab, int suppress, int32_t* __restrict__ next,
+                                                     int32_t* __restrict__ pos_inc) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.x;
+  const bf16_t* lr = logits + (int64_t)b * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int ch = threadIdx.x; ch < (vocab >> 3); ch += 256) {
+    const u32x4 q = *(const u32x4*)(lr + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = ch * 8 + e;
+      float v = (e & 1) ? hi_bf(q[e >> 1]) : lo_bf(q[e >> 1]);
+      if (idx == suppress) v = -INFINITY;
+      if (v > best || (v == best && idx < bi)) {
+        best = v;
+        bi = idx;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = best;
+    si[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+        best = sv[w];
+        bi = si[w];
+      }
+    next[b] = bi;
+    if (pos_inc) pos_inc[b] += 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stitch + adaptive average pool + concat.  grid (g*g, n_images).
+// stitched(y, x) comes from local crop (ty, tx) at (y - ty*inner, x - tx*inner)
+// where a crop keeps its interior plus the outer margin on image borders
+// (reference: image_crops.py:170-231 with patch_size=1); pooling bin i covers
+// [floor(i*H/g), ceil((i+1)*H/g)) (reference: vision.py:83-86).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stitch_pool_kernel(const bf16_t* __restrict__ feats,
+                                                          const bf16_t* __restrict__ grid_in,
+                                                          bf16_t* __restrict__ out, int64_t ld_out,
+                                                          int64_t out_img_stride, int dim, int g,
+                                                          int margin, int th, int tw, int H_in,
+                                                          int W_in) {
+  // grid_in != nullptr: the local features are an ALREADY stitched [H_in][W_in][dim]
+  // grid (the reference seam's _vis_proj(g, r) form) and feats is the global crop only.
+  const int p = blockIdx.x, img = blockIdx.y;
+  const int pi = p / g, pj = p % g;
+  const int inner = g - 2 * margin;
+  const int H = grid_in ? H_in : inner * th + 2 * margin;
+  const int W = grid_in ? W_in : inner * tw + 2 * margin;
+  const int y0 = (pi * H) / g, y1 = ((pi + 1) * H + g - 1) / g;
+  const int x0 = (pj * W) / g, x1 = ((pj + 1) * W + g - 1) / g;
+  const int64_t crop_sz = (int64_t)g * g * dim;
+  const bf16_t* fimg = feats + (grid_in ? 0 : (int64_t)img * (1 + th * tw) * crop_sz);
+  bf16_t* o = out + (int64_t)img * out_img_stride + (int64_t)p * ld_out;
+  // sum / count, the form torch's adaptive_avg_pool2d uses
+  const float cnt = (float)((y1 - y0) * (x1 - x0));
+  for (int ch = threadIdx.x; ch < (dim >> 3); ch += 256) {
+    // global crop features
+    *(u32x4*)(o + ch * 8) = *(const u32x4*)(fimg + (int64_t)p * dim + ch * 8);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int y = y0; y < y1; ++y) {
+      const int ty = (y < margin) ? 0 : min((y - margin) / inner, th - 1);
+      const int ly = y - ty * inner;
+      for (int x = x0; x < x1; ++x) {
+        const bf16_t* s;
+        if (grid_in) {
+          s = grid_in + ((int64_t)y * W + x) * dim + ch * 8;
+        } else {
+          const int tx = (x < margin) ? 0 : min((x - margin) / inner, tw - 1);
+          const int lx = x - tx * inner;
+          s = fimg + (int64_t)(1 + ty * tw + tx) * crop_sz + ((int64_t)ly * g + lx) * dim + ch * 8;
+        }
+        const u32x4 q = *(const u32x4*)s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] += lo_bf(q[e]);
+          acc[2 * e + 1] += hi_bf(q[e]);
+        }
+      }
+    }
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(acc[2 * e] / cnt, acc[2 * e + 1] / cnt);
+    *(u32x4*)(o + dim + ch * 8) = w;
+  }
+}
+
+}  // namespace
+
+extern "C" md_status md_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy,
+                                       const md_layernorm* p, int32_t rows, int32_t dim, float eps,
+                                       void* stream) {
+  MD_CHECK_ARG(x && y && p && p->w && p->b && rows > 0);
+  MD_CHECK_ARG(dim % 8 == 0 && dim > 0 && dim <= 4096 && ldx % 8 == 0 && ldy % 8 == 0);
+  MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)p->w | (uintptr_t)p->b) & 15) == 0);
+  dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* xx = (const bf16_t*)x;
+  bf16_t* yy = (bf16_t*)y;
+  const bf16_t* w = (const bf16_t*)p->w;
+  const bf16_t* b = (const bf16_t*)p->b;
+  if (dim <= 512)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, xx, ldx, yy, ldy, w, b, rows, dim, eps);
+  else if (dim <= 1536)
+    hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, xx, ldx, yy, ldy, w, b, rows, dim, eps);
+  else if (dim <= 2560)
+    hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, s, xx, ldx, yy, ldy, w, b, rows, dim, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, xx, ldx, yy, ldy, w, b, rows, dim, eps);
+  return md_launch_status();
+}
+
+extern "C" md_status md_patchify_u8(const void* crops_u8, const void* lut_bf16, void* out,
+                                    int64_t ld_out, int32_t n_crops, int32_t crop, int32_t patch,
+                                    void* stream) {
+  MD_CHECK_ARG(crops_u8 && lut_bf16 && out && n_crops > 0 && patch > 0 && crop % patch == 0);
+  MD_CHECK_ARG(ld_out >= 3 * patch * patch);
+  const int g = crop / patch;
+  hipLaunchKernelGGL(patchify_kernel<true>, dim3(n_crops * g * g), dim3(256), 0, (hipStream_t)stream,
+                     crops_u8, (const bf16_t*)lut_bf16, (bf16_t*)out, ld_out, crop, patch, g);
+  return md_launch_status();
+}
+
+extern "C" md_status md_patchify_bf16(const void* crops, void* out, int64_t ld_out, int32_t n_crops,
+                                      int32_t crop, int32_t patch, void* stream) {
+  MD_CHECK_ARG(crops && out && n_crops > 0 && patch > 0 && crop % patch == 0);
+  MD_CHECK_ARG(ld_out >= 3 * patch * patch);
+  const int g = crop / patch;
+  hipLaunchKernelGGL(patchify_kernel<false>, dim3(n_crops * g * g), dim3(256), 0, (hipStream_t)stream,
+                     crops, (const bf16_t*)nullptr, (bf16_t*)out, ld_out, crop, patch, g);
+  return md_launch_status();
+}
+
+extern "C" md_status md_rope_kv_write(void* qkv, int64_t ld, const float* freqs, const int32_t* pos0,
+                                      void* k_slab, void* v_slab, int64_t slab_batch_stride,
+                                      int32_t ctx, int32_t batch, int32_t q_len, int32_t n_heads,
+                                      int32_t n_kv_heads, int32_t head_dim, int32_t rot_dim,
+                                      void* stream) {
+  MD_CHECK_ARG(qkv && freqs && pos0 && k_slab && v_slab && batch > 0 && q_len > 0);
+  MD_CHECK_ARG(head_dim % 8 == 0 && rot_dim % 8 == 0 && rot_dim <= head_dim && ld % 8 == 0);
+  MD_CHECK_ARG((n_heads + n_kv_heads) * (rot_dim / 2) <= 1024);
+  MD_CHECK_ARG(ld >= (int64_t)(n_heads + 2 * n_kv_heads) * head_dim);
+  hipLaunchKernelGGL(rope_kv_kernel, dim3(batch * q_len), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)qkv, ld, freqs, pos0, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                     slab_batch_stride, ctx, q_len, n_heads, n_kv_heads, head_dim, rot_dim);
+  return md_launch_status();
+}
+
+extern "C" md_status md_embed_tokens(const int32_t* ids, const void* table, int64_t ld_table, void* out,
+                                     int64_t ld_out, int32_t n, int32_t dim, void* stream) {
+  MD_CHECK_ARG(ids && table && out && n > 0 && dim % 8 == 0 && ld_table % 8 == 0 && ld_out % 8 == 0);
+  hipLaunchKernelGGL(embed_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ids,
+                     (const bf16_t*)table, ld_table, (bf16_t*)out, ld_out, dim);
+  return md_launch_status();
+}
+
+// internal (api.hip): argmax that also advances pos
+md_status md_argmax_advance(const void* logits, int64_t ld, int32_t batch, int32_t vocab,
+                            int32_t suppress_id, int32_t* next, int32_t* pos, hipStream_t stream) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(batch), dim3(256), 0, stream, (const bf16_t*)logits, ld, vocab,
+                     suppress_id, next, pos);
+  return md_launch_status();
+}
+
+extern "C" md_status md_argmax_bf16(const void* logits, int64_t ld, int32_t batch, int32_t vocab,
+                                    int32_t suppress_id, int32_t* next, void* stream) {
+  MD_CHECK_ARG(logits && next && batch > 0 && vocab > 0 && vocab % 8 == 0 && ld % 8 == 0);
+  return md_argmax_advance(logits, ld, batch, vocab, suppress_id, next, nullptr, (hipStream_t)stream);
+}
+
+// internal: batched form used by md_vision_project
+md_status md_stitch_pool_batched(const void* feats, void* out, int64_t ld_out, int64_t out_img_stride,
+                                 int32_t n_images, int32_t dim, int32_t grid, int32_t margin,
+                                 int32_t tiles_h, int32_t tiles_w, hipStream_t stream) {
+  hipLaunchKernelGGL(stitch_pool_kernel, dim3(grid * grid, n_images), dim3(256), 0, stream,
+                     (const bf16_t*)feats, (const bf16_t*)nullptr, (bf16_t*)out, ld_out, out_img_stride,
+                     dim, grid, margin, tiles_h, tiles_w, 0, 0);
+  return md_launch_status();
+}
+
+// internal: pool an already stitched [H][W][dim] grid (the _vis_proj(g, r) seam form)
+md_status md_pool_grid_concat(const void* global_feats, const void* grid_feats, int32_t H, int32_t W,
+                              void* out, int64_t ld_out, int32_t dim, int32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(stitch_pool_kernel, dim3(grid * grid, 1), dim3(256), 0, stream,
+                     (const bf16_t*)global_feats, (const bf16_t*)grid_feats, (bf16_t*)out, ld_out,
+                     (int64_t)0, dim, grid, 0, 1, 1, H, W);
+  return md_launch_status();
+}
+
+extern "C" md_status md_stitch_pool_concat(const void* feats, void* out, int64_t ld_out, int32_t dim,
+                                           int32_t grid, int32_t margin, int32_t tiles_h,
+                                           int32_t tiles_w, void* stream) {
+  MD_CHECK_ARG(feats && out && dim % 8 == 0 && ld_out >= 2 * dim && ld_out % 8 == 0);
+  MD_CHECK_ARG(grid > 2 * margin && tiles_h > 0 && tiles_w > 0);
+  return md_stitch_pool_batched(feats, out, ld_out, 0, 1, dim, grid, margin, tiles_h, tiles_w,
+                                (hipStream_t)stream);
+}

@@ -1,0 +1,303 @@
+// bf16 GEMM on the CDNA4 matrix cores:  C = epilogue(A . W^T + b)
+//
+// This is the kernel that carries ~90 % of the encode FLOPs (SURVEY.md section
+// 8a rows a4/a6/a9/a12: every nn.Linear of the ViT, the projector and the
+// decoder prefill).  Both operands are K-contiguous (activations [M,K], weights
+// in the nn.Linear layout [N,K]), so both MFMA fragments are plain 16-byte
+// K-runs of one row.
+//
+// Structure (one workgroup = one BM x BN tile of C, 64-wide wavefronts):
+//   * K is walked in 64-element slices.  A and W slices are copied HBM/L2 -> LDS
+//     by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) into a 2-deep
+//     ring; slice t+1 is in flight while slice t feeds the matrix cores.
+//   * LDS image per operand: [rows][8 x 16 B], 16-byte chunk c of row r stored
+//     at physical chunk c ^ ((r >> 1) & 7).  LDS-DMA writes lane-linear, so the
+//     permutation is applied on the per-lane SOURCE address and again on the
+//     ds_read_b128 address; the 16-lane groups of a b128 read then touch 16
+//     distinct 16-byte bank slots (conflict-free).
+//   * v_mfma_f32_32x32x16_bf16 with the weight fragment as the first operand:
+//     the accumulator then holds, per lane, one row m and runs of 4 consecutive
+//     columns n, so (acc + bias) packs straight into 8-byte bf16 quads.
+//   * epilogue: bias add in fp32, ONE rounding to bf16 (the reference's
+//     F.linear rounding point), transposition through a wave-private LDS tile,
+//     then GELU / residual add on whole 16-byte row segments with fully
+//     coalesced global traffic.
+//   * workgroup id -> tile: XCD-contiguous remap, then grouped (8 row panels x
+//     n) ordering so the 32 CUs of one XCD work on a compact 2-D block of
+//     tiles and share A/W slices through their private L2.
+#include "md_common.hpp"
+
+namespace {
+
+struct GemmK {
+  const bf16_t* A;
+  const bf16_t* W;
+  const bf16_t* bias;
+  const bf16_t* R;
+  bf16_t* C;
+  int64_t lda, ldw, ldc, ldr;
+  int M, n_store, n_pad, K;
+  int tiles_m, tiles_n;
+  int res_row_mod;
+};
+
+constexpr int BK = 64;           // K slice (elements) = 128 B per row
+constexpr int ROW_BYTES = BK * 2;
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  static_assert(TN == 64, "epilogue transposes 32 x 64 wave tiles");
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;  // 16-byte LDS-DMA pieces per thread
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // ---- workgroup -> tile -------------------------------------------------
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int L = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (L / per_group) * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (L % per_group) % gsz;
+  const int tn = (L % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-thread LDS-DMA source pointers (advance 128 B per K slice) -----
+  const char* a_src[NA];
+  const char* b_src[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int slot = j * NT + tid, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    const int64_t row = min(m0 + r, p.M - 1);
+    a_src[j] = (const char*)(p.A + row * p.lda + c * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int slot = j * NT + tid, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    const int64_t row = min(n0 + r, p.n_pad - 1);
+    b_src[j] = (const char*)(p.W + row * p.ldw + c * 8);
+  }
+
+  auto stage_load = [&](int stage) {
+    char* base = smem + stage * STAGE + wave * (64 * 16);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_src[j],
+                                       (__attribute__((address_space(3))) void*)(base + j * NT * 16),
+                                       16, 0, 0);
+      a_src[j] += ROW_BYTES;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)b_src[j],
+          (__attribute__((address_space(3))) void*)(base + A_BYTES + j * NT * 16), 16, 0, 0);
+      b_src[j] += ROW_BYTES;
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets: row = (tile row base, multiple of 32) + l31, so the
+  // swizzle term (row >> 1) & 7 depends on the lane only
+  const int swz = (l31 >> 1) & 7;
+  const int a_row_off = (wm * TM + l31) * ROW_BYTES;
+  const int b_row_off = A_BYTES + (wn * TN + l31) * ROW_BYTES;
+
+  const int nk = p.K / BK;
+  stage_load(0);
+  for (int t = 0; t < nk; ++t) {
+    // slice t has landed (own DMA: vmcnt; everybody's: barrier); the barrier also
+    // fences the previous iteration's reads of the buffer refilled below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nk) stage_load((t + 1) & 1);
+    const char* st = smem + (t & 1) * STAGE;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int coff = ((2 * s + hi) ^ swz) * 16;
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *(const bf16x8*)(st + a_row_off + i * 32 * ROW_BYTES + coff);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bfr[j] = *(const bf16x8*)(st + b_row_off + j * 32 * ROW_BYTES + coff);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------
+  // acc[i][j][r]: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)
+  __syncthreads();  // all waves are done reading the operand ring
+  char* tile = smem + wave * 4096;  // wave-private 32 x 64 bf16 transposition tile
+  const int wn0 = n0 + wn * TN;
+
+  float bias_v[NI][4][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = wn0 + 32 * j + 8 * g + 4 * hi;
+      u32x2 bw = {0u, 0u};
+      if (p.bias != nullptr && n < p.n_pad) bw = *(const u32x2*)(p.bias + n);
+      bias_v[j][g][0] = lo_bf(bw[0]);
+      bias_v[j][g][1] = hi_bf(bw[0]);
+      bias_v[j][g][2] = lo_bf(bw[1]);
+      bias_v[j][g][3] = hi_bf(bw[1]);
+    }
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = pack_bf16x2(acc[i][j][4 * g + 0] + bias_v[j][g][0], acc[i][j][4 * g + 1] + bias_v[j][g][1]);
+        w[1] = pack_bf16x2(acc[i][j][4 * g + 2] + bias_v[j][g][2], acc[i][j][4 * g + 3] + bias_v[j][g][3]);
+        const int ch = 4 * j + g;
+        *(u32x2*)(tile + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8) = w;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+      u32x4 v = *(const u32x4*)(tile + row * 128 + ((ch ^ (row & 7)) * 16));
+      const int m = m0 + wm * TM + 32 * i + row;
+      const int n = wn0 + ch * 8;
+      if (m < p.M && n < p.n_store) {
+        if constexpr (EPI == MD_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = pack_bf16x2(gelu_tanh_f32(lo_bf(v[e])), gelu_tanh_f32(hi_bf(v[e])));
+        } else if constexpr (EPI == MD_EPI_RESIDUAL) {
+          const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
+          const u32x4 rv = *(const u32x4*)(p.R + rrow * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = pack_bf16x2(lo_bf(rv[e]) + lo_bf(v[e]), hi_bf(rv[e]) + hi_bf(v[e]));
+        }
+        *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+md_status launch_cfg(const GemmK& k, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int ring = 2 * (BM + BN) * ROW_BYTES;
+  constexpr int epi = WM * WN * 4096;
+  constexpr int lds = ring > epi ? ring : epi;
+  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return MD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  GemmK kk = k;
+  kk.tiles_m = (k.M + BM - 1) / BM;
+  kk.tiles_n = (k.n_store + BN - 1) / BN;
+  hipLaunchKernelGGL(fn, dim3(kk.tiles_m * kk.tiles_n), dim3(NT), lds, stream, kk);
+  return md_launch_status();
+}
+
+template <int EPI>
+md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
+  switch (tile) {
+    case 0: return launch_cfg<256, 256, 2, 4, EPI>(k, stream);
+    case 1: return launch_cfg<256, 128, 4, 2, EPI>(k, stream);
+    default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
+  }
+}
+
+// Tile choice: estimated time ~ (waves of workgroups over 256 CUs) x tile area /
+// per-config efficiency.  Independent of anything but (M, N), so a given layer
+// always runs the same kernel -- and every config accumulates K in the same
+// order (sequential 16-wide MFMA steps), so results do not depend on it.
+int pick_tile(int M, int n_store) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("MD_GEMM_TILE");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced >= 0) return forced;
+  const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 128};
+  const double eff[3] = {1.0, 0.85, 0.7};
+  const int slots[3] = {256, 256, 512};
+  int best = 2;
+  double best_cost = 1e300;
+  for (int c = 0; c < 3; ++c) {
+    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((n_store + bn[c] - 1) / bn[c]);
+    const long rounds = (tiles + slots[c] - 1) / slots[c];
+    const double cost = (double)rounds * slots[c] * bm[c] * bn[c] / eff[c];
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = c;
+    }
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
+  MD_CHECK_ARG(a && a->a && a->c && a->lin.w);
+  MD_CHECK_ARG(a->m > 0 && a->lin.n > 0 && a->lin.k > 0);
+  MD_CHECK_ARG(a->lin.k_pad % BK == 0 && a->lin.k_pad >= a->lin.k);
+  MD_CHECK_ARG(a->lin.n_pad % 64 == 0 && a->lin.n_pad >= a->lin.n && a->lin.n % 8 == 0);
+  MD_CHECK_ARG(a->lda >= a->lin.k_pad && a->lda % 8 == 0 && a->ldc % 8 == 0);
+  MD_CHECK_ARG(((uintptr_t)a->a & 15) == 0 && ((uintptr_t)a->c & 15) == 0 && ((uintptr_t)a->lin.w & 15) == 0);
+  GemmK k;
+  k.A = (const bf16_t*)a->a;
+  k.W = (const bf16_t*)a->lin.w;
+  k.bias = (const bf16_t*)a->lin.b;
+  k.R = (const bf16_t*)a->r;
+  k.C = (bf16_t*)a->c;
+  k.lda = a->lda;
+  k.ldw = a->lin.k_pad;
+  k.ldc = a->ldc;
+  k.ldr = a->ldr;
+  k.M = a->m;
+  k.n_pad = a->lin.n_pad;
+  k.n_store = a->store_pad_cols ? a->lin.n_pad : a->lin.n;
+  MD_CHECK_ARG(a->ldc >= k.n_store);
+  k.K = a->lin.k_pad;
+  k.res_row_mod = a->res_row_mod;
+  k.tiles_m = k.tiles_n = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int tile = pick_tile(k.M, k.n_store);
+  switch (a->epilogue) {
+    case MD_EPI_BIAS: return launch_epi<MD_EPI_BIAS>(k, tile, s);
+    case MD_EPI_GELU: return launch_epi<MD_EPI_GELU>(k, tile, s);
+    case MD_EPI_RESIDUAL:
+      MD_CHECK_ARG(a->r != nullptr && a->ldr % 8 == 0 && ((uintptr_t)a->r & 15) == 0);
+      return launch_epi<MD_EPI_RESIDUAL>(k, tile, s);
+    default: return MD_ERR_INVALID_ARG;
+  }
+}

@@ -1,0 +1,76 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave64,
+// v_cvt_pk_bf16_f32, MFMA 32x32x16 bf16, LDS-DMA (global_load_lds_dwordx4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/moondream_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits everywhere; arithmetic is fp32
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // one 32x32 accumulator tile
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define MD_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even; lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// GELU(tanh) in the algebraically equal sigmoid form
+//   0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3)
+// (reference: layers.py:24-25, F.gelu(approximate="tanh") evaluated in fp32).  No
+// cancellation for large |u| and a single v_exp + v_rcp.
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+  const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
+  const float kKappa = 0.044715f;
+  float u = kBeta * (x + kKappa * x * x * x);
+  float e = __expf(-2.0f * u);
+  return __fdividef(x, 1.0f + e);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware remap of a linear workgroup id: hardware places block b on XCD b % 8,
+// so give every XCD a contiguous chunk of the logical tile sequence (neighbouring
+// tiles share operand panels -> hit the same private L2).  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int xcd = bid % nx, idx = bid / nx;
+  int q = nwg / nx, r = nwg % nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+#define MD_CHECK_ARG(cond)                  \
+  do {                                      \
+    if (!(cond)) return MD_ERR_INVALID_ARG; \
+  } while (0)
+
+static inline md_status md_launch_status() {
+  return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_LAUNCH;
+}

@@ -1,0 +1,103 @@
+"""Host-side image tiling (integer / uint8 work in front of the ViT).
+
+Same contract as the reference's ``image_crops`` module (reference:
+moondream/torch/image_crops.py:17-231): ``select_tiling``,
+``overlap_crop_image`` (global 378x378 crop + overlapping local crops cut from
+the image resized to the tiling) and ``reconstruct_from_crops``.  The resize
+uses PIL LANCZOS, the reference's fallback branch (image_crops.py:137-150);
+pyvips is not available in this environment, and the two branches give
+different pixels ("image resize parity").
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Tuple, TypedDict, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+
+class OverlapCropOutput(TypedDict):
+    crops: np.ndarray
+    tiling: Tuple[int, int]
+
+
+def select_tiling(height: int, width: int, crop_size: int, max_crops: int) -> Tuple[int, int]:
+    """Number of local crops along (height, width).  reference: image_crops.py:17-50."""
+    if height <= crop_size or width <= crop_size:
+        return (1, 1)
+    lo_h = math.ceil(height / crop_size)
+    lo_w = math.ceil(width / crop_size)
+    if lo_h * lo_w > max_crops:
+        # too many even at the minimum: shrink both proportionally
+        shrink = math.sqrt(max_crops / (lo_h * lo_w))
+        return (max(1, math.floor(lo_h * shrink)), max(1, math.floor(lo_w * shrink)))
+    # aspect-ratio-matched split of the crop budget, never below the minimum
+    n_h = max(math.floor(math.sqrt(max_crops * height / width)), lo_h)
+    n_w = max(math.floor(math.sqrt(max_crops * width / height)), lo_w)
+    if n_h * n_w > max_crops:
+        if n_w > n_h:
+            n_w = math.floor(max_crops / n_h)
+        else:
+            n_h = math.floor(max_crops / n_w)
+    return (max(1, n_h), max(1, n_w))
+
+
+def _resize(img: np.ndarray, height: int, width: int) -> np.ndarray:
+    pil = Image.fromarray(img)
+    return np.asarray(pil.resize((int(width), int(height)), resample=Image.Resampling.LANCZOS))
+
+
+def overlap_crop_image(
+    image: np.ndarray,
+    overlap_margin: int,
+    max_crops: int,
+    base_size: Tuple[int, int] = (378, 378),
+    patch_size: int = 14,
+) -> OverlapCropOutput:
+    """crops[0] = whole image resized to base_size; crops[1:] = base_size windows
+    at stride (base - 2*margin*patch) over the image resized to the tiling.
+    reference: image_crops.py:58-167."""
+    src_h, src_w = image.shape[:2]
+    margin_px = patch_size * overlap_margin
+    window = (base_size[0] // patch_size - 2 * overlap_margin) * patch_size  # stride between crops
+
+    tiling = select_tiling(src_h - 2 * margin_px, src_w - 2 * margin_px, window, max_crops)
+    th, tw = tiling
+    crops = np.zeros((th * tw + 1, base_size[0], base_size[1], image.shape[2]), dtype=np.uint8)
+
+    resized = _resize(image, th * window + 2 * margin_px, tw * window + 2 * margin_px)
+    crops[0] = _resize(image, base_size[0], base_size[1])
+    for ty in range(th):
+        for tx in range(tw):
+            y0, x0 = ty * window, tx * window
+            piece = resized[y0 : min(y0 + base_size[0], resized.shape[0]), x0 : min(x0 + base_size[1], resized.shape[1])]
+            crops[1 + ty * tw + tx, : piece.shape[0], : piece.shape[1]] = piece
+    return {"crops": crops, "tiling": tiling}
+
+
+def reconstruct_from_crops(
+    crops: Union[torch.Tensor, Sequence[torch.Tensor]],
+    tiling: Tuple[int, int],
+    overlap_margin: int,
+    patch_size: int = 14,
+) -> torch.Tensor:
+    """Stitch per-crop (H, W, C) grids back into one grid: every crop contributes
+    its interior, plus its outer margin where it touches the image border.
+    reference: image_crops.py:170-231."""
+    th, tw = tiling
+    ch, cw = crops[0].shape[:2]
+    m = overlap_margin * patch_size
+    step_h, step_w = ch - 2 * m, cw - 2 * m
+    out = torch.zeros(
+        (step_h * th + 2 * m, step_w * tw + 2 * m, crops[0].shape[2]), device=crops[0].device, dtype=crops[0].dtype
+    )
+    for idx, crop in enumerate(crops):
+        ty, tx = divmod(idx, tw)
+        ys = 0 if ty == 0 else m
+        ye = ch if ty == th - 1 else ch - m
+        xs = 0 if tx == 0 else m
+        xe = cw if tx == tw - 1 else cw - m
+        out[ty * step_h + ys : ty * step_h + ye, tx * step_w + xs : tx * step_w + xe] = crop[ys:ye, xs:xe]
+    return out

@@ -1,0 +1,728 @@
+"""MoondreamModel: the reference's Python API on top of libmoondream_hip.so.
+
+Public surface mirrors the reference class (reference:
+moondream/torch/moondream.py:81-973): ``encode_image``, ``caption``, ``query``,
+``detect``, ``point``, ``load_encoded_image``, ``compile`` and the four seam
+methods ``_vis_enc / _vis_proj / _prefill / _decode_one_tok``
+(moondream.py:168-192) -- here bound to hand-written gfx950 kernels through the
+C ABI instead of ATen ops.  New: ``batch_generate`` / ``batch_caption`` /
+``batch_query`` run B images in lockstep (the reference has no batching;
+hf_moondream.py:99-103 is a sequential loop) and return exactly what the
+sequential path returns.
+
+PyTorch is used for device memory, streams and (optionally) hipGraph capture
+only.  There is no eager / CPU fallback: without the built library or a GPU the
+constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, Iterable, List, Literal, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import _lib
+from .config import MoondreamConfig
+from .image_crops import overlap_crop_image, reconstruct_from_crops
+from .weights import PackedModel
+
+BF16 = torch.bfloat16
+
+DEFAULT_MAX_TOKENS = 768
+DEFAULT_TEMPERATURE = 0.5
+DEFAULT_TOP_P = 0.3
+DEFAULT_MAX_OBJECTS = 50
+
+SpatialRefs = List[Union[Tuple[float, float], Tuple[float, float, float, float]]]
+
+
+@dataclass(frozen=True)
+class EncodedImage:
+    """reference: moondream.py:56-59."""
+
+    pos: int
+    caches: List[Tuple[torch.Tensor, torch.Tensor]]
+
+
+class IdTokenizer:
+    """Stand-in used when the real vocabulary (``moondream/starmie-v1``) cannot be
+    loaded offline: text is a space-separated list of token ids."""
+
+    class _Enc:
+        def __init__(self, ids):
+            self.ids = ids
+
+    def encode(self, s: str):
+        return self._Enc([int(t) for t in s.split()])
+
+    def decode(self, ids: Iterable[int]) -> str:
+        return "".join(f"{int(i)} " for i in ids)
+
+
+def _load_tokenizer():
+    try:
+        from tokenizers import Tokenizer
+
+        return Tokenizer.from_pretrained("moondream/starmie-v1")
+    except Exception:
+        return IdTokenizer()
+
+
+def _is_cjk_char(cp: int) -> bool:
+    return (0x4E00 <= cp <= 0x9FFF) or (0x3400 <= cp <= 0x4DBF) or (0x2F800 <= cp <= 0x2FA1F)
+
+
+class MoondreamModel:
+    def __init__(
+        self,
+        config: MoondreamConfig,
+        state_dict: Dict[str, torch.Tensor],
+        device: Union[str, torch.device] = "cuda",
+        dtype: torch.dtype = BF16,
+        setup_caches: bool = True,
+        tokenizer: Any = None,
+        max_batch: int = 1,
+        vit_chunk_crops: int = 32,
+    ):
+        if dtype != BF16:
+            raise ValueError("the Moondream hot path is bf16-only (reference: vision.py:36)")
+        self.config = config
+        self.lib = _lib.load()  # raises when the HIP library has not been built
+        self._device = torch.device(device)
+        if self._device.type != "cuda":
+            raise _lib.MoondreamHipError("MoondreamModel needs a GPU device; there is no CPU path")
+        self.tokenizer = tokenizer if tokenizer is not None else _load_tokenizer()
+        self.w = PackedModel(config, state_dict, self._device)
+        self.vit_chunk_crops = int(vit_chunk_crops)
+        self._ws = None
+        self._ws2 = None
+        self._max_batch = 0
+        self._kv_k = self._kv_v = None
+        self._graphs: Dict[Any, Any] = {}
+        self.use_graphs = False
+        if setup_caches:
+            self._setup_caches(max_batch)
+
+    # ------------------------------------------------------------------ infra
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _setup_caches(self, max_batch: Optional[int] = None):
+        """Zeroed KV slabs [L][B][H_kv][ctx][hd] (reference: moondream.py:62-72,152-162)."""
+        t = self.config.text
+        b = max(1, int(max_batch or self._max_batch or 1))
+        self._kv_k = torch.zeros(t.n_layers, b, t.n_kv_heads, t.max_context, t.head_dim, dtype=BF16, device=self._device)
+        self._kv_v = torch.zeros_like(self._kv_k)
+        self._max_batch = b
+        self._graphs.clear()
+
+    def _ensure_batch(self, b: int):
+        if self._kv_k is None or b > self._max_batch:
+            self._setup_caches(b)
+
+    def _kv_struct(self, slot0: int = 0) -> _lib.MdKvCache:
+        t = self.config.text
+        bs = t.n_kv_heads * t.max_context * t.head_dim
+        off = slot0 * bs * 2
+        return _lib.MdKvCache(
+            self._kv_k.data_ptr() + off, self._kv_v.data_ptr() + off, self._max_batch * bs, bs, t.max_context
+        )
+
+    def _workspace(self, nbytes: int, which: int = 0) -> torch.Tensor:
+        attr = "_ws" if which == 0 else "_ws2"
+        ws = getattr(self, attr)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=self._device)
+            setattr(self, attr, ws)
+            self._graphs.clear()
+        return ws
+
+    def compile(self):
+        """The reference rebinds the seam to torch.compile'd functions here
+        (moondream.py:194-204).  The seam is already native; ``compile`` turns on
+        hipGraph replay of the device-resident decode step."""
+        self.use_graphs = True
+
+    # ------------------------------------------------------------------ seam
+    def _vis_enc(self, x: torch.Tensor) -> torch.Tensor:
+        """bf16 [N,3,378,378] -> bf16 [N,729,D_v].  reference: moondream.py:168-169."""
+        v = self.config.vision
+        assert x.dtype == BF16 and x.dim() == 4 and x.shape[1:] == (3, v.crop_size, v.crop_size)
+        x = x.contiguous()
+        return self._vit_run(x, _lib.MD_CROPS_BF16_CHW)
+
+    def _vit_run(self, crops: torch.Tensor, kind: int) -> torch.Tensor:
+        v = self.config.vision
+        n = crops.shape[0]
+        out = torch.empty(n, v.n_patches, v.enc_dim, dtype=BF16, device=self._device)
+        chunk = max(1, self.vit_chunk_crops)
+        need = self.lib.md_vit_workspace_bytes(C.byref(self.w.vit), min(n, chunk))
+        ws = self._workspace(need)
+        for i in range(0, n, chunk):
+            m = min(chunk, n - i)
+            _lib.check(
+                self.lib.md_vit_encode(
+                    C.byref(self.w.vit), crops[i : i + m].data_ptr(), kind, m, out[i : i + m].data_ptr(),
+                    ws.data_ptr(), ws.numel(), self._stream(),
+                ),
+                "md_vit_encode",
+            )
+        return out
+
+    def _vis_proj(self, g: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
+        """global [729,D_v] + stitched grid [h,w,D_v] -> [729,D].  reference: moondream.py:171-172."""
+        v = self.config.vision
+        g, r = g.contiguous(), r.contiguous()
+        out = torch.empty(v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
+        need = self.lib.md_vision_project_workspace_bytes(C.byref(self.w.vit), 1)
+        ws = self._workspace(need)
+        _lib.check(
+            self.lib.md_vision_project_grid(
+                C.byref(self.w.vit), g.data_ptr(), r.data_ptr(), r.shape[0], r.shape[1], out.data_ptr(),
+                v.proj_out_dim, ws.data_ptr(), ws.numel(), self._stream(),
+            ),
+            "md_vision_project_grid",
+        )
+        return out
+
+    def _text_forward(self, x: torch.Tensor, pos0: torch.Tensor, slot0: int = 0) -> torch.Tensor:
+        """x [B,T,D] embeddings -> hidden [B,T,D]; K,V written at pos0[b]..pos0[b]+T-1."""
+        b, t, d = x.shape
+        self._ensure_batch(slot0 + b)
+        x = x.contiguous()
+        hidden = torch.empty_like(x)
+        need = self.lib.md_text_workspace_bytes(C.byref(self.w.text), b, t)
+        ws = self._workspace(need)
+        kv = self._kv_struct(slot0)
+        _lib.check(
+            self.lib.md_text_forward(
+                C.byref(self.w.text), x.data_ptr(), hidden.data_ptr(), b, t, pos0.data_ptr(), C.byref(kv),
+                ws.data_ptr(), ws.numel(), self._stream(),
+            ),
+            "md_text_forward",
+        )
+        return hidden
+
+    def _lm_head(self, hidden: torch.Tensor) -> torch.Tensor:
+        """hidden [B,T,D] -> logits of the last token [B,V].  reference: text.py:163-167."""
+        b, t, d = hidden.shape
+        logits = torch.empty(b, self.config.text.vocab_size, dtype=BF16, device=self._device)
+        need = self.lib.md_lm_head_workspace_bytes(C.byref(self.w.text), b)
+        ws = self._workspace(need, 1)
+        _lib.check(
+            self.lib.md_lm_head(
+                C.byref(self.w.text), hidden.contiguous().data_ptr(), b, t, logits.data_ptr(), logits.shape[1],
+                ws.data_ptr(), ws.numel(), self._stream(),
+            ),
+            "md_lm_head",
+        )
+        return logits
+
+    def _prefill(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, lora=None):
+        """reference: moondream.py:174-181.  x [1,T,D]; pos_ids int64 [T] consecutive."""
+        if lora is not None:
+            raise NotImplementedError("LoRA variants are not on the native path")
+        pos0 = torch.tensor([int(pos_ids[0])], dtype=torch.int32, device=self._device)
+        return self._text_forward(x.to(self._device), pos0, 0)
+
+    def _decode_one_tok(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, lora=None):
+        """reference: moondream.py:183-192.  x [1,1,D] -> (logits [1,V], hidden [1,1,D])."""
+        hidden = self._prefill(x, attn_mask, pos_ids, lora)
+        return self._lm_head(hidden), hidden
+
+    # ------------------------------------------------------------ vision path
+    def _embed(self, ids: torch.Tensor) -> torch.Tensor:
+        """token ids [..] -> embeddings [.., D]  (reference: text.py:12-13)."""
+        flat = ids.reshape(-1).to(device=self._device, dtype=torch.int32).contiguous()
+        d = self.config.text.dim
+        out = torch.empty(flat.numel(), d, dtype=BF16, device=self._device)
+        _lib.check(
+            self.lib.md_embed_tokens(flat.data_ptr(), self.w.wte.data_ptr(), d, out.data_ptr(), d, flat.numel(), d, self._stream()),
+            "md_embed_tokens",
+        )
+        return out.reshape(*ids.shape, d)
+
+    def _crop(self, image: Image.Image):
+        v = self.config.vision
+        arr = np.array(image.convert("RGB"))
+        oc = overlap_crop_image(arr, max_crops=v.max_crops, overlap_margin=v.overlap_margin)
+        return oc["crops"], tuple(oc["tiling"])
+
+    def _run_vision_encoder_batch(self, images: Sequence[Image.Image]) -> torch.Tensor:
+        """images -> [B,729,D] projected embeddings (reference: moondream.py:206-228, per image)."""
+        v = self.config.vision
+        cropped = [self._crop(im) for im in images]
+        all_crops = np.concatenate([c for c, _ in cropped], axis=0)
+        dev_crops = torch.from_numpy(all_crops).to(self._device, non_blocking=True)
+        feats = self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC)  # [sum crops, 729, Dv]
+        out = torch.empty(len(images), v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
+        # images with the same tiling are projected together
+        offsets, off = [], 0
+        for c, _ in cropped:
+            offsets.append(off)
+            off += c.shape[0]
+        groups: Dict[Tuple[int, int], List[int]] = {}
+        for i, (_, tiling) in enumerate(cropped):
+            groups.setdefault(tiling, []).append(i)
+        for tiling, idxs in groups.items():
+            nc = 1 + tiling[0] * tiling[1]
+            contiguous = idxs == list(range(idxs[0], idxs[0] + len(idxs))) and len(groups) == 1
+            if contiguous:
+                f = feats
+            else:
+                f = torch.cat([feats[offsets[i] : offsets[i] + nc] for i in idxs], dim=0)
+            o = out if contiguous else torch.empty(len(idxs), v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
+            need = self.lib.md_vision_project_workspace_bytes(C.byref(self.w.vit), len(idxs))
+            ws = self._workspace(need)
+            _lib.check(
+                self.lib.md_vision_project(
+                    C.byref(self.w.vit), f.data_ptr(), len(idxs), tiling[0], tiling[1], v.overlap_margin,
+                    o.data_ptr(), v.proj_out_dim, ws.data_ptr(), ws.numel(), self._stream(),
+                ),
+                "md_vision_project",
+            )
+            if not contiguous:
+                out[torch.tensor(idxs, device=self._device)] = o
+        return out
+
+    def _run_vision_encoder(self, image: Image.Image) -> torch.Tensor:
+        return self._run_vision_encoder_batch([image])[0]
+
+    def _prefill_images(self, img_emb: torch.Tensor, slot0: int = 0) -> int:
+        """[B,729,D] -> image prefix in the KV slabs of slots [slot0, slot0+B); returns pos (730)."""
+        b = img_emb.shape[0]
+        bos = self._embed(torch.full((b, 1), self.config.tokenizer.bos_id, dtype=torch.int32))
+        x = torch.cat([bos, img_emb], dim=1)
+        pos0 = torch.zeros(b, dtype=torch.int32, device=self._device)
+        self._text_forward(x, pos0, slot0)
+        return x.shape[1]
+
+    def encode_image(self, image: Union[Image.Image, EncodedImage], settings: Optional[dict] = None) -> EncodedImage:
+        """reference: moondream.py:230-268."""
+        if isinstance(image, EncodedImage):
+            return image
+        if not isinstance(image, Image.Image):
+            raise ValueError("image must be a PIL Image or EncodedImage")
+        if settings is not None and settings.get("variant") is not None:
+            raise NotImplementedError("LoRA variants are not on the native path")
+        with torch.inference_mode():
+            self._ensure_batch(1)
+            pos = self._prefill_images(self._run_vision_encoder(image)[None], 0)
+            caches = [
+                (self._kv_k[l, 0:1, :, :pos, :].clone(), self._kv_v[l, 0:1, :, :pos, :].clone())
+                for l in range(self.config.text.n_layers)
+            ]
+        return EncodedImage(pos=pos, caches=caches)
+
+    def load_encoded_image(self, encoded_image: EncodedImage, slot: int = 0):
+        """reference: moondream.py:620-623."""
+        self._ensure_batch(slot + 1)
+        for l, (k, v) in enumerate(encoded_image.caches):
+            self._kv_k[l, slot : slot + 1, :, : k.size(2), :] = k
+            self._kv_v[l, slot : slot + 1, :, : v.size(2), :] = v
+
+    # --------------------------------------------------------------- sampling
+    def _apply_top_p(self, probs: torch.Tensor, top_p: float) -> torch.Tensor:
+        """reference: moondream.py:270-278."""
+        probs_sort, probs_idx = torch.sort(probs, dim=-1, descending=True)
+        csum = torch.cumsum(probs_sort, dim=-1)
+        probs_sort[csum - probs_sort > top_p] = 0.0
+        probs_sort.div_(probs_sort.sum(dim=-1, keepdim=True))
+        out = torch.zeros_like(probs)
+        out.scatter_(dim=-1, index=probs_idx, src=probs_sort)
+        return out
+
+    def _pick(self, logits: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
+        """[B,V] -> int32 [B]   (reference: moondream.py:313-318,521-528)."""
+        if temperature == 0:
+            b, v = logits.shape
+            nxt = torch.empty(b, dtype=torch.int32, device=self._device)
+            _lib.check(
+                self.lib.md_argmax_bf16(logits.data_ptr(), v, b, v, -1, nxt.data_ptr(), self._stream()), "md_argmax_bf16"
+            )
+            return nxt
+        probs = torch.softmax(logits / temperature, dim=-1)
+        probs = self._apply_top_p(probs, top_p)
+        return torch.multinomial(probs.float(), num_samples=1)[:, 0].to(torch.int32)
+
+    # ---------------------------------------------------------- batched engine
+    def _prefill_prompts(self, prompts: Sequence[Sequence[int]], pos: int, slot0: int = 0, prompt_embs=None):
+        """Prefill B equal-length prompts at position ``pos``; returns (logits [B,V], hidden [B,T,D], pos+T).
+        reference: moondream.py:280-321 (per sequence)."""
+        b = len(prompts)
+        ids = torch.tensor(prompts, dtype=torch.int32)
+        x = self._embed(ids) if prompt_embs is None else prompt_embs
+        pos0 = torch.full((b,), pos, dtype=torch.int32, device=self._device)
+        hidden = self._text_forward(x, pos0, slot0)
+        return self._lm_head(hidden), hidden, pos + ids.shape[1]
+
+    def _decode_greedy(self, first: torch.Tensor, pos: int, max_tokens: int, suppress_id: int, slot0: int = 0,
+                       eos_id: Optional[int] = None, check_every: int = 16) -> torch.Tensor:
+        """Device-resident greedy loop: returns int32 [steps+1, B] (row 0 = ``first``).
+        reference: the generator of moondream.py:471-530 without its per-token host sync."""
+        b = first.shape[0]
+        t = self.config.text
+        self._ensure_batch(slot0 + b)
+        hist = torch.zeros(max_tokens + 1, b, dtype=torch.int32, device=self._device)
+        hist[0] = first
+        pos_t = torch.full((b,), pos, dtype=torch.int32, device=self._device)
+        logits = torch.empty(b, t.vocab_size, dtype=BF16, device=self._device)
+        need = self.lib.md_decode_workspace_bytes(C.byref(self.w.text), b)
+        ws = self._workspace(need)
+        kv = self._kv_struct(slot0)
+        steps = 0
+        while steps < max_tokens and pos + steps < t.max_context - 1:
+            _lib.check(
+                self.lib.md_decode_step(
+                    C.byref(self.w.text), hist[steps].data_ptr(), hist[steps + 1].data_ptr(), pos_t.data_ptr(), b,
+                    C.byref(kv), suppress_id, logits.data_ptr(), t.vocab_size, ws.data_ptr(), ws.numel(), self._stream(),
+                ),
+                "md_decode_step",
+            )
+            steps += 1
+            if eos_id is not None and check_every and steps % check_every == 0:
+                if bool((hist[: steps + 1] == eos_id).any(dim=0).all()):
+                    break
+        return hist[: steps + 1]
+
+    @staticmethod
+    def _truncate(seq: List[int], eos_id: Optional[int], max_tokens: int) -> List[int]:
+        out = []
+        for tok in seq:
+            if (eos_id is not None and tok == eos_id) or len(out) >= max_tokens:
+                break
+            out.append(tok)
+        return out
+
+    def batch_generate_ids(
+        self,
+        images: Sequence[Union[Image.Image, EncodedImage]],
+        prompts: Sequence[Sequence[int]],
+        max_tokens: int = DEFAULT_MAX_TOKENS,
+        eos_id: Optional[int] = None,
+        ignore_eos: bool = False,
+    ) -> List[List[int]]:
+        """Greedy token ids for B (image, prompt-ids) pairs, decoded in lockstep.
+
+        Defined as: element i equals what the sequential reference path
+        (encode_image -> load_encoded_image -> _generate_answer with
+        temperature 0) returns for (images[i], prompts[i]).  Every kernel's
+        accumulation order is independent of the batch, so this holds
+        bit-for-bit against this model's own B=1 path.
+        """
+        b = len(images)
+        assert b == len(prompts) and b > 0
+        tk = self.config.tokenizer
+        eos = tk.eos_id if eos_id is None else eos_id
+        with torch.inference_mode():
+            self._ensure_batch(b)
+            raw = [im for im in images if not isinstance(im, EncodedImage)]
+            if len(raw) == b:
+                pos = self._prefill_images(self._run_vision_encoder_batch(raw), 0)
+            else:
+                pos = None
+                for i, im in enumerate(images):
+                    enc = self.encode_image(im)
+                    self.load_encoded_image(enc, i)
+                    pos = enc.pos
+            lens = {len(p) for p in prompts}
+            results: List[Optional[List[int]]] = [None] * b
+            if len(lens) == 1:
+                logits, _, p1 = self._prefill_prompts(prompts, pos, 0)
+                first = self._pick(logits, 0.0, 0.0)
+                hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, 0, None if ignore_eos else eos)
+                cols = hist.t().tolist()
+                for i in range(b):
+                    results[i] = self._truncate(cols[i], None if ignore_eos else eos, max_tokens)
+            else:
+                # ragged prompts: one lockstep group per distinct length over contiguous slots
+                for i in range(b):
+                    logits, _, p1 = self._prefill_prompts([prompts[i]], pos, i)
+                    first = self._pick(logits, 0.0, 0.0)
+                    hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, i, None if ignore_eos else eos)
+                    results[i] = self._truncate(hist[:, 0].tolist(), None if ignore_eos else eos, max_tokens)
+        return results  # type: ignore[return-value]
+
+    def batch_caption(self, images, length: str = "normal", settings: Optional[dict] = None) -> List[str]:
+        tpl = self.config.tokenizer.templates["caption"]
+        if tpl is None:
+            raise NotImplementedError("Model does not support captioning.")
+        if length not in tpl:
+            raise ValueError(f"Model does not support caption length '{length}'.")
+        mt = (settings or {}).get("max_tokens", DEFAULT_MAX_TOKENS)
+        ids = self.batch_generate_ids(images, [tpl[length]] * len(images), mt)
+        return [self.tokenizer.decode(s) for s in ids]
+
+    def batch_query(self, images, questions: Sequence[str], settings: Optional[dict] = None) -> List[str]:
+        tpl = self.config.tokenizer.templates["query"]
+        if tpl is None:
+            raise NotImplementedError("Model does not support querying.")
+        mt = (settings or {}).get("max_tokens", DEFAULT_MAX_TOKENS)
+        prompts = [
+            list(tpl["prefix"]) + list(self.tokenizer.encode(q).ids) + list(tpl["suffix"]) + list(tpl["suffix"])
+            for q in questions
+        ]
+        ids = self.batch_generate_ids(images, prompts, mt)
+        return [self.tokenizer.decode(s) for s in ids]
+
+    def batch_generate(self, images, prompts: Optional[Sequence[str]] = None, settings: Optional[dict] = None) -> List[str]:
+        """BASELINE.json's ``batch_generate``: captions when ``prompts`` is None, else answers
+        (greedy; element i == caption(images[i]) / query(images[i], prompts[i]) at temperature 0)."""
+        if prompts is None:
+            return self.batch_caption(images, "normal", settings)
+        return self.batch_query(images, prompts, settings)
+
+    # ------------------------------------------------------- sequential API
+    def _prefill_prompt(self, prompt_tokens: torch.Tensor, pos: int, temperature: float, top_p: float,
+                        spatial_refs: Optional[SpatialRefs] = None, attn_mask=None, lora=None):
+        """reference: moondream.py:280-321."""
+        with torch.inference_mode():
+            ids = prompt_tokens.to(torch.int32)
+            emb = self._embed(ids)
+            if spatial_refs:
+                enc = self.encode_spatial_refs(spatial_refs)
+                emb[ids.to(self._device) == self.config.tokenizer.coord_id] = enc["coords"]
+                if enc["sizes"] is not None:
+                    emb[ids.to(self._device) == self.config.tokenizer.size_id] = enc["sizes"]
+            pos0 = torch.full((1,), pos, dtype=torch.int32, device=self._device)
+            hidden = self._text_forward(emb, pos0, 0)
+            logits = self._lm_head(hidden)
+            nxt = self._pick(logits, temperature, top_p)
+        return logits, hidden, nxt.reshape(1, 1), pos + ids.shape[1]
+
+    def _generate_answer(self, prompt_tokens: torch.Tensor, pos: int, settings: Optional[dict] = None,
+                         spatial_refs: Optional[SpatialRefs] = None, eos_id: Optional[int] = None, attn_mask=None):
+        """Generator of text pieces.  reference: moondream.py:434-539."""
+        settings = settings or {}
+        max_tokens = settings.get("max_tokens", DEFAULT_MAX_TOKENS)
+        temperature = settings.get("temperature", DEFAULT_TEMPERATURE)
+        top_p = settings.get("top_p", DEFAULT_TOP_P)
+        if settings.get("variant") is not None:
+            raise NotImplementedError("LoRA variants are not on the native path")
+        eos = eos_id if eos_id is not None else self.config.tokenizer.eos_id
+        _, _, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask)
+
+        def token_source():
+            if temperature == 0:
+                done = 0
+                first = nxt.reshape(1).to(torch.int32)
+                cur_pos = pos
+                while done < max_tokens:
+                    chunk = min(16, max_tokens - done)
+                    hist = self._decode_greedy(first, cur_pos, chunk, self.config.tokenizer.answer_id, 0, None)
+                    toks = hist[:, 0].tolist()
+                    for tok in toks[:-1]:
+                        yield tok
+                    done += len(toks) - 1
+                    cur_pos += len(toks) - 1
+                    first = hist[-1]
+                    if len(toks) - 1 < chunk:
+                        break
+                yield int(first[0])
+            else:
+                tok = nxt.reshape(1).to(torch.int32)
+                cur_pos = pos
+                while True:
+                    yield int(tok[0])
+                    with torch.inference_mode():
+                        emb = self._embed(tok.reshape(1, 1))
+                        p0 = torch.full((1,), cur_pos, dtype=torch.int32, device=self._device)
+                        hidden = self._text_forward(emb, p0, 0)
+                        logits = self._lm_head(hidden)
+                        logits[:, self.config.tokenizer.answer_id] = float("-inf")
+                        cur_pos += 1
+                        tok = self._pick(logits, temperature, top_p)
+
+        def generator():
+            # streaming detokeniser: flush on newline, CJK, or up to the last space
+            # (reference: moondream.py:477-537)
+            cache: List[int] = []
+            print_len = 0
+            n = 0
+            for tok in token_source():
+                if tok == eos or n >= max_tokens:
+                    break
+                n += 1
+                cache.append(tok)
+                text = self.tokenizer.decode(cache)
+                if text.endswith("\n"):
+                    piece, cache, print_len = text[print_len:], [], 0
+                    if piece:
+                        yield piece
+                elif len(text) > 0 and _is_cjk_char(ord(text[-1])):
+                    piece = text[print_len:]
+                    print_len += len(piece)
+                    if piece:
+                        yield piece
+                else:
+                    sp = text.rfind(" ", print_len)
+                    if sp >= print_len:
+                        piece = text[print_len : sp + 1]
+                        print_len += len(piece)
+                        if piece:
+                            yield piece
+            if cache:
+                piece = self.tokenizer.decode(cache)[print_len:]
+                if piece:
+                    yield piece
+
+        return generator()
+
+    def caption(self, image, length: Literal["normal", "short", "long"] = "normal", stream: bool = False,
+                settings: Optional[dict] = None):
+        """reference: moondream.py:625-651."""
+        tpl = self.config.tokenizer.templates["caption"]
+        if tpl is None:
+            raise NotImplementedError("Model does not support captioning.")
+        if length not in tpl:
+            raise ValueError(f"Model does not support caption length '{length}'.")
+        enc = self.encode_image(image)
+        self.load_encoded_image(enc)
+        prompt = torch.tensor([tpl[length]])
+        gen = self._generate_answer(prompt, enc.pos, settings)
+        return {"caption": gen} if stream else {"caption": "".join(list(gen))}
+
+    def query(self, image=None, question: str = None, reasoning: bool = False,
+              spatial_refs: Optional[SpatialRefs] = None, stream: bool = False, settings: Optional[dict] = None):
+        """reference: moondream.py:541-618 (the ``reasoning`` branch is not on the native path)."""
+        tpl = self.config.tokenizer.templates["query"]
+        if tpl is None:
+            raise NotImplementedError("Model does not support querying.")
+        if question is None:
+            raise ValueError("question must be provided.")
+        if spatial_refs and image is None:
+            raise ValueError("spatial_refs can only be used with an image.")
+        if reasoning:
+            raise NotImplementedError("reasoning mode is not on the native path yet")
+        if image is None:
+            raise NotImplementedError("text-only query (plain causal mask) is not on the native path yet")
+        enc = self.encode_image(image)
+        self.load_encoded_image(enc)
+        spatial = []
+        if spatial_refs:
+            tk = self.config.tokenizer
+            for ref in spatial_refs:
+                spatial.extend([tk.coord_id, tk.coord_id] if len(ref) == 2 else [tk.coord_id, tk.coord_id, tk.size_id])
+        prompt = list(tpl["prefix"]) + spatial + list(self.tokenizer.encode(question).ids) + list(tpl["suffix"]) + list(tpl["suffix"])
+        gen = self._generate_answer(torch.tensor([prompt]), enc.pos, settings, spatial_refs)
+        return {"answer": gen} if stream else {"answer": "".join(list(gen))}
+
+    # ------------------------------------------------------------ region head
+    def _gemm(self, a: torch.Tensor, lin, epi: int = _lib.MD_EPI_BIAS) -> torch.Tensor:
+        """rows [m, k] -> [m, n] through md_gemm_bf16 (pads the operand to k_pad)."""
+        m = a.shape[0]
+        ap = torch.zeros(m, lin.k_pad, dtype=BF16, device=self._device)
+        ap[:, : lin.k] = a
+        out = torch.empty(m, lin.n_pad, dtype=BF16, device=self._device)
+        args = _lib.MdGemmArgs(ap.data_ptr(), lin.k_pad, lin.struct(), out.data_ptr(), lin.n_pad, None, 0, 0, m, epi, 1)
+        _lib.check(self.lib.md_gemm_bf16(C.byref(args), self._stream()), "md_gemm_bf16")
+        return out[:, : lin.n]
+
+    def _mlp(self, x: torch.Tensor, fc1, fc2) -> torch.Tensor:
+        h = self._gemm(x, fc1, _lib.MD_EPI_GELU)
+        return self._gemm(h, fc2)
+
+    def _fourier(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """reference: region.py:12-29 (tiny: evaluated with torch elementwise ops on device)."""
+        f = (2 * math.pi * x) @ w
+        return torch.cat([f.cos(), f.sin()], dim=-1)
+
+    def encode_coordinate(self, coord: torch.Tensor) -> torch.Tensor:
+        """reference: region.py:32-43."""
+        r = self.w.region
+        return self._gemm(self._fourier(coord.reshape(-1, 1).to(self._device, BF16), r["coord_features"]), r["coord_encoder"])
+
+    def decode_coordinate(self, hidden: torch.Tensor) -> torch.Tensor:
+        """reference: region.py:46-57."""
+        r = self.w.region
+        return self._mlp(hidden.reshape(-1, hidden.shape[-1]), r["coord_dec_fc1"], r["coord_dec_fc2"])
+
+    def encode_size(self, size: torch.Tensor) -> torch.Tensor:
+        """reference: region.py:60-71."""
+        r = self.w.region
+        return self._gemm(self._fourier(size.reshape(-1, 2).to(self._device, BF16), r["size_features"]), r["size_encoder"])
+
+    def decode_size(self, hidden: torch.Tensor) -> torch.Tensor:
+        """reference: region.py:74-93."""
+        r = self.w.region
+        return self._mlp(hidden.reshape(-1, hidden.shape[-1]), r["size_dec_fc1"], r["size_dec_fc2"]).reshape(2, -1)
+
+    def encode_spatial_refs(self, spatial_refs: SpatialRefs):
+        """reference: region.py:96-136."""
+        coords, sizes = [], []
+        for ref in spatial_refs:
+            if len(ref) == 2:
+                coords += [ref[0], ref[1]]
+            else:
+                coords += [(ref[0] + ref[2]) / 2, (ref[1] + ref[3]) / 2]
+                sizes.append([ref[2] - ref[0], ref[3] - ref[1]])
+        c = self.encode_coordinate(torch.tensor(coords, dtype=BF16).view(-1, 1))
+        s = self.encode_size(torch.tensor(sizes, dtype=BF16)) if sizes else None
+        return {"coords": c, "sizes": s}
+
+    def _generate_points(self, hidden: torch.Tensor, next_token: torch.Tensor, pos: int, include_size: bool = True,
+                         max_objects: int = DEFAULT_MAX_OBJECTS):
+        """reference: moondream.py:653-733."""
+        out = []
+        eos = self.config.tokenizer.eos_id
+
+        def step(emb):
+            nonlocal pos
+            p0 = torch.full((1,), pos, dtype=torch.int32, device=self._device)
+            h = self._text_forward(emb.reshape(1, 1, -1), p0, 0)
+            pos += 1
+            return h
+
+        with torch.inference_mode():
+            while int(next_token.reshape(-1)[0]) != eos and len(out) < max_objects:
+                x_logits = self.decode_coordinate(hidden)
+                x_center = torch.argmax(x_logits, dim=-1) / x_logits.size(-1)
+                hidden = step(self.encode_coordinate(x_center.to(dtype=x_logits.dtype)))
+                y_logits = self.decode_coordinate(hidden)
+                y_center = torch.argmax(y_logits, dim=-1) / y_logits.size(-1)
+                emb = self.encode_coordinate(y_center.to(dtype=y_logits.dtype))
+                if include_size:
+                    hidden = step(emb)
+                    size_logits = self.decode_size(hidden)
+                    w_bin = torch.argmax(size_logits[0], dim=-1)
+                    h_bin = torch.argmax(size_logits[1], dim=-1)
+                    w = torch.pow(2.0, (w_bin.float() / 1023.0) * 10.0 - 10.0)
+                    h = torch.pow(2.0, (h_bin.float() / 1023.0) * 10.0 - 10.0)
+                    emb = self.encode_size(torch.tensor([w, h], device=self._device, dtype=size_logits.dtype))
+                    xc, yc, wf, hf = x_center.item(), y_center.item(), w.item(), h.item()
+                    out.append({"x_min": xc - wf / 2, "y_min": yc - hf / 2, "x_max": xc + wf / 2, "y_max": yc + hf / 2})
+                else:
+                    out.append({"x": x_center.item(), "y": y_center.item()})
+                hidden = step(emb)
+                next_token = self._pick(self._lm_head(hidden), 0.0, 0.0)
+        return out
+
+    def _detect_like(self, image, obj: str, kind: str, include_size: bool, settings: Optional[dict]):
+        tpl = self.config.tokenizer.templates[kind]
+        if tpl is None:
+            raise NotImplementedError(f"Model does not support {kind}.")
+        if self.w.region is None:
+            raise NotImplementedError("checkpoint has no region head")
+        enc = self.encode_image(image)
+        self.load_encoded_image(enc)
+        prompt = torch.tensor([list(tpl["prefix"]) + list(self.tokenizer.encode(" " + obj).ids) + list(tpl["suffix"])])
+        _, hidden, nxt, pos = self._prefill_prompt(prompt, enc.pos, temperature=0, top_p=0)
+        hidden = hidden[:, -1:, :]
+        max_objects = (settings or {}).get("max_objects", DEFAULT_MAX_OBJECTS)
+        return self._generate_points(hidden, nxt, pos, include_size=include_size, max_objects=max_objects)
+
+    def detect(self, image, object: str, settings: Optional[dict] = None):
+        """reference: moondream.py:735-781."""
+        return {"objects": self._detect_like(image, object, "detect", True, settings)}
+
+    def point(self, image, object: str, settings: Optional[dict] = None):
+        """reference: moondream.py:783-829."""
+        return {"points": self._detect_like(image, object, "point", False, settings)}

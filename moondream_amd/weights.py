@@ -1,0 +1,209 @@
+"""Checkpoint -> packed device layouts + the C structs the HIP library reads.
+
+Input is a ``state_dict`` keyed like the reference module tree
+(``vision.blocks.0.attn.qkv.weight`` ...; reference: vision.py:92-147,
+text.py:175-221, moondream.py:94-136).  ``remap_legacy_keys`` additionally
+accepts the older on-disk names the reference's loader maps
+(reference: weights.py:36-109).
+
+Packing (done once at load time, the GEMM kernel's contract in
+include/moondream_hip.h): every nn.Linear weight [n, k] becomes a zero-padded
+[n_pad, k_pad] bf16 matrix with n_pad, k_pad rounded up to 64 -- this is how
+K = 588 (patch embedding) and FF = 4304 (ViT MLP) reach MFMA-friendly shapes
+without touching any activation layout in HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .config import MoondreamConfig
+
+BF16 = torch.bfloat16
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def reference_pixel_lut() -> torch.Tensor:
+    """bf16 [256]: what the reference's in-place bf16 normalisation makes of each
+    byte value (reference: vision.py:33-40: ``.to(bf16).div_(255.0).sub_(0.5).div_(0.5)``)."""
+    return torch.arange(256, dtype=torch.uint8).to(BF16).div_(255.0).sub_(0.5).div_(0.5)
+
+
+def rope_table(rot_dim: int, max_context: int, theta: float = 10000.0) -> torch.Tensor:
+    """fp32 [max_context, rot_dim/2, 2] = (cos, sin) of pos * theta^(-2j/rot_dim)
+    (reference: rope.py:6-17, called with dim = rot_dim at text.py:214-218)."""
+    freqs = 1.0 / (theta ** (torch.arange(0, rot_dim, 2, dtype=torch.float32)[: rot_dim // 2] / rot_dim))
+    ang = torch.arange(max_context, dtype=torch.float32).unsqueeze(1) * freqs.unsqueeze(0)
+    cis = torch.exp(1j * ang)
+    return torch.stack([cis.real, cis.imag], dim=-1).contiguous()
+
+
+class PackedLinear:
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device):
+        n, k = w.shape
+        self.n, self.k = n, k
+        self.n_pad, self.k_pad = _round_up(n, 64), _round_up(k, 64)
+        wp = torch.zeros(self.n_pad, self.k_pad, dtype=BF16, device=device)
+        wp[:n, :k] = w.to(device=device, dtype=BF16)
+        bp = torch.zeros(self.n_pad, dtype=BF16, device=device)
+        if b is not None:
+            bp[:n] = b.to(device=device, dtype=BF16)
+        self.w, self.b = wp, bp
+
+    def struct(self) -> _lib.MdLinear:
+        return _lib.MdLinear(self.w.data_ptr(), self.b.data_ptr(), self.n, self.k, self.n_pad, self.k_pad)
+
+
+class PackedLayerNorm:
+    def __init__(self, w: torch.Tensor, b: torch.Tensor, device):
+        self.w = w.to(device=device, dtype=BF16).contiguous()
+        self.b = b.to(device=device, dtype=BF16).contiguous()
+
+    def struct(self) -> _lib.MdLayerNorm:
+        return _lib.MdLayerNorm(self.w.data_ptr(), self.b.data_ptr())
+
+
+LEGACY_KEY_PREFIXES = {
+    # old checkpoint layout -> module-tree layout (reference: weights.py:36-109)
+    "vision_encoder.encoder.model.visual.patch_embed.linear": "vision.patch_emb",
+    "vision_encoder.encoder.model.visual.norm": "vision.post_ln",
+    "vision_encoder.projection.mlp.fc1": "vision.proj_mlp.fc1",
+    "vision_encoder.projection.mlp.fc2": "vision.proj_mlp.fc2",
+    "text_model.lm_head.ln": "text.post_ln",
+    "text_model.lm_head.linear": "text.lm_head",
+    "region_model.coordinate_encoder": "region.coord_encoder",
+    "region_model.coordinate_decoder.fc1": "region.coord_decoder.fc1",
+    "region_model.coordinate_decoder.fc2": "region.coord_decoder.fc2",
+    "region_model.size_encoder": "region.size_encoder",
+    "region_model.size_decoder.fc1": "region.size_decoder.fc1",
+    "region_model.size_decoder.fc2": "region.size_decoder.fc2",
+}
+
+
+def remap_legacy_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Accept the older safetensors key layout (reference: weights.py:36-109)."""
+    if any(k.startswith("vision.") or k.startswith("text.") for k in sd):
+        return sd
+    out = {}
+    for k, v in sd.items():
+        nk = k
+        if k == "vision_encoder.encoder.model.visual.pos_embed":
+            nk = "vision.pos_emb"
+        elif k == "text_model.transformer.embd.wte.weight":
+            nk = "text.wte"
+        elif k == "region_model.coordinate_features.weight":
+            nk, v = "region.coord_features", v.T
+        elif k == "region_model.size_features.weight":
+            nk, v = "region.size_features", v.T
+        elif k.startswith("vision_encoder.encoder.model.visual.blocks."):
+            rest = k[len("vision_encoder.encoder.model.visual.blocks."):]
+            i, rest = rest.split(".", 1)
+            rest = rest.replace("norm1", "ln1").replace("norm2", "ln2")
+            nk = f"vision.blocks.{i}.{rest}"
+        elif k.startswith("text_model.transformer.h."):
+            rest = k[len("text_model.transformer.h."):]
+            i, rest = rest.split(".", 1)
+            rest = rest.replace("mixer.Wqkv", "attn.qkv").replace("mixer.out_proj", "attn.proj")
+            nk = f"text.blocks.{i}.{rest}"
+        else:
+            for old, new in LEGACY_KEY_PREFIXES.items():
+                if k.startswith(old + "."):
+                    nk = new + k[len(old):]
+                    break
+        out[nk] = v
+    return out
+
+
+class PackedModel:
+    """All weights resident on one device + the md_vit_model / md_text_model
+    structs (kept alive here; the library only borrows the pointers)."""
+
+    def __init__(self, config: MoondreamConfig, state_dict: Dict[str, torch.Tensor], device):
+        self.config = config
+        self.device = torch.device(device)
+        sd = remap_legacy_keys(state_dict)
+        self.sd_keys = set(sd)
+        v, t = config.vision, config.text
+        dev = self.device
+        self._keep: List[object] = []
+
+        def lin(prefix):
+            p = PackedLinear(sd[prefix + ".weight"], sd.get(prefix + ".bias"), dev)
+            self._keep.append(p)
+            return p
+
+        def ln(prefix):
+            p = PackedLayerNorm(sd[prefix + ".weight"], sd[prefix + ".bias"], dev)
+            self._keep.append(p)
+            return p
+
+        # ---------------- vision
+        self.patch_emb = lin("vision.patch_emb")
+        self.pos_emb = sd["vision.pos_emb"].to(device=dev, dtype=BF16).reshape(v.n_patches, v.enc_dim).contiguous()
+        self.pixel_lut = reference_pixel_lut().to(dev)
+        self.vit_blocks = (_lib.MdVitBlock * v.enc_n_layers)()
+        for i in range(v.enc_n_layers):
+            p = f"vision.blocks.{i}"
+            blk = self.vit_blocks[i]
+            blk.ln1 = ln(p + ".ln1").struct()
+            blk.qkv = lin(p + ".attn.qkv").struct()
+            blk.proj = lin(p + ".attn.proj").struct()
+            blk.ln2 = ln(p + ".ln2").struct()
+            blk.fc1 = lin(p + ".mlp.fc1").struct()
+            blk.fc2 = lin(p + ".mlp.fc2").struct()
+        self.vit_post_ln = ln("vision.post_ln")
+        self.proj_fc1 = lin("vision.proj_mlp.fc1")
+        self.proj_fc2 = lin("vision.proj_mlp.fc2")
+        self.vit = _lib.MdVitModel(
+            v.enc_dim, v.enc_n_heads, v.enc_n_layers, v.enc_ff_dim, v.enc_patch_size, v.crop_size,
+            self.patch_emb.struct(), self.pos_emb.data_ptr(),
+            C.cast(self.vit_blocks, C.POINTER(_lib.MdVitBlock)), self.vit_post_ln.struct(),
+            self.proj_fc1.struct(), self.proj_fc2.struct(), self.pixel_lut.data_ptr(),
+        )
+
+        # ---------------- text
+        self.text_blocks = (_lib.MdTextBlock * t.n_layers)()
+        for i in range(t.n_layers):
+            p = f"text.blocks.{i}"
+            blk = self.text_blocks[i]
+            blk.ln = ln(p + ".ln").struct()
+            blk.qkv = lin(p + ".attn.qkv").struct()
+            blk.proj = lin(p + ".attn.proj").struct()
+            blk.fc1 = lin(p + ".mlp.fc1").struct()
+            blk.fc2 = lin(p + ".mlp.fc2").struct()
+        self.text_post_ln = ln("text.post_ln")
+        self.lm_head = lin("text.lm_head")
+        self.wte = sd["text.wte"].to(device=dev, dtype=BF16).contiguous()
+        self.freqs = rope_table(t.rot_dim, t.max_context).to(dev)
+        self.text = _lib.MdTextModel(
+            t.dim, t.n_heads, t.n_kv_heads, t.n_layers, t.ff_dim, t.vocab_size, t.max_context,
+            t.prefix_attn, t.rot_dim, C.cast(self.text_blocks, C.POINTER(_lib.MdTextBlock)),
+            self.text_post_ln.struct(), self.lm_head.struct(), self.wte.data_ptr(), self.freqs.data_ptr(),
+        )
+
+        # ---------------- region head (detect / point), optional
+        self.region = None
+        if "region.coord_encoder.weight" in sd:
+            self.region = {
+                "coord_encoder": lin("region.coord_encoder"),
+                "coord_dec_fc1": lin("region.coord_decoder.fc1"),
+                "coord_dec_fc2": lin("region.coord_decoder.fc2"),
+                "size_encoder": lin("region.size_encoder"),
+                "size_dec_fc1": lin("region.size_decoder.fc1"),
+                "size_dec_fc2": lin("region.size_decoder.fc2"),
+                "coord_features": sd["region.coord_features"].to(device=dev, dtype=BF16).contiguous(),
+                "size_features": sd["region.size_features"].to(device=dev, dtype=BF16).contiguous(),
+            }
+
+    def param_bytes(self) -> int:
+        total = 0
+        for p in self._keep:
+            total += p.w.numel() * 2 + p.b.numel() * 2
+        return total + self.wte.numel() * 2 + self.pos_emb.numel() * 2

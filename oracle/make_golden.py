@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation.
+
+TEST INFRASTRUCTURE.  Runs only in the build container, where the read-only
+reference checkout exists (``/root/reference``); the GPU box never runs this.
+It imports ``moondream.torch`` from that checkout unmodified, with the two
+shims SURVEY.md section 8c describes:
+
+  1. ``Tokenizer.from_pretrained`` is replaced by an id-echo stub (the real
+     vocabulary needs the network); the hot path is driven with token IDs.
+  2. all parameters come from ``moondream_amd.synth.synthetic_state_dict``
+     (no checkpoint is available offline).
+
+and records, for fixed seeded inputs, the per-stage activations, KV rows,
+logits, greedy token ids and top-1/top-2 margins that the oracle
+(``oracle/moondream_oracle.py``) and the HIP path are compared against.
+
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [0.5b] [2b]
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = os.environ.get("MOONDREAM_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REFERENCE)
+
+from moondream_amd.config import get_config  # noqa: E402
+from moondream_amd import synth  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+class EchoTokenizer:
+    """decode() prints ids separated by spaces so generated ids can be parsed
+    back out of the reference's streamed text."""
+
+    class _Enc:
+        def __init__(self, ids):
+            self.ids = ids
+
+    def encode(self, s):
+        return self._Enc([int(t) for t in s.split()])
+
+    def decode(self, ids):
+        return "".join(f"{int(i)} " for i in ids)
+
+
+def load_reference(cfg, sd):
+    import moondream.torch.moondream as ref_md
+    from moondream.torch.config import MoondreamConfig as RefConfig
+
+    ref_md.Tokenizer.from_pretrained = staticmethod(lambda *_a, **_k: EchoTokenizer())
+    model = ref_md.MoondreamModel(RefConfig.from_dict(cfg.to_dict()), dtype=torch.bfloat16)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "kv_cache" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+    return model, ref_md
+
+
+def bf16_bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().contiguous().view(torch.int16).numpy().copy()
+
+
+def run_reference_caption(model, ref_md, image, prompt_ids, max_tokens):
+    """Greedy generation through the reference's own _generate_answer with
+    taps on the seam methods.  Returns dict of recorded arrays."""
+    from PIL import Image
+
+    rec = {"decode_logits": [], "prefill_hidden": []}
+    orig_decode, orig_prefill, orig_lm_head = model._decode_one_tok, model._prefill, ref_md.lm_head
+
+    def decode_tap(x, mask, pos_ids, lora):
+        logits, hidden = orig_decode(x, mask, pos_ids, lora)
+        rec["decode_logits"].append(logits[0].clone())
+        return logits, hidden
+
+    def prefill_tap(x, mask, pos_ids, lora):
+        h = orig_prefill(x, mask, pos_ids, lora)
+        rec["prefill_hidden"].append(h[0].clone())
+        return h
+
+    def lm_head_tap(h, w):
+        out = orig_lm_head(h, w)
+        rec.setdefault("prompt_logits", out[0].clone())  # first call = the prompt prefill
+        return out
+
+    model._decode_one_tok, model._prefill, ref_md.lm_head = decode_tap, prefill_tap, lm_head_tap
+    try:
+        t0 = time.perf_counter()
+        enc = model.encode_image(Image.fromarray(image, "RGB"))
+        t_enc = time.perf_counter() - t0
+        model.load_encoded_image(enc)
+        toks = torch.tensor([prompt_ids])
+        t0 = time.perf_counter()
+        text = "".join(
+            model._generate_answer(toks, enc.pos, {"temperature": 0, "max_tokens": max_tokens})
+        )
+        t_gen = time.perf_counter() - t0
+    finally:
+        model._decode_one_tok, model._prefill, ref_md.lm_head = orig_decode, orig_prefill, orig_lm_head
+    tokens = [int(t) for t in text.split()]
+    answer_id = model.config.tokenizer.answer_id
+    steps = [rec["prompt_logits"]]
+    for lg in rec["decode_logits"]:
+        lg = lg.clone()
+        lg[answer_id] = float("-inf")
+        steps.append(lg)
+    margins, argmaxes = [], []
+    for lg in steps:
+        top = torch.topk(lg.float(), 2).values
+        margins.append(float(top[0] - top[1]))
+        argmaxes.append(int(torch.argmax(lg.float())))
+    return dict(
+        enc=enc,
+        tokens=tokens,
+        margins=margins,
+        argmaxes=argmaxes,
+        steps=steps,
+        image_prefill_hidden=rec["prefill_hidden"][0],
+        prompt_hidden=rec["prefill_hidden"][1],
+        t_enc=t_enc,
+        t_gen=t_gen,
+    )
+
+
+def reference_vision_taps(model, ref_md, image):
+    """Stage-by-stage ViT activations using the reference's own functions."""
+    from PIL import Image
+    from moondream.torch.vision import prepare_crops, create_patches
+    from moondream.torch.layers import attn, layer_norm, mlp
+    from moondream.torch.image_crops import reconstruct_from_crops
+
+    cfg = model.config.vision
+    w = model.vision
+    taps = {}
+    with torch.inference_mode():
+        crops, tiling = prepare_crops(Image.fromarray(image, "RGB"), cfg, device="cpu")
+        taps["crops_norm"] = crops
+        x = w.patch_emb(create_patches(crops, cfg.enc_patch_size)) + w.pos_emb
+        taps["vit.embed"] = x
+        for i, block in enumerate(w.blocks):
+            x = x + attn(layer_norm(x, block.ln1), block.attn, n_heads=cfg.enc_n_heads)
+            x = x + mlp(layer_norm(x, block.ln2), block.mlp)
+            if i in (0, cfg.enc_n_layers - 1):
+                taps[f"vit.block{i}"] = x
+        x = layer_norm(x, w.post_ln)
+        taps["vit.out"] = x
+        full = model._vis_enc(crops)
+        assert torch.equal(full, x), "step-by-step ViT differs from vision_encoder()"
+        local = x[1:].view(-1, cfg.enc_n_layers, cfg.enc_n_layers, cfg.enc_dim)
+        rec = reconstruct_from_crops(local, tiling, patch_size=1, overlap_margin=cfg.overlap_margin)
+        taps["vis.proj"] = model._vis_proj(x[0], rec)
+    return taps, tiling
+
+
+def model_pixel_lut(model):
+    """What the reference's prepare_crops makes of each of the 256 byte values."""
+    from PIL import Image
+    from moondream.torch.vision import prepare_crops
+
+    ramp = np.zeros((378, 378, 3), dtype=np.uint8)
+    ramp[0, :256, 0] = np.arange(256)
+    crops, _ = prepare_crops(Image.fromarray(ramp, "RGB"), model.config.vision, device="cpu")
+    return crops[0, 0, 0, :256].clone()
+
+
+def gen_model_case(name, cfg_name, seed, image_sizes, max_tokens, full_tensors, n_images=1, min_margin=1.0):
+    cfg = get_config(cfg_name)
+    t0 = time.perf_counter()
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    print(f"[{name}] synthetic weights in {time.perf_counter()-t0:.1f}s", flush=True)
+    model, ref_md = load_reference(cfg, sd)
+    caption_ids = cfg.tokenizer.templates["caption"]["normal"]
+    out = {"seed": np.int64(seed), "cfg": np.array(cfg_name)}
+    # Keep only images on which EVERY greedy decision of the reference has a
+    # top-1/top-2 margin >= min_margin (several bf16 ulps at these logit
+    # magnitudes): on those, token ids are a well-posed integer output that two
+    # correct bf16 implementations must agree on bit-for-bit.
+    idx, src = 0, -1
+    image_index = []
+    while idx < n_images:
+        src += 1
+        assert src < 400, "could not find enough wide-margin images"
+        size = image_sizes[idx % len(image_sizes)]
+        image = synth.synthetic_image_array(src, seed, size)
+        first = run_reference_caption(model, ref_md, image, caption_ids, max_tokens)
+        if min(first["margins"]) < min_margin:
+            print(f"[{name}] skip image {src}: min margin {min(first['margins']):.3f}", flush=True)
+            continue
+        image_index.append(src)
+        for kind, prompt in (("cap", caption_ids), ("vqa", synth.synthetic_vqa_prompt(cfg, src, seed))):
+            if kind == "vqa" and idx > 0:
+                continue
+            r = first if kind == "cap" else run_reference_caption(model, ref_md, image, prompt, max_tokens)
+            p = f"img{idx}.{kind}."
+            out[p + "size"] = np.array(size)
+            out[p + "prompt"] = np.array(prompt)
+            out[p + "tokens"] = np.array(r["tokens"])
+            out[p + "margins"] = np.array(r["margins"], dtype=np.float32)
+            out[p + "argmaxes"] = np.array(r["argmaxes"])
+            out[p + "pos"] = np.int64(r["enc"].pos)
+            if full_tensors:
+                out[p + "step_logits"] = bf16_bits(torch.stack(r["steps"]))
+            else:
+                top = torch.topk(torch.stack(r["steps"]).float(), 8, dim=-1)
+                out[p + "top8_val"] = top.values.numpy()
+                out[p + "top8_idx"] = top.indices.numpy()
+            print(
+                f"[{name}] img{idx} {kind}: {len(r['tokens'])} tokens, min margin "
+                f"{min(r['margins']):.4f}, encode {r['t_enc']:.2f}s gen {r['t_gen']:.2f}s",
+                flush=True,
+            )
+            if kind == "cap":
+                # sampled KV rows written by the image prefill (layer 0 and last)
+                L = cfg.text.n_layers
+                for li in (0, L - 1):
+                    k, v = r["enc"].caches[li]
+                    out[p + f"k{li}"] = bf16_bits(k[0, :, ::37])
+                    out[p + f"v{li}"] = bf16_bits(v[0, :, ::37])
+                rs = 1 if full_tensors else 23
+                out[p + "image_prefill_hidden"] = bf16_bits(r["image_prefill_hidden"][::rs])
+                out[p + "prompt_hidden"] = bf16_bits(r["prompt_hidden"])
+                out["kv_row_stride"] = np.int64(37)
+                out["hidden_row_stride"] = np.int64(rs)
+        if idx == 0:
+            taps, tiling = reference_vision_taps(model, ref_md, image)
+            out["img0.tiling"] = np.array(tiling)
+            out["img0.crops_norm_lut"] = bf16_bits(
+                model_pixel_lut(model)
+            )
+            for k, t in taps.items():
+                if k == "crops_norm":
+                    out["img0.crops_norm_crc"] = np.int64(zlib.crc32(bf16_bits(t).tobytes()))
+                    continue
+                if full_tensors and k in ("vit.out", "vis.proj"):
+                    out["img0." + k] = bf16_bits(t)
+                elif t.dim() == 3:
+                    out["img0." + k] = bf16_bits(t[:, ::9] if full_tensors else t[:, ::31, ::5])
+                else:
+                    out["img0." + k] = bf16_bits(t[::9] if full_tensors else t[::31, ::5])
+            out["vit_token_stride"] = np.int64(9 if full_tensors else 31)
+            out["vit_feat_stride"] = np.int64(1 if full_tensors else 5)
+        idx += 1
+    out["image_index"] = np.array(image_index)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
+
+
+def gen_multicrop():
+    """Tiny model on non-square images: exercises tiling, stitch and the
+    non-trivial adaptive pool."""
+    cfg = get_config("tiny")
+    sd = synth.synthetic_state_dict(cfg, seed=3)
+    model, ref_md = load_reference(cfg, sd)
+    out = {}
+    for i, size in enumerate([(500, 700), (420, 1000), (900, 640)]):
+        image = synth.synthetic_image_array(i, 3, size)
+        taps, tiling = reference_vision_taps(model, ref_md, image)
+        out[f"case{i}.size"] = np.array(size)
+        out[f"case{i}.tiling"] = np.array(tiling)
+        out[f"case{i}.vis.proj"] = bf16_bits(taps["vis.proj"])
+        out[f"case{i}.vit.out"] = bf16_bits(taps["vit.out"][:, ::27])
+        print(f"[multicrop] {size} -> tiling {tiling}", flush=True)
+    path = os.path.join(GOLD, "tiny_multicrop.npz")
+    np.savez_compressed(path, **out)
+    print(f"[multicrop] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
+def gen_crops():
+    """Host-side integer work: select_tiling table and crop checksums from the
+    reference's PIL-LANCZOS branch (pyvips is not installed here).
+    reference: image_crops.py:17-167."""
+    from moondream.torch.image_crops import select_tiling, overlap_crop_image, HAS_VIPS
+
+    assert not HAS_VIPS
+    sizes = []
+    for h in list(range(1, 1400, 37)) + [266, 267, 378, 379, 532, 533, 644, 645, 2048, 4000]:
+        for w in list(range(1, 1400, 41)) + [266, 267, 378, 379, 532, 533, 644, 645, 2048, 4000]:
+            sizes.append((h, w))
+    table = np.array(
+        [[h, w, *select_tiling(h, w, 266, 12)] for (h, w) in sizes], dtype=np.int32
+    )
+    out = {"tiling_table": table}
+    img_sizes = [(378, 378), (300, 200), (800, 600), (480, 640), (768, 1024), (1000, 333), (97, 1300), (1500, 1500)]
+    crcs = []
+    for i, (h, w) in enumerate(img_sizes):
+        img = synth.synthetic_image_array(i, 11, (h, w))
+        r = overlap_crop_image(img, overlap_margin=4, max_crops=12)
+        crcs.append([h, w, r["tiling"][0], r["tiling"][1], len(r["crops"]), zlib.crc32(r["crops"].tobytes())])
+        print(f"[crops] {(h, w)} -> tiling {r['tiling']} n={len(r['crops'])}")
+    out["crop_cases"] = np.array(crcs, dtype=np.int64)
+    path = os.path.join(GOLD, "image_crops.npz")
+    np.savez_compressed(path, **out)
+    print(f"[crops] wrote {path}")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["tiny", "multicrop", "crops"]
+    if "crops" in which:
+        gen_crops()
+    if "tiny" in which:
+        gen_model_case("tiny_seed1", "tiny", 1, [(378, 378)], 24, True, n_images=3)
+    if "multicrop" in which:
+        gen_multicrop()
+    if "0.5b" in which:
+        gen_model_case("md05b_seed1", "0.5b", 1, [(378, 378)], 32, False, n_images=2, min_margin=0.5)
+    if "2b" in which:
+        gen_model_case("md2b_seed1", "2b", 1, [(378, 378)], 32, False, n_images=3, min_margin=0.5)
+
+
+if __name__ == "__main__":
+    main()

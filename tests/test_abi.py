@@ -1,0 +1,49 @@
+"""The C-ABI library loads and exports every symbol include/moondream_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from moondream_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "moondream_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(md_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == _lib.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build_library(verbose=False)
+    lib = _lib.load()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.md_abi_version() == 1
+    assert lib.md_status_string(0) == b"ok"
+    assert b"workspace" in lib.md_status_string(3)
+
+
+def test_argument_validation_needs_no_gpu():
+    """Contract violations are rejected on the host, before any launch."""
+    lib = _lib.load()
+    args = _lib.MdGemmArgs()  # all null
+    assert lib.md_gemm_bf16(ctypes.byref(args), None) == 1
+    assert lib.md_gemm_bf16(None, None) == 1
+    assert lib.md_vit_workspace_bytes(None, 4) == 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "moondream_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "moondream_oracle" not in src and "oracle/" not in src, f

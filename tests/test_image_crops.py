@@ -1,0 +1,60 @@
+"""Host tiling: (1) the reference's own three tests (reference:
+tests/test_image_crops.py:6-57) run against this package's implementation,
+(2) bit-exact crops and tilings against goldens recorded from the reference."""
+import os
+import zlib
+
+import numpy as np
+import torch
+
+from moondream_amd import synth
+from moondream_amd.image_crops import overlap_crop_image, reconstruct_from_crops, select_tiling
+
+
+def test_overlap_crop_basic():
+    img = np.zeros((800, 600, 3), dtype=np.uint8)
+    img[300:500, 200:400] = 255
+    r = overlap_crop_image(img, overlap_margin=4, max_crops=12)
+    assert r["crops"][0].shape == (378, 378, 3)
+    assert len(r["crops"]) > 1
+    assert all(c.shape == (378, 378, 3) for c in r["crops"])
+    assert len(r["tiling"]) == 2
+
+
+def test_overlap_crop_small_image():
+    r = overlap_crop_image(np.zeros((300, 200, 3), dtype=np.uint8), overlap_margin=4, max_crops=12)
+    assert r["crops"][0].shape == (378, 378, 3)
+    assert len(r["crops"]) == 2
+    assert r["tiling"] == (1, 1)
+
+
+def test_reconstruction():
+    img = np.zeros((800, 600, 3), dtype=np.uint8)
+    img[300:500, 200:400] = 255
+    r = overlap_crop_image(img, overlap_margin=4, max_crops=12)
+    rec = reconstruct_from_crops([torch.from_numpy(c) for c in r["crops"][1:]], r["tiling"], overlap_margin=4).numpy()
+    cy, cx = rec.shape[0] // 2, rec.shape[1] // 2
+    assert rec[cy - 100 : cy + 100, cx - 100 : cx + 100].mean() > rec[:100, :100].mean() + 100
+
+
+def test_tiling_table_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "image_crops.npz"))
+    for h, w, th, tw in g["tiling_table"]:
+        assert select_tiling(int(h), int(w), 266, 12) == (int(th), int(tw)), (h, w)
+
+
+def test_crops_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "image_crops.npz"))
+    for i, (h, w, th, tw, n, crc) in enumerate(g["crop_cases"]):
+        img = synth.synthetic_image_array(i, 11, (int(h), int(w)))
+        r = overlap_crop_image(img, overlap_margin=4, max_crops=12)
+        assert tuple(r["tiling"]) == (int(th), int(tw))
+        assert len(r["crops"]) == int(n)
+        assert zlib.crc32(r["crops"].tobytes()) == int(crc), (h, w)
+
+
+def test_identical_crops_at_378():
+    """At <= 378 px the global and the single local crop are the same pixels
+    (SURVEY.md section 7); both are still encoded."""
+    r = overlap_crop_image(synth.synthetic_image_array(0, 0), overlap_margin=4, max_crops=12)
+    assert r["tiling"] == (1, 1) and np.array_equal(r["crops"][0], r["crops"][1])

@@ -97,6 +97,15 @@ typedef struct {
 
 md_status md_gemm_bf16(const md_gemm_args* args, void* stream);
 
+/* Live timing of the GEMM launches for the roofline report: while enabled,
+ * md_gemm_bf16 brackets every launch with HIP events on the caller's stream.
+ * md_profile_gemm(0|1) also resets the log.  md_profile_gemm_read waits for the
+ * recorded events and returns the summed ALGORITHMIC flops (2 m n k with the
+ * logical n, k), the summed kernel time in ms and the launch count.  Not for
+ * use inside hipGraph capture. */
+void md_profile_gemm(int32_t enable);
+md_status md_profile_gemm_read(double* flops, double* ms, int64_t* launches);
+
 /* y[r, :dim] = LN(x[r, :dim]) * w + b, fp32 statistics, eps as given
  * (reference: layers.py:118-119, default eps 1e-5).  dim % 8 == 0, dim <= 4096. */
 md_status md_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const md_layernorm* p,

@@ -27,7 +27,18 @@
 //     tiles and share A/W slices through their private L2.
 #include "md_common.hpp"
 
+#include <vector>
+
 namespace {
+
+// Optional live timing (bench.py's roofline leg): HIP events recorded on the
+// caller's stream around every GEMM launch, read back with md_profile_gemm_read.
+struct ProfRec {
+  hipEvent_t start, stop;
+  double flops;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
 
 struct GemmK {
   const bf16_t* A;
@@ -241,12 +252,8 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
 // always runs the same kernel -- and every config accumulates K in the same
 // order (sequential 16-wide MFMA steps), so results do not depend on it.
 int pick_tile(int M, int n_store) {
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("MD_GEMM_TILE");
-    forced = e ? atoi(e) : -1;
-  }
-  if (forced >= 0) return forced;
+  const char* e = getenv("MD_GEMM_TILE");  // experiments / tests: force a tile config
+  if (e && *e) return atoi(e);
   const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 128};
   const double eff[3] = {1.0, 0.85, 0.7};
   const int slots[3] = {256, 256, 512};
@@ -292,12 +299,50 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.tiles_m = k.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
   const int tile = pick_tile(k.M, k.n_store);
-  switch (a->epilogue) {
-    case MD_EPI_BIAS: return launch_epi<MD_EPI_BIAS>(k, tile, s);
-    case MD_EPI_GELU: return launch_epi<MD_EPI_GELU>(k, tile, s);
-    case MD_EPI_RESIDUAL:
-      MD_CHECK_ARG(a->r != nullptr && a->ldr % 8 == 0 && ((uintptr_t)a->r & 15) == 0);
-      return launch_epi<MD_EPI_RESIDUAL>(k, tile, s);
-    default: return MD_ERR_INVALID_ARG;
+  if (a->epilogue == MD_EPI_RESIDUAL)
+    MD_CHECK_ARG(a->r != nullptr && a->ldr % 8 == 0 && ((uintptr_t)a->r & 15) == 0);
+  ProfRec rec;
+  const bool prof = g_prof_on;
+  if (prof) {
+    if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return MD_ERR_LAUNCH;
+    rec.flops = 2.0 * a->m * (double)a->lin.n * (double)a->lin.k;  // algorithmic: logical n, k
+    (void)hipEventRecord(rec.start, s);
   }
+  md_status st;
+  switch (a->epilogue) {
+    case MD_EPI_BIAS: st = launch_epi<MD_EPI_BIAS>(k, tile, s); break;
+    case MD_EPI_GELU: st = launch_epi<MD_EPI_GELU>(k, tile, s); break;
+    case MD_EPI_RESIDUAL: st = launch_epi<MD_EPI_RESIDUAL>(k, tile, s); break;
+    default: st = MD_ERR_INVALID_ARG;
+  }
+  if (prof) {
+    (void)hipEventRecord(rec.stop, s);
+    g_prof.push_back(rec);
+  }
+  return st;
+}
+
+extern "C" void md_profile_gemm(int32_t enable) {
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  g_prof.clear();
+  g_prof_on = enable != 0;
+}
+
+extern "C" md_status md_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
+  MD_CHECK_ARG(flops && ms && launches);
+  double f = 0, t = 0;
+  for (auto& r : g_prof) {
+    float e = 0;
+    if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&e, r.start, r.stop) != hipSuccess)
+      return MD_ERR_LAUNCH;
+    f += r.flops;
+    t += e;
+  }
+  *flops = f;
+  *ms = t;
+  *launches = (int64_t)g_prof.size();
+  return MD_OK;
 }

@@ -1,0 +1,117 @@
+"""Image-level data parallelism: one process per GPU, RCCL over xGMI.
+
+The path shards by independent units (images): every image's vision pass, KV
+slab and decode loop is independent of every other image's (the reference's
+batch entry point is a plain loop, hf_moondream.py:99-103).  So there is no
+collective on the data path.  RCCL is used for exactly two things
+(SURVEY.md section 8e):
+
+  * once, at start-up: broadcast the checkpoint from rank 0 (one flat bf16
+    buffer -> one large collective, sized for the per-link xGMI bandwidth
+    instead of ~600 small ones);
+  * once per batch: gather the int32 token ids (a few KB) on rank 0.
+
+``backend="nccl"`` is RCCL on ROCm; the same code runs over ``gloo`` on CPU
+tensors, which is how tests/test_dist_cpu.py covers it with world_size 2.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the
+    default process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous block of items for ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def broadcast_state_dict(
+    sd: Optional[Dict[str, torch.Tensor]],
+    template: Dict[str, Tuple[Tuple[int, ...], torch.dtype]],
+    device,
+    src: int = 0,
+) -> Dict[str, torch.Tensor]:
+    """Rank ``src`` holds ``sd``; every rank returns a full copy on ``device``.
+
+    ``template`` (name -> (shape, dtype)) is known everywhere from the config, so
+    only payload bytes travel: all tensors are packed into ONE flat uint8 buffer
+    and sent with a single broadcast."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert sd is not None
+        return {k: v.to(device) for k, v in sd.items()}
+    names = sorted(template)
+    sizes = [int(torch.empty(template[n][0], dtype=template[n][1]).numel()) * torch.empty((), dtype=template[n][1]).element_size() for n in names]
+    offsets, total = [], 0
+    for s in sizes:
+        offsets.append(total)
+        total += (s + 255) // 256 * 256
+    flat = torch.empty(total, dtype=torch.uint8, device=device)
+    if dist.get_rank() == src:
+        assert sd is not None
+        for n, o, s in zip(names, offsets, sizes):
+            flat[o : o + s] = sd[n].to(device).contiguous().view(torch.uint8).reshape(-1)
+    dist.broadcast(flat, src=src)
+    out = {}
+    for n, o, s in zip(names, offsets, sizes):
+        shape, dtype = template[n]
+        out[n] = flat[o : o + s].view(dtype).reshape(shape)
+    return out
+
+
+def state_dict_template(sd: Dict[str, torch.Tensor]) -> Dict[str, Tuple[Tuple[int, ...], torch.dtype]]:
+    return {k: (tuple(v.shape), v.dtype) for k, v in sd.items()}
+
+
+def gather_token_ids(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+    """local: int32 [B_local, T].  Rank ``dst`` gets the list of every rank's block
+    (in rank order = image order under ``shard_range``); others get None."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [local]
+    world = dist.get_world_size()
+    # block sizes may differ by one row: exchange the row counts first
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    mx = int(max(int(c) for c in counts))
+    pad = torch.zeros(mx, local.shape[1], dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    if dist.get_rank() != dst:
+        return None
+    return [b[: int(c)] for b, c in zip(bufs, counts)]
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

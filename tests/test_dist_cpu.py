@@ -1,0 +1,62 @@
+"""The N>1 path (shard -> per-rank work -> gather) on CPU with gloo, world_size 2."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from moondream_amd import dist as mdist
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                seen += list(mdist.shard_range(n, r, world))
+            assert seen == list(range(n))
+            sizes = [len(mdist.shard_range(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = mdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    # 1. weight broadcast from rank 0
+    full = {"a.weight": torch.arange(12, dtype=torch.float32).reshape(3, 4).to(torch.bfloat16), "b": torch.tensor([7], dtype=torch.int32), "c": torch.randn(5, 5, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16)}
+    tpl = mdist.state_dict_template(full)
+    got = mdist.broadcast_state_dict(full if rank == 0 else None, tpl, "cpu")
+    for k in full:
+        assert torch.equal(got[k], full[k]), k
+    # 2. shard 7 "images", fake per-rank decode (ids derive from the image index), gather on rank 0
+    mine = mdist.shard_range(7, rank, world)
+    local = torch.tensor([[i * 10 + t for t in range(4)] for i in mine], dtype=torch.int32).reshape(len(mine), 4)
+    blocks = mdist.gather_token_ids(local)
+    t = mdist.max_over_ranks(float(rank + 1), "cpu")
+    assert t == float(world)
+    mdist.barrier()
+    if rank == 0:
+        allids = torch.cat(blocks, 0)
+        assert allids.tolist() == [[i * 10 + t for t in range(4)] for i in range(7)]
+        open(os.path.join(out_dir, "ok"), "w").write("1")
+    else:
+        assert blocks is None
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()

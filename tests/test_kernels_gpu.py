@@ -1,0 +1,299 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel, called through the
+C ABI, against a plain fp32 torch restatement of the same op (and against the
+CPU oracle's functions where one exists).  Sizes cover the awkward shapes of
+the real models: K = 588, head_dim 72, 729 tokens, FF 4304, ragged M."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from moondream_amd import _lib
+from moondream_amd.weights import PackedLinear, PackedLayerNorm, rope_table, reference_pixel_lut
+from util import compare
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return _lib.load()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def randn(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF16).cuda()
+
+
+def gemm(lib, a, lin, epi=0, r=None, res_row_mod=0, store_pad=0, out=None):
+    m = a.shape[0]
+    width = lin.n_pad if store_pad else lin.n
+    c = out if out is not None else torch.full((m, width), float("nan"), dtype=BF16, device="cuda")
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), lin.struct(), c.data_ptr(), c.stride(0),
+                           r.data_ptr() if r is not None else None, r.stride(0) if r is not None else 0,
+                           res_row_mod, m, epi, store_pad)
+    _lib.check(lib.md_gemm_bf16(C.byref(args), stream()), "gemm")
+    torch.cuda.synchronize()
+    return c
+
+
+def ref_linear(a, w, b):
+    return (a.float() @ w.float().t() + b.float()).to(BF16)
+
+
+def pad_k(a, k_pad):
+    out = torch.zeros(a.shape[0], k_pad, dtype=BF16, device="cuda")
+    out[:, : a.shape[1]] = a
+    return out
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+def test_gemm_identity_detects_transposes(lib, tile, monkeypatch):
+    """A = I with an ASYMMETRIC W: C must equal W^T bit for bit."""
+    monkeypatch.setenv("MD_GEMM_TILE", tile)
+    n = k = 512
+    w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(BF16).cuda()
+    a = torch.eye(k, dtype=BF16, device="cuda")
+    lin = PackedLinear(w, torch.zeros(n, dtype=BF16), "cuda")
+    c = gemm(lib, a, lin)
+    assert torch.equal(c, w.t().contiguous())
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("m,k,n", [(300, 588, 1152), (777, 1152, 3456), (1000, 2048, 6144), (64, 2048, 1024), (1, 256, 64)])
+def test_gemm_bias(lib, tile, m, k, n, monkeypatch):
+    monkeypatch.setenv("MD_GEMM_TILE", tile)
+    a, w, b = randn(m, k, seed=1), randn(n, k, scale=1 / math.sqrt(k), seed=2), randn(n, scale=0.1, seed=3)
+    lin = PackedLinear(w, b, "cuda")
+    c = gemm(lib, pad_k(a, lin.k_pad), lin)
+    compare(f"gemm_bias {m}x{k}x{n} tile{tile}", c, ref_linear(a, w, b), 3e-3, 2e-2)
+
+
+def test_gemm_gelu_writes_zero_pad_columns(lib):
+    m, k, n = 515, 1152, 4304
+    a, w, b = randn(m, k, seed=4), randn(n, k, scale=1 / math.sqrt(k), seed=5), randn(n, scale=0.1, seed=6)
+    lin = PackedLinear(w, b, "cuda")
+    assert lin.n_pad == 4352
+    c = gemm(lib, a, lin, epi=_lib.MD_EPI_GELU, store_pad=1)
+    ref = torch.nn.functional.gelu(ref_linear(a, w, b).float(), approximate="tanh").to(BF16)
+    compare("gemm_gelu", c[:, :n], ref, 3e-3, 2e-2)
+    assert torch.count_nonzero(c[:, n:]) == 0
+
+
+def test_gemm_residual_in_place_and_row_mod(lib):
+    m, k, n = 2 * 729, 4352, 1152
+    a, w, b = randn(m, k, seed=7), randn(n, k, scale=1 / math.sqrt(k), seed=8), randn(n, scale=0.1, seed=9)
+    x = randn(m, n, seed=10)
+    lin = PackedLinear(w, b, "cuda")
+    ref = (x.float() + ref_linear(a, w, b).float()).to(BF16)
+    out = x.clone()
+    gemm(lib, a, lin, epi=_lib.MD_EPI_RESIDUAL, r=out, out=out)  # r aliases c, like x += f(x)
+    compare("gemm_residual_inplace", out, ref, 3e-3, 2e-2)
+    pos = randn(729, n, seed=11)  # pos_emb broadcast over crops
+    ref2 = (pos.float().repeat(2, 1) + ref_linear(a, w, b).float()).to(BF16)
+    c2 = gemm(lib, a, lin, epi=_lib.MD_EPI_RESIDUAL, r=pos, res_row_mod=729)
+    compare("gemm_residual_rowmod", c2, ref2, 3e-3, 2e-2)
+
+
+def test_gemm_batch_invariance(lib):
+    """Row i of the result must not depend on M (batched == sequential decode)."""
+    k, n = 2048, 2048
+    a, w, b = randn(64, k, seed=12), randn(n, k, scale=1 / math.sqrt(k), seed=13), randn(n, scale=0.1, seed=14)
+    lin = PackedLinear(w, b, "cuda")
+    full = gemm(lib, a, lin)
+    for rows in (1, 5, 33):
+        assert torch.equal(gemm(lib, a[:rows].contiguous(), lin), full[:rows])
+    big = gemm(lib, randn(1000, k, seed=12)[:1000].contiguous(), lin)
+    assert torch.equal(big[:64], gemm(lib, randn(1000, k, seed=12)[:64].contiguous(), lin))
+
+
+@pytest.mark.parametrize("rows,dim", [(7, 144), (1458, 1152), (730, 2048), (3, 720), (5, 256)])
+def test_layernorm(lib, rows, dim):
+    x = randn(rows, dim, scale=3.0, seed=15) + 0.5
+    w, b = randn(dim, scale=0.1, seed=16) + 1.0, randn(dim, scale=0.1, seed=17)
+    ln = PackedLayerNorm(w, b, "cuda")
+    ld = (dim + 63) // 64 * 64
+    y = torch.zeros(rows, ld, dtype=BF16, device="cuda")
+    st = ln.struct()
+    _lib.check(lib.md_layernorm_bf16(x.data_ptr(), dim, y.data_ptr(), ld, C.byref(st), rows, dim, 1e-5, stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.float(), (dim,), w.float(), b.float(), 1e-5).to(BF16)
+    compare(f"layernorm {rows}x{dim}", y[:, :dim], ref, 2e-3, 1e-2)
+    assert torch.count_nonzero(y[:, dim:]) == 0
+
+
+def test_patchify_both_inputs(lib):
+    from oracle import moondream_oracle as O
+
+    rng = np.random.default_rng(0)
+    crops = rng.integers(0, 256, (3, 378, 378, 3), dtype=np.uint8)
+    lut = reference_pixel_lut()
+    ref = O.patchify(O.normalize_crops(crops), 14)  # [3, 729, 588]
+    out = torch.full((3 * 729, 640), float("nan"), dtype=BF16, device="cuda")
+    d_crops, d_lut = torch.from_numpy(crops).cuda(), lut.cuda()
+    _lib.check(lib.md_patchify_u8(d_crops.data_ptr(), d_lut.data_ptr(), out.data_ptr(), 640, 3, 378, 14, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :588].cpu(), ref.reshape(-1, 588))
+    assert torch.count_nonzero(out[:, 588:]) == 0
+    chw = O.normalize_crops(crops).cuda()
+    out2 = torch.full((3 * 729, 640), float("nan"), dtype=BF16, device="cuda")
+    _lib.check(lib.md_patchify_bf16(chw.data_ptr(), out2.data_ptr(), 640, 3, 378, 14, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+
+
+def ref_attention(q, k, v, allowed, scale):
+    """q [B,H,Tq,d], k/v [B,H,Tk,d] fp32 reference with bf16 probabilities (the oracle's model)."""
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if allowed is not None:
+        s = s.masked_fill(~allowed, float("-inf"))
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    l = p.sum(-1, keepdim=True)
+    return ((p.to(BF16).float() @ v.float()) / l).to(BF16)
+
+
+def run_prefill(lib, q, k, v, q_len, kv_len, prefix, pos0=None, kv_lens=None):
+    """q [B,Tq,H,d]; k,v [B,H,Tk,d] (slab layout)."""
+    b, tq, h, d = q.shape
+    tk = k.shape[2]
+    o = torch.full((b, tq, h * d), float("nan"), dtype=BF16, device="cuda")
+    a = _lib.MdAttnArgs()
+    a.q, a.q_bs, a.q_ts, a.q_hs = q.data_ptr(), tq * h * d, h * d, d
+    a.k, a.k_bs, a.k_ts, a.k_hs = k.data_ptr(), h * tk * d, d, tk * d
+    a.v, a.v_bs, a.v_ts, a.v_hs = v.data_ptr(), h * tk * d, d, tk * d
+    a.o, a.o_bs, a.o_ts, a.o_hs = o.data_ptr(), tq * h * d, h * d, d
+    a.batch, a.n_heads, a.n_kv_heads, a.head_dim = b, h, h, d
+    a.q_len, a.kv_len_all = q_len, kv_len
+    a.q_pos0 = pos0.data_ptr() if pos0 is not None else None
+    a.kv_len = kv_lens.data_ptr() if kv_lens is not None else None
+    a.prefix_len, a.scale = prefix, 1.0 / math.sqrt(d)
+    _lib.check(lib.md_attention_prefill(C.byref(a), stream()), "attn")
+    torch.cuda.synchronize()
+    return o.view(b, tq, h, d)
+
+
+@pytest.mark.parametrize("hd,t", [(72, 729), (72, 100), (64, 730), (64, 64), (64, 129)])
+def test_attention_no_mask(lib, hd, t):
+    b, h = 2, 3
+    q, k, v = randn(b, t, h, hd, seed=20), randn(b, h, t, hd, seed=21), randn(b, h, t, hd, seed=22)
+    o = run_prefill(lib, q, k, v, t, t, prefix=t)
+    ref = ref_attention(q.permute(0, 2, 1, 3), k, v, None, 1 / math.sqrt(hd)).permute(0, 2, 1, 3)
+    compare(f"attn hd{hd} t{t}", o, ref, 6e-3, 4e-2)
+
+
+def test_attention_spiky_scores_force_rescale(lib):
+    """One key dominates late in the sequence: the online-softmax rescale path."""
+    b, h, t, hd = 1, 2, 300, 72
+    q, k, v = randn(b, t, h, hd, seed=23), randn(b, h, t, hd, seed=24), randn(b, h, t, hd, seed=25)
+    k[:, :, 250] = q[:, 7].clone() * 4.0  # q row 7 . k row 250 >> everything else
+    o = run_prefill(lib, q, k, v, t, t, prefix=t)
+    ref = ref_attention(q.permute(0, 2, 1, 3), k, v, None, 1 / math.sqrt(hd)).permute(0, 2, 1, 3)
+    compare("attn spiky", o, ref, 6e-3, 4e-2)
+
+
+@pytest.mark.parametrize("q_len,pos", [(730, 0), (5, 730), (32, 730), (1, 735), (200, 650)])
+def test_attention_prefix_lm_against_slab(lib, q_len, pos):
+    """Decoder prefill: queries at pos..pos+q_len-1 against keys [0, pos+q_len) of a
+    2048-slot slab with the prefix-LM rule (prefix 730), per-sequence positions."""
+    from oracle.moondream_oracle import prefix_lm_allowed
+
+    b, h, hd, ctx, prefix = 2, 4, 64, 2048, 730
+    q = randn(b, q_len, h, hd, seed=26)
+    k, v = randn(b, h, ctx, hd, seed=27), randn(b, h, ctx, hd, seed=28)
+    pos0 = torch.tensor([pos, max(pos - 3, 0)], dtype=torch.int32, device="cuda")
+    kv_lens = pos0 + q_len
+    o = run_prefill(lib, q, k, v, q_len, 0, prefix, pos0, kv_lens)
+    for bi in range(b):
+        p0 = int(pos0[bi])
+        allowed = prefix_lm_allowed(torch.arange(p0, p0 + q_len), p0 + q_len, prefix).cuda()
+        ref = ref_attention(q[bi].permute(1, 0, 2), k[bi, :, : p0 + q_len], v[bi, :, : p0 + q_len], allowed, 1 / 8.0)
+        compare(f"prefix-lm q{q_len} pos{p0}", o[bi], ref.permute(1, 0, 2), 6e-3, 4e-2)
+
+
+def test_attention_decode(lib):
+    b, h, hd, ctx = 3, 4, 64, 2048
+    q = randn(b, h * hd * 3, seed=29)  # rows with a leading dimension like the fused qkv activation
+    k, v = randn(b, h, ctx, hd, seed=30), randn(b, h, ctx, hd, seed=31)
+    lens = torch.tensor([736, 1, 2048], dtype=torch.int32, device="cuda")
+    o = torch.full((b, h * hd), float("nan"), dtype=BF16, device="cuda")
+    _lib.check(lib.md_attention_decode(q.data_ptr(), q.stride(0), o.data_ptr(), h * hd, k.data_ptr(), v.data_ptr(),
+                                       h * ctx * hd, ctx, lens.data_ptr(), b, h, h, hd, 0.125, stream()))
+    torch.cuda.synchronize()
+    for bi in range(b):
+        n = int(lens[bi])
+        qq = q[bi, : h * hd].view(h, 1, hd)
+        ref = ref_attention(qq, k[bi, :, :n], v[bi, :, :n], None, 0.125)
+        compare(f"decode attn len{n}", o[bi].view(h, 1, hd), ref, 6e-3, 4e-2)
+
+
+def test_rope_kv_write(lib):
+    from oracle.moondream_oracle import apply_rope, rope_table as o_rope_table
+
+    b, t, h, hd, ctx, rot = 2, 9, 4, 64, 256, 32
+    qkv = randn(b * t, 3 * h * hd, seed=32)
+    orig = qkv.clone()
+    freqs = rope_table(rot, ctx).cuda()
+    pos0 = torch.tensor([100, 7], dtype=torch.int32, device="cuda")
+    ks = torch.zeros(b, h, ctx, hd, dtype=BF16, device="cuda")
+    vs = torch.zeros_like(ks)
+    _lib.check(lib.md_rope_kv_write(qkv.data_ptr(), qkv.stride(0), freqs.data_ptr(), pos0.data_ptr(), ks.data_ptr(),
+                                    vs.data_ptr(), h * ctx * hd, ctx, b, t, h, h, hd, rot, stream()))
+    torch.cuda.synchronize()
+    cos, sin = o_rope_table(rot // 2, ctx)
+    assert torch.equal(torch.stack([cos, sin], -1), freqs.cpu())  # same table as the oracle
+    o = orig.cpu().view(b, t, 3, h, hd)
+    for bi in range(b):
+        pos = torch.arange(int(pos0[bi]), int(pos0[bi]) + t)
+        qr = apply_rope(o[bi, :, 0].permute(1, 0, 2), cos, sin, pos, rot)
+        kr = apply_rope(o[bi, :, 1].permute(1, 0, 2), cos, sin, pos, rot)
+        got_q = qkv.cpu().view(b, t, 3, h, hd)[bi, :, 0].permute(1, 0, 2)
+        assert torch.equal(got_q, qr)
+        assert torch.equal(ks.cpu()[bi][:, pos], kr)
+        assert torch.equal(vs.cpu()[bi][:, pos], o[bi, :, 2].permute(1, 0, 2))
+    assert torch.equal(qkv.cpu().view(b, t, 3, h, hd)[:, :, 1:], o[:, :, 1:])  # k, v left in place untouched
+
+
+def test_embed_and_argmax(lib):
+    vocab, dim = 51200, 2048
+    table = randn(vocab, dim, seed=33)
+    ids = torch.tensor([0, 51199, 7, 7, 12345], dtype=torch.int32, device="cuda")
+    out = torch.empty(5, dim, dtype=BF16, device="cuda")
+    _lib.check(lib.md_embed_tokens(ids.data_ptr(), table.data_ptr(), dim, out.data_ptr(), dim, 5, dim, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, table[ids.long()])
+    logits = randn(4, vocab, seed=34)
+    logits[0, 100] = logits[0, 40000] = 50.0  # tie -> lowest index
+    logits[1, 3] = 60.0  # suppressed
+    logits[1, 77] = 55.0
+    logits[2, vocab - 1] = 70.0
+    nxt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.md_argmax_bf16(logits.data_ptr(), vocab, 4, vocab, 3, nxt.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    ref = logits.float().clone()
+    ref[:, 3] = float("-inf")
+    assert nxt.tolist()[:3] == [100, 77, vocab - 1]
+    assert int(nxt[3]) == int(torch.argmax(ref[3]))
+
+
+@pytest.mark.parametrize("th,tw", [(1, 1), (2, 3), (3, 4), (4, 1)])
+def test_stitch_pool_concat(lib, th, tw):
+    from oracle import moondream_oracle as O
+
+    dim, g, margin = 144, 27, 4
+    feats = randn(1 + th * tw, g * g, dim, seed=35)
+    out = torch.full((g * g, 2 * dim + 32), float("nan"), dtype=BF16, device="cuda")
+    _lib.check(lib.md_stitch_pool_concat(feats.data_ptr(), out.data_ptr(), out.stride(0), dim, g, margin, th, tw, stream()))
+    torch.cuda.synchronize()
+    f = feats.cpu()
+    stitched = O.stitch_local_features(f[1:].reshape(-1, g, g, dim), (th, tw), margin)
+    pooled = O.adaptive_avg_pool_hw(stitched, g).reshape(g * g, dim)
+    assert torch.equal(out[:, :dim].cpu(), f[0])
+    compare(f"stitch_pool {th}x{tw}", out[:, dim : 2 * dim], pooled, 2e-3, 1e-2)

@@ -177,16 +177,21 @@ def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c=4.0, s0=0.1):
     # perm(t) = (a*t + b) mod V  ->  perm^-1(v) = a_inv * (v - b) mod V
     t_even = (a_inv * (((rows & ~1) - b) % V)) % V
     t_odd = (a_inv * (((rows | 1) - b) % V)) % V
+    # Reductions (norms, dot products) run in float64 and are rounded to fp32 once, so
+    # that CPU and GPU generation give the same bits despite different summation
+    # orders; everything else is elementwise IEEE arithmetic.
     wte = sd["text.wte"].float()
-    unit = wte / wte.norm(dim=-1, keepdim=True)
+    unit = wte / wte.double().norm(dim=-1, keepdim=True).float()
     r = hash_uniform(D, _key("text.lm_head.context_dir", seed), device) * math.sqrt(3.0)
-    r = r / r.norm()  # <LN(h), r> ~ N(0,1) for |LN(h)| ~ sqrt(D)
+    r = r / r.double().norm().float()  # <LN(h), r> ~ N(0,1) for |LN(h)| ~ sqrt(D)
     sign = torch.where((rows & 1) == 0, 1.0, -1.0).to(torch.float32).unsqueeze(1)
     noise = hash_uniform(V * D, _key("text.lm_head.weight", seed), device).reshape(V, D)
     ue, uo = unit[t_even], unit[t_odd]
     # context direction with the pair's own token directions projected out, so the
     # winning bit is not a function of the current token's embedding alone
-    r_pair = r.unsqueeze(0) - (ue @ r).unsqueeze(1) * ue - (uo @ r).unsqueeze(1) * uo
+    dot_e = (ue.double() @ r.double()).float().unsqueeze(1)
+    dot_o = (uo.double() @ r.double()).float().unsqueeze(1)
+    r_pair = r.unsqueeze(0) - dot_e * ue - dot_o * uo
     w = beta * (ue + uo) + c * sign * r_pair + noise * (s0 * math.sqrt(3.0 / D))
     sd["text.lm_head.weight"] = w.to(dtype)
     bias = _tensor("text.lm_head.bias", (V,), 0.05, seed, device, torch.float32)

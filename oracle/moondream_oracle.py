@@ -251,7 +251,10 @@ def rope_table(rot_half: int, n_pos: int, theta: float = 10000.0):
     dim = 2 * rot_half
     freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32)[:rot_half] / dim))
     ang = torch.arange(n_pos, dtype=torch.float32).unsqueeze(1) * freqs.unsqueeze(0)
-    return torch.cos(ang), torch.sin(ang)
+    # the reference builds the table as exp(i * angle) in complex64 (rope.py:16-17);
+    # its real/imag parts are not bit-identical to cos()/sin() of the fp32 angle
+    cis = torch.exp(1j * ang)
+    return cis.real.contiguous(), cis.imag.contiguous()
 
 
 def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, rot_dim: int):
@@ -436,7 +439,7 @@ class Oracle:
     def fourier(self, x: torch.Tensor, w: torch.Tensor):
         """reference: region.py:12-29; bf16 matmul, bf16 scalar multiply, then
         cos/sin in bf16."""
-        f = _r(_r(_r(x.float() * (2 * math.pi))).float() @ w.float())
+        f = _r(_r(x.float() * (2 * math.pi)).float() @ w.float())
         return torch.cat([_r(torch.cos(f.float())), _r(torch.sin(f.float()))], dim=-1)
 
     def encode_coordinate(self, c: torch.Tensor):

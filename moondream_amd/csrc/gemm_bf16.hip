@@ -29,6 +29,8 @@
 
 #include <vector>
 
+md_status md_gemm_skinny(const md_gemm_args* a, hipStream_t stream);  // gemm_skinny.hip
+
 namespace {
 
 // Optional live timing (bench.py's roofline leg): HIP events recorded on the
@@ -309,6 +311,11 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
     (void)hipEventRecord(rec.start, s);
   }
   md_status st;
+  // decode regime: <= 64 rows is a weight stream, not a matrix-core problem
+  const char* forced = getenv("MD_GEMM_TILE");
+  if (a->m <= 64 && !(forced && *forced)) {
+    st = md_gemm_skinny(a, s);
+  } else
   switch (a->epilogue) {
     case MD_EPI_BIAS: st = launch_epi<MD_EPI_BIAS>(k, tile, s); break;
     case MD_EPI_GELU: st = launch_epi<MD_EPI_GELU>(k, tile, s); break;

@@ -111,8 +111,25 @@ def test_gemm_batch_invariance(lib):
     full = gemm(lib, a, lin)
     for rows in (1, 5, 33):
         assert torch.equal(gemm(lib, a[:rows].contiguous(), lin), full[:rows])
-    big = gemm(lib, randn(1000, k, seed=12)[:1000].contiguous(), lin)
-    assert torch.equal(big[:64], gemm(lib, randn(1000, k, seed=12)[:64].contiguous(), lin))
+    # big-tile regime: M = 1000 and M = 200 pick different tile configs
+    a2 = randn(1000, k, seed=12)
+    assert torch.equal(gemm(lib, a2, lin)[:200], gemm(lib, a2[:200].contiguous(), lin))
+
+
+@pytest.mark.parametrize("m", [1, 7, 33, 64])
+@pytest.mark.parametrize("k,n,epi", [(2048, 6144, 0), (2048, 8192, 1), (8192, 2048, 2), (588, 1152, 0), (256, 1024, 2)])
+def test_gemm_decode_regime(lib, m, k, n, epi):
+    """m <= 64 dispatches to the weight-streaming kernel (in-workgroup split-K)."""
+    a, w, b = randn(m, k, seed=40), randn(n, k, scale=1 / math.sqrt(k), seed=41), randn(n, scale=0.1, seed=42)
+    lin = PackedLinear(w, b, "cuda")
+    r = randn(m, n, seed=43)
+    c = gemm(lib, pad_k(a, lin.k_pad), lin, epi=epi, r=r if epi == 2 else None)
+    ref = ref_linear(a, w, b)
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref.float(), approximate="tanh").to(BF16)
+    if epi == 2:
+        ref = (r.float() + ref.float()).to(BF16)
+    compare(f"skinny m{m} {k}x{n} epi{epi}", c, ref, 3e-3, 2e-2)
 
 
 @pytest.mark.parametrize("rows,dim", [(7, 144), (1458, 1152), (730, 2048), (3, 720), (5, 256)])

@@ -93,18 +93,30 @@ typedef struct {
   int32_t m;
   int32_t epilogue;
   int32_t store_pad_cols; /* 1: also store columns [n, n_pad) */
+  /* Scratch for the decode regime (m <= 64), where K is split over several
+   * workgroups per output tile: md_gemm_workspace_bytes() bytes, or NULL (then K
+   * is not split across workgroups: slower, and a different -- still
+   * deterministic -- summation tree).  Its first 8 KiB are arrival tickets:
+   * they must be ZERO before the first launch that uses the buffer; every launch
+   * leaves them zero, so launches that follow each other on one stream can share
+   * the buffer. */
+  void* splitk_ws;
+  size_t splitk_ws_bytes;
 } md_gemm_args;
 
 md_status md_gemm_bf16(const md_gemm_args* args, void* stream);
+size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols);
 
 /* Live timing of the GEMM launches for the roofline report: while enabled,
  * md_gemm_bf16 brackets every launch with HIP events on the caller's stream.
  * md_profile_gemm(0|1) also resets the log.  md_profile_gemm_read waits for the
- * recorded events and returns the summed ALGORITHMIC flops (2 m n k with the
- * logical n, k), the summed kernel time in ms and the launch count.  Not for
- * use inside hipGraph capture. */
+ * recorded events of one kernel family and returns its summed ALGORITHMIC work,
+ * kernel time in ms and launch count: kind 0 = the MFMA tile kernel (m > 64),
+ * work = flops 2 m n k; kind 1 = the decode-regime weight-streaming kernel
+ * (m <= 64), work = weight bytes 2 n k (logical n, k).  Not for use inside
+ * hipGraph capture. */
 void md_profile_gemm(int32_t enable);
-md_status md_profile_gemm_read(double* flops, double* ms, int64_t* launches);
+md_status md_profile_gemm_read(int32_t kind, double* work, double* ms, int64_t* launches);
 
 /* y[r, :dim] = LN(x[r, :dim]) * w + b, fp32 statistics, eps as given
  * (reference: layers.py:118-119, default eps 1e-5).  dim % 8 == 0, dim <= 4096. */

@@ -37,7 +37,7 @@ class MdGemmArgs(C.Structure):
     _fields_ = [
         ("a", c_void_p), ("lda", c_int64), ("lin", MdLinear), ("c", c_void_p), ("ldc", c_int64),
         ("r", c_void_p), ("ldr", c_int64), ("res_row_mod", c_int32), ("m", c_int32),
-        ("epilogue", c_int32), ("store_pad_cols", c_int32),
+        ("epilogue", c_int32), ("store_pad_cols", c_int32), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_size_t),
     ]
 
 
@@ -90,8 +90,9 @@ SIGNATURES = {
     "md_abi_version": (C.c_int, []),
     "md_status_string": (C.c_char_p, [C.c_int]),
     "md_gemm_bf16": (C.c_int, [P(MdGemmArgs), c_void_p]),
+    "md_gemm_workspace_bytes": (c_size_t, [P(MdLinear), c_int32, c_int32]),
     "md_profile_gemm": (None, [c_int32]),
-    "md_profile_gemm_read": (C.c_int, [P(C.c_double), P(C.c_double), P(c_int64)]),
+    "md_profile_gemm_read": (C.c_int, [c_int32, P(C.c_double), P(C.c_double), P(c_int64)]),
     "md_layernorm_bf16": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_float, c_void_p]),
     "md_patchify_u8": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "md_patchify_bf16": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),

@@ -4,6 +4,8 @@
 // including the workspace, belongs to the caller.
 #include "md_common.hpp"
 
+#include <algorithm>
+
 md_status md_argmax_advance(const void* logits, int64_t ld, int32_t batch, int32_t vocab,
                             int32_t suppress_id, int32_t* next, int32_t* pos, hipStream_t stream);
 md_status md_stitch_pool_batched(const void* feats, void* out, int64_t ld_out, int64_t out_img_stride,
@@ -35,8 +37,11 @@ struct Arena {
   } while (0)
 
 md_status gemm(const void* a, int64_t lda, const md_linear& lin, void* c, int64_t ldc, int m, int epi,
-               const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s) {
+               const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s,
+               void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
   md_gemm_args g;
+  g.splitk_ws = splitk_ws;
+  g.splitk_ws_bytes = splitk_bytes;
   g.a = a;
   g.lda = lda;
   g.lin = lin;
@@ -76,7 +81,8 @@ md_status zero_if_padded(void* p, size_t rows, int ld, int width, hipStream_t s)
 }
 
 struct TextWs {
-  void *h, *qkv, *att, *ff, *pos_kv;
+  void *h, *qkv, *att, *ff, *pos_kv, *splitk;
+  size_t splitk_bytes;
   size_t total;
 };
 
@@ -90,6 +96,15 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
   w.att = a.take(M * m->blocks[0].proj.k_pad * 2);
   w.ff = a.take(M * m->blocks[0].fc1.n_pad * 2);
   w.pos_kv = a.take((size_t)batch * 4);
+  // decode regime: split-K scratch shared by the layer's four linears (stream-ordered)
+  size_t sk = 0;
+  if (M <= 64) {
+    const md_text_block& b0 = m->blocks[0];
+    sk = std::max(std::max(md_gemm_workspace_bytes(&b0.qkv, (int)M, 0), md_gemm_workspace_bytes(&b0.proj, (int)M, 0)),
+                  std::max(md_gemm_workspace_bytes(&b0.fc1, (int)M, 1), md_gemm_workspace_bytes(&b0.fc2, (int)M, 0)));
+  }
+  w.splitk_bytes = sk;
+  w.splitk = a.take(sk);
   w.total = a.off;
   return w;
 }
@@ -261,6 +276,9 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     if (hipMemcpyAsync(hidden, x_in, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return MD_ERR_LAUNCH;
   }
+  if (w.splitk_bytes) {
+    if (hipMemsetAsync(w.splitk, 0, 8192, s) != hipSuccess) return MD_ERR_LAUNCH;  // arrival tickets
+  }
   int32_t* kv_len = (int32_t*)w.pos_kv;
   hipLaunchKernelGGL(kv_len_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pos0, kv_len, q_len, batch);
   const float scale = 1.0f / sqrtf((float)hd);
@@ -272,7 +290,7 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     // l_in = ln(x)                                            (text.py:145)
     MD_TRY(md_layernorm_bf16(x, D, w.h, Dp, &b.ln, M, D, 1e-5f, s));
     // qkv, rope(q), rope(k), cache update                      (text.py:30-46)
-    MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));
+    MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s, w.splitk, w.splitk_bytes));
     MD_TRY(md_rope_kv_write(w.qkv, qkv_w, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
                             q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
     // attention over the slab                                   (text.py:48-51)
@@ -307,10 +325,10 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       MD_TRY(md_attention_prefill(&a, s));
     }
     // x = (x + proj(att)) + fc2(gelu(fc1(l_in)))               (text.py:53,157-158)
-    MD_TRY(gemm(w.att, Dp, b.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
-    MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, b.fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s));
+    MD_TRY(gemm(w.att, Dp, b.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
+    MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, b.fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, w.splitk, w.splitk_bytes));
     MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad);
-    MD_TRY(gemm(w.ff, b.fc1.n_pad, b.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
+    MD_TRY(gemm(w.ff, b.fc1.n_pad, b.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
   }
   return MD_OK;
 }

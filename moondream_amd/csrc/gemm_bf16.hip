@@ -27,9 +27,11 @@
 //     tiles and share A/W slices through their private L2.
 #include "md_common.hpp"
 
+#include <type_traits>
 #include <vector>
 
 md_status md_gemm_skinny(const md_gemm_args* a, hipStream_t stream);  // gemm_skinny.hip
+size_t md_gemm_skinny_ws_bytes(const md_linear* lin, int store_pad);
 
 namespace {
 
@@ -37,7 +39,8 @@ namespace {
 // caller's stream around every GEMM launch, read back with md_profile_gemm_read.
 struct ProfRec {
   hipEvent_t start, stop;
-  double flops;
+  double work;  // kind 0: algorithmic flops; kind 1: weight bytes streamed
+  int kind;     // 0 = MFMA tile kernel, 1 = decode-regime weight-streaming kernel
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -56,6 +59,25 @@ struct GemmK {
 
 constexpr int BK = 64;           // K slice (elements) = 128 B per row
 constexpr int ROW_BYTES = BK * 2;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ds_read_b128 the compiler does not track: the caller waits (wait_lgkm) before use
+template <int OFF>
+__device__ __forceinline__ void ds_read_b128(bf16x8& dst, uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+}
 
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
@@ -132,8 +154,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   // fragment read offsets: row = (tile row base, multiple of 32) + l31, so the
   // swizzle term (row >> 1) & 7 depends on the lane only
   const int swz = (l31 >> 1) & 7;
-  const int a_row_off = (wm * TM + l31) * ROW_BYTES;
-  const int b_row_off = A_BYTES + (wn * TN + l31) * ROW_BYTES;
+  const uint32_t a_row_off = (wm * TM + l31) * ROW_BYTES;
+  const uint32_t b_row_off = A_BYTES + (wn * TN + l31) * ROW_BYTES;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int nk = p.K / BK;
   stage_load(0);
@@ -143,23 +166,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < nk) stage_load((t + 1) & 1);
-    const char* st = smem + (t & 1) * STAGE;
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int coff = ((2 * s + hi) ^ swz) * 16;
-      bf16x8 af[MI], bfr[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = *(const bf16x8*)(st + a_row_off + i * 32 * ROW_BYTES + coff);
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        bfr[j] = *(const bf16x8*)(st + b_row_off + j * 32 * ROW_BYTES + coff);
+    // LDS -> register fragments, software pipelined by hand: the six ds_read_b128 of
+    // K-step s+1 are issued BEFORE the eight MFMAs of step s and waited for with a
+    // counted lgkmcnt (LDS returns in order), so the matrix pipe never waits on LDS
+    // latency inside a slice.  (The two waves of a SIMD leave the barrier in
+    // lockstep and cannot cover for each other; left to itself hipcc sinks every
+    // read next to its use and waits lgkmcnt(0) in front of each MFMA group.)
+    // Inline asm: the compiler neither counts these reads nor moves MFMAs across
+    // the sched_barrier that follows each wait (cdna guide 5.7, form iii).
+    const uint32_t st = lds_base + (t & 1) * STAGE;
+    bf16x8 af[2][MI], bfr[2][NI];
+    auto issue_reads = [&](auto set_c, auto step_c) {
+      constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
+      const uint32_t coff = (uint32_t)(((2 * S + hi) ^ swz) * 16);
+      const uint32_t a_addr = st + a_row_off + coff, b_addr = st + b_row_off + coff;
+      static_for<0, NI>([&](auto j) { ds_read_b128<decltype(j)::value * 32 * ROW_BYTES>(bfr[SET][decltype(j)::value], b_addr); });
+      static_for<0, MI>([&](auto i) { ds_read_b128<decltype(i)::value * 32 * ROW_BYTES>(af[SET][decltype(i)::value], a_addr); });
+    };
+    issue_reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    static_for<0, BK / 16>([&](auto sc) {
+      constexpr int S = decltype(sc)::value, SET = S & 1;
+      if constexpr (S + 1 < BK / 16) {
+        issue_reads(std::integral_constant<int, (S + 1) & 1>{}, std::integral_constant<int, S + 1>{});
+        wait_lgkm<MI + NI>();  // everything but the reads just issued has landed
+      } else {
+        wait_lgkm<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][j], af[SET][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 
   // ---- epilogue -----------------------------------------------------------
@@ -279,7 +319,8 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   MD_CHECK_ARG(a && a->a && a->c && a->lin.w);
   MD_CHECK_ARG(a->m > 0 && a->lin.n > 0 && a->lin.k > 0);
   MD_CHECK_ARG(a->lin.k_pad % BK == 0 && a->lin.k_pad >= a->lin.k);
-  MD_CHECK_ARG(a->lin.n_pad % 64 == 0 && a->lin.n_pad >= a->lin.n && a->lin.n % 8 == 0);
+  MD_CHECK_ARG(a->lin.n_pad % 64 == 0 && a->lin.n_pad >= a->lin.n);
+  MD_CHECK_ARG(a->store_pad_cols || a->lin.n % 8 == 0);  // rows are stored in 16-byte pieces
   MD_CHECK_ARG(a->lda >= a->lin.k_pad && a->lda % 8 == 0 && a->ldc % 8 == 0);
   MD_CHECK_ARG(((uintptr_t)a->a & 15) == 0 && ((uintptr_t)a->c & 15) == 0 && ((uintptr_t)a->lin.w & 15) == 0);
   GemmK k;
@@ -307,7 +348,9 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   const bool prof = g_prof_on;
   if (prof) {
     if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return MD_ERR_LAUNCH;
-    rec.flops = 2.0 * a->m * (double)a->lin.n * (double)a->lin.k;  // algorithmic: logical n, k
+    rec.kind = a->m <= 64 ? 1 : 0;
+    rec.work = rec.kind ? 2.0 * (double)a->lin.n * (double)a->lin.k           // bf16 weight bytes, logical n, k
+                        : 2.0 * a->m * (double)a->lin.n * (double)a->lin.k;  // algorithmic flops
     (void)hipEventRecord(rec.start, s);
   }
   md_status st;
@@ -329,6 +372,11 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   return st;
 }
 
+extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols) {
+  if (!lin || m > 64) return 0;
+  return md_gemm_skinny_ws_bytes(lin, store_pad_cols);
+}
+
 extern "C" void md_profile_gemm(int32_t enable) {
   for (auto& r : g_prof) {
     (void)hipEventDestroy(r.start);
@@ -338,18 +386,21 @@ extern "C" void md_profile_gemm(int32_t enable) {
   g_prof_on = enable != 0;
 }
 
-extern "C" md_status md_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
-  MD_CHECK_ARG(flops && ms && launches);
+extern "C" md_status md_profile_gemm_read(int32_t kind, double* work, double* ms, int64_t* launches) {
+  MD_CHECK_ARG(work && ms && launches);
   double f = 0, t = 0;
+  int64_t n = 0;
   for (auto& r : g_prof) {
+    if (r.kind != kind) continue;
     float e = 0;
     if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&e, r.start, r.stop) != hipSuccess)
       return MD_ERR_LAUNCH;
-    f += r.flops;
+    f += r.work;
     t += e;
+    ++n;
   }
-  *flops = f;
+  *work = f;
   *ms = t;
-  *launches = (int64_t)g_prof.size();
+  *launches = n;
   return MD_OK;
 }

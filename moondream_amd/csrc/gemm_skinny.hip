@@ -3,19 +3,21 @@
 // With at most 64 activation rows (one per sequence in flight) the layer is a
 // stream over the weights: every W byte is used by <= 64 rows, so the bound is
 // HBM bandwidth (2.6 GB of weights per decode step), not
-// the matrix cores.  The big-tile kernel would put N/256 workgroups on 256 CUs;
-// this one instead
-//   * gives every workgroup 32 weight rows and ALL of K, split over its 8 waves
-//     (in-workgroup split-K, combined in a FIXED order through LDS, so results
-//     are deterministic and independent of how many rows M are live -- the
-//     batched decode must equal the sequential one bit for bit);
-//   * streams W straight into MFMA operand registers (16 B per lane, row =
-//     lane & 31; four consecutive K-steps cover a full 128-byte line per row),
-//     eight loads in flight per wave, no LDS round trip for the operand that is
-//     read exactly once;
-//   * reads the activations (<= 64 x K bf16, L2-resident) the same way.
-// MFMA is used because it is the cheapest way to do 64 rows x 32 cols x 16 k of
-// FMAs per instruction, not because the kernel is compute bound.
+// the matrix cores.  A CU streams ~10 B/clk at best, so the whole chip has to
+// pull: the grid is (N / 32 weight-row tiles) x (S K-slices), S chosen so that
+// ~1000 workgroups of 4 waves are resident, each wave streaming its own K range
+// with 8 x 1 KiB loads in flight straight into MFMA operand registers (row =
+// lane & 31, 16 B per lane; four consecutive K-steps consume a full 128-byte
+// line per row; no LDS round trip for data that is read exactly once).
+//
+// Reduction over K is DETERMINISTIC and independent of M: the 4 waves of a
+// workgroup combine through LDS in wave order; the S workgroups of a tile
+// publish fp32 slabs and the last one to arrive (agent-scope release -> ticket
+// -> acquire, cdna guide section 6 guideline 16) sums them in slice order and
+// runs the epilogue.  So batched decode equals sequential decode bit for bit.
+//
+// MFMA is used because it is the cheapest way to issue 64 rows x 32 cols x 16 k
+// of FMAs per instruction, not because the kernel is compute bound.
 #include "md_common.hpp"
 
 namespace {
@@ -26,26 +28,31 @@ struct SkinnyK {
   const bf16_t* bias;
   const bf16_t* R;
   bf16_t* C;
+  float* slabs;        // [tile][slice][MT*16*64] fp32, slices > 1 only
+  unsigned* tickets;   // [tile], zero on entry, left zero on exit
   int64_t ldx, ldw, ldc, ldr;
   int M, n_store, n_pad, K;
-  int res_row_mod;
+  int res_row_mod, slices;
 };
 
-constexpr int SK_WAVES = 8;
-constexpr int SK_UNROLL = 4;
+constexpr int SK_WAVES = 4;
+constexpr int SK_U = 8;  // K-steps (1 KiB weight loads) in flight per wave
 
 template <int MT, int EPI>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const SkinnyK p) {
-  __shared__ float part[SK_WAVES][MT][16][64];  // [wave][m tile][acc reg][lane]
+  __shared__ float part[SK_WAVES][MT][16][64];  // [wave][m tile][acc reg][lane]; part[0][0][0][0] doubles as the "last" flag
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int n0 = blockIdx.x * 32;
+  const int tile = blockIdx.x, slice = blockIdx.y;
+  const int n0 = tile * 32;
 
-  // K range of this wave: whole 16-wide steps, contiguous
+  // contiguous range of 16-wide K-steps for this (slice, wave)
   const int steps = p.K / 16;
-  const int per = (steps + SK_WAVES - 1) / SK_WAVES;
-  const int s0 = min(wave * per, steps), s1 = min(s0 + per, steps);
+  const int parts = p.slices * SK_WAVES;
+  const int per = (steps + parts - 1) / parts;
+  const int q = slice * SK_WAVES + wave;
+  const int s0 = min(q * per, steps), s1 = min(s0 + per, steps);
 
   const bf16_t* wrow = p.W + (int64_t)min(n0 + l31, p.n_pad - 1) * p.ldw + 8 * hi;
   const bf16_t* xrow[MT];
@@ -58,26 +65,23 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const Skinny
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  int s = s0;
-  for (; s + SK_UNROLL <= s1; s += SK_UNROLL) {
-    bf16x8 wf[SK_UNROLL], xf[SK_UNROLL][MT];
+  for (int s = s0; s < s1; s += SK_U) {
+    bf16x8 wf[SK_U];
 #pragma unroll
-    for (int u = 0; u < SK_UNROLL; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wrow + (s + u) * 16));
+    for (int u = 0; u < SK_U; ++u) {
+      const int ss = min(s + u, s1 - 1);  // tail: replay the last step's address, result discarded below
+      wf[u] = __builtin_nontemporal_load((const bf16x8*)(wrow + ss * 16));
+    }
 #pragma unroll
-    for (int u = 0; u < SK_UNROLL; ++u)
+    for (int u = 0; u < SK_U; ++u) {
+      if (s + u < s1) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[u][mt] = *(const bf16x8*)(xrow[mt] + (s + u) * 16);
-#pragma unroll
-    for (int u = 0; u < SK_UNROLL; ++u)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[u][mt], acc[mt], 0, 0, 0);
-  }
-  for (; s < s1; ++s) {
-    const bf16x8 wf = *(const bf16x8*)(wrow + s * 16);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, *(const bf16x8*)(xrow[mt] + s * 16), acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 xf = *(const bf16x8*)(xrow[mt] + (s + u) * 16);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf, acc[mt], 0, 0, 0);
+        }
+      }
+    }
   }
 
 #pragma unroll
@@ -86,17 +90,57 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const Skinny
     for (int r = 0; r < 16; ++r) part[wave][mt][r][lane] = acc[mt][r];
   __syncthreads();
 
-  // combine the 8 K-partials in wave order, then the reference's rounding points
-  for (int slot = tid; slot < MT * 16 * 64; slot += SK_WAVES * 64) {
-    const int ln = slot & 63, r = (slot >> 6) & 15, mt = slot >> 10;
-    float v = 0.f;
+  constexpr int SLOTS = MT * 16 * 64, PER_T = SLOTS / (SK_WAVES * 64);
+  float v[PER_T];
 #pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) v += part[w][mt][r][ln];
+  for (int i = 0; i < PER_T; ++i) {
+    const int slot = tid + i * SK_WAVES * 64;
+    const int ln = slot & 63, r = (slot >> 6) & 15, mt = slot >> 10;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) a += part[w][mt][r][ln];
+    v[i] = a;
+  }
+
+  if (p.slices > 1) {
+    // publish this slice's slab, take a ticket; the last arriver reduces
+    float* slab = p.slabs + ((int64_t)tile * p.slices + slice) * SLOTS;
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) slab[tid + i * SK_WAVES * 64] = v[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // also orders the reads of part[] above before the flag write below
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      part[0][0][0][0] = (t == (unsigned)p.slices - 1u) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (part[0][0][0][0] == 0.f) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    const float* base = p.slabs + (int64_t)tile * p.slices * SLOTS;
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) v[i] = 0.f;
+    for (int sl = 0; sl < p.slices; ++sl)  // fixed slice order: deterministic sum
+#pragma unroll
+      for (int i = 0; i < PER_T; ++i) v[i] += base[(int64_t)sl * SLOTS + tid + i * SK_WAVES * 64];
+  }
+
+  // the reference's rounding points: bf16(acc + bias), then the elementwise op
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int slot = tid + i * SK_WAVES * 64;
+    const int ln = slot & 63, r = (slot >> 6) & 15, mt = slot >> 10;
     const int m = mt * 32 + (ln & 31);
     const int n = n0 + 8 * (r >> 2) + 4 * (ln >> 5) + (r & 3);
     if (m < p.M && n < p.n_store) {
-      if (p.bias != nullptr) v += bf2f(p.bias[n]);
-      float y = bf2f(f2bf(v));
+      float a = v[i];
+      if (p.bias != nullptr) a += bf2f(p.bias[n]);
+      float y = bf2f(f2bf(a));
       if constexpr (EPI == MD_EPI_GELU) {
         y = gelu_tanh_f32(y);
       } else if constexpr (EPI == MD_EPI_RESIDUAL) {
@@ -110,7 +154,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const Skinny
 
 template <int EPI>
 md_status launch(const SkinnyK& k, hipStream_t s) {
-  dim3 grid((k.n_store + 31) / 32), block(SK_WAVES * 64);
+  dim3 grid((k.n_store + 31) / 32, k.slices), block(SK_WAVES * 64);
   if (k.M <= 32)
     hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI>), grid, block, 0, s, k);
   else
@@ -118,7 +162,26 @@ md_status launch(const SkinnyK& k, hipStream_t s) {
   return md_launch_status();
 }
 
+// K-slices so that ~1024 workgroups are resident; a function of the layer shape
+// only (never of M), so the summation tree of a row never depends on the batch.
+int pick_slices(int n_store, int k_pad) {
+  const int tiles = (n_store + 31) / 32;
+  int s = 1;
+  while (s < 8 && tiles * s * 2 <= 1024 && k_pad / (16 * SK_WAVES * s * 2) >= 2) s *= 2;
+  return s;
+}
+
 }  // namespace
+
+constexpr size_t SK_TICKET_BYTES = 8192;  // fixed-size ticket area at the head of the scratch (<= 1024 tiles when sliced)
+
+size_t md_gemm_skinny_ws_bytes(const md_linear* lin, int store_pad) {
+  const int n_store = store_pad ? lin->n_pad : lin->n;
+  const int s = pick_slices(n_store, lin->k_pad);
+  if (s == 1) return 0;
+  const size_t tiles = (n_store + 31) / 32;
+  return SK_TICKET_BYTES + tiles * s * (2 * 16 * 64) * sizeof(float);
+}
 
 // internal: called by md_gemm_bf16 for m <= 64
 md_status md_gemm_skinny(const md_gemm_args* a, hipStream_t stream) {
@@ -137,6 +200,18 @@ md_status md_gemm_skinny(const md_gemm_args* a, hipStream_t stream) {
   k.n_store = a->store_pad_cols ? a->lin.n_pad : a->lin.n;
   k.K = a->lin.k_pad;
   k.res_row_mod = a->res_row_mod;
+  k.slices = pick_slices(k.n_store, k.K);
+  k.slabs = nullptr;
+  k.tickets = nullptr;
+  if (k.slices > 1) {
+    const size_t need = md_gemm_skinny_ws_bytes(&a->lin, a->store_pad_cols);
+    if (a->splitk_ws == nullptr || a->splitk_ws_bytes < need) {
+      k.slices = 1;  // no scratch from the caller: single-slice (still deterministic, just slower)
+    } else {
+      k.tickets = (unsigned*)a->splitk_ws;
+      k.slabs = (float*)((char*)a->splitk_ws + SK_TICKET_BYTES);
+    }
+  }
   switch (a->epilogue) {
     case MD_EPI_BIAS: return launch<MD_EPI_BIAS>(k, stream);
     case MD_EPI_GELU: return launch<MD_EPI_GELU>(k, stream);

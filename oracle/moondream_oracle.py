@@ -40,6 +40,17 @@ def _r(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------
 # primitive ops
 # --------------------------------------------------------------------------
+_FP32_CACHE: Dict[int, torch.Tensor] = {}
+
+
+def cache_fp32_weights(sd: Dict[str, torch.Tensor]) -> None:
+    """Keep fp32 copies of every 2-D weight so that the timed CPU baseline measures
+    the contractions, not bf16 -> fp32 conversion of 2B parameters per call."""
+    for v in sd.values():
+        if v.dim() == 2 and v.dtype == BF16:
+            _FP32_CACHE[id(v)] = v.float()
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], fast: bool = False):
     """y = bf16( fp32(x) . fp32(w)^T + fp32(b) ).  reference: layers.py:34-35
     (F.linear on bf16 operands).  ``fast`` routes the same contraction through
@@ -47,7 +58,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], fast: bo
     fp32 copies of 2B parameters; the rounding points are identical."""
     if fast:
         return F.linear(x, w, b)
-    y = x.float() @ w.float().t()
+    w32 = _FP32_CACHE.get(id(w))
+    y = x.float() @ (w.float() if w32 is None else w32).t()
     if b is not None:
         y = y + b.float()
     return _r(y)

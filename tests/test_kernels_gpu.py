@@ -33,13 +33,20 @@ def randn(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).to(BF16).cuda()
 
 
-def gemm(lib, a, lin, epi=0, r=None, res_row_mod=0, store_pad=0, out=None):
+_SPLITK_WS = {}  # zeroed once; every launch leaves the ticket area zero again
+
+
+def gemm(lib, a, lin, epi=0, r=None, res_row_mod=0, store_pad=0, out=None, use_ws=True):
     m = a.shape[0]
     width = lin.n_pad if store_pad else lin.n
     c = out if out is not None else torch.full((m, width), float("nan"), dtype=BF16, device="cuda")
-    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), lin.struct(), c.data_ptr(), c.stride(0),
+    st = lin.struct()
+    need = lib.md_gemm_workspace_bytes(C.byref(st), m, store_pad)
+    ws = _SPLITK_WS.setdefault(need, torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")) if use_ws else None
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0),
                            r.data_ptr() if r is not None else None, r.stride(0) if r is not None else 0,
-                           res_row_mod, m, epi, store_pad)
+                           res_row_mod, m, epi, store_pad, ws.data_ptr() if ws is not None else None,
+                           need if ws is not None else 0)
     _lib.check(lib.md_gemm_bf16(C.byref(args), stream()), "gemm")
     torch.cuda.synchronize()
     return c
@@ -130,6 +137,14 @@ def test_gemm_decode_regime(lib, m, k, n, epi):
     if epi == 2:
         ref = (r.float() + ref.float()).to(BF16)
     compare(f"skinny m{m} {k}x{n} epi{epi}", c, ref, 3e-3, 2e-2)
+    # same scratch, launched again (tickets were left zero), and row-subset invariance
+    assert torch.equal(c, gemm(lib, pad_k(a, lin.k_pad), lin, epi=epi, r=r if epi == 2 else None))
+    if m > 1:
+        sub = gemm(lib, pad_k(a, lin.k_pad)[:1].contiguous(), lin, epi=epi, r=r[:1].contiguous() if epi == 2 else None)
+        assert torch.equal(sub, c[:1])
+    # without scratch K is not split across workgroups: still correct
+    c1 = gemm(lib, pad_k(a, lin.k_pad), lin, epi=epi, r=r if epi == 2 else None, use_ws=False)
+    compare(f"skinny(no scratch) m{m} {k}x{n}", c1, ref, 3e-3, 2e-2)
 
 
 @pytest.mark.parametrize("rows,dim", [(7, 144), (1458, 1152), (730, 2048), (3, 720), (5, 256)])

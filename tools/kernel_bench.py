@@ -42,7 +42,10 @@ def bench_gemm(m, k, n, epi=0, tiles=("0", "1", "2")):
         a[:, k:] = 0
     c = torch.empty(m, lin.n_pad, dtype=BF16, device="cuda")
     r = torch.randn(m, lin.n_pad, device="cuda").to(BF16)
-    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), lin.struct(), c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0)
+    st = lin.struct()
+    need = lib.md_gemm_workspace_bytes(C.byref(st), m, 0)
+    ws = torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, ws.data_ptr(), need)
     res = []
     for t in tiles:
         os.environ["MD_GEMM_TILE"] = t
@@ -51,7 +54,8 @@ def bench_gemm(m, k, n, epi=0, tiles=("0", "1", "2")):
     os.environ.pop("MD_GEMM_TILE", None)
     dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())))
     auto = 2.0 * m * n * k / dt / 1e12
-    print(f"gemm m={m:6d} k={k:5d} n={n:5d} epi={epi}: " + " ".join(f"tile{t}={x:7.1f}" for t, x in zip(tiles, res)) + f"  auto={auto:7.1f} TF/s", flush=True)
+    extra = f"  ({2.0*n*k/dt/1e12:5.2f} TB/s weights, {dt*1e6:6.1f} us)" if m <= 64 else ""
+    print(f"gemm m={m:6d} k={k:5d} n={n:5d} epi={epi}: " + " ".join(f"tile{t}={x:7.1f}" for t, x in zip(tiles, res)) + f"  auto={auto:7.1f} TF/s" + extra, flush=True)
 
 
 def bench_attn(b, h, t, hd, prefix=None):

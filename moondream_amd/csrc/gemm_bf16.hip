@@ -125,21 +125,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
     b_src[j] = (const char*)(p.W + row * p.ldw + c * 8);
   }
 
-  auto stage_load = [&](int stage) {
+  // one 16-byte-per-lane LDS-DMA piece (1 KiB per wave) of slice `stage`
+  auto issue_piece = [&](auto piece_c, int stage) {
+    constexpr int P = decltype(piece_c)::value;
     char* base = smem + stage * STAGE + wave * (64 * 16);
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_src[j],
-                                       (__attribute__((address_space(3))) void*)(base + j * NT * 16),
-                                       16, 0, 0);
-      a_src[j] += ROW_BYTES;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)b_src[j],
-          (__attribute__((address_space(3))) void*)(base + A_BYTES + j * NT * 16), 16, 0, 0);
-      b_src[j] += ROW_BYTES;
+    if constexpr (P < NA) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_src[P],
+                                       (__attribute__((address_space(3))) void*)(base + P * NT * 16), 16, 0, 0);
+      a_src[P] += ROW_BYTES;
+    } else {
+      constexpr int Q = P - NA;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[Q],
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + Q * NT * 16), 16, 0, 0);
+      b_src[Q] += ROW_BYTES;
     }
   };
 
@@ -159,13 +157,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int nk = p.K / BK;
-  stage_load(0);
+  static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, 0); });
   for (int t = 0; t < nk; ++t) {
     // slice t has landed (own DMA: vmcnt; everybody's: barrier); the barrier also
-    // fences the previous iteration's reads of the buffer refilled below
+    // fences the previous iteration's reads of the buffer refilled during this one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < nk) stage_load((t + 1) & 1);
+    const bool has_next = t + 1 < nk;
+    const int nstage = (t + 1) & 1;
     // LDS -> register fragments, software pipelined by hand: the six ds_read_b128 of
     // K-step s+1 are issued BEFORE the eight MFMAs of step s and waited for with a
     // counted lgkmcnt (LDS returns in order), so the matrix pipe never waits on LDS
@@ -193,11 +192,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
         wait_lgkm<0>();
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][j], af[SET][i], acc[i][j], 0, 0, 0);
+      // The LDS-DMA pieces of slice t+1 are spread over the four K-steps and issued
+      // BETWEEN MFMAs: an LDS-DMA issue costs the wave 60-180 cycles, which hides
+      // under the 32-cycle-per-MFMA matrix pipe instead of idling it at the head
+      // of the slice.  Piece p goes to step p % 4.
+      static_for<0, MI * NI>([&](auto mc) {
+        constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
+        acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
+        constexpr int SLOT = (Mx == 1) ? 0 : (Mx == MI * NI / 2 + 1 ? 1 : -1);  // after MFMA #1 and #(half+1)
+        if constexpr (SLOT >= 0) {
+          constexpr int P = S + 4 * SLOT;
+          if constexpr (P < NA + NB) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) issue_piece(std::integral_constant<int, P>{}, nstage);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      });
       __builtin_amdgcn_sched_barrier(0);
     });
   }

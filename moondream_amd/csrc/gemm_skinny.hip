@@ -36,28 +36,28 @@ struct SkinnyK {
 };
 
 constexpr int SK_WAVES = 4;
-constexpr int SK_U = 8;  // K-steps (1 KiB weight loads) in flight per wave
+constexpr int SK_CHUNK = 256;                 // K elements of X staged in LDS per round (16 K-steps, 4 per wave)
+constexpr int SK_XSTR = SK_CHUNK * 2 + 16;    // padded LDS row stride (bytes): 16-B slots rotate by one per row
 
 template <int MT, int EPI>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const SkinnyK p) {
-  __shared__ float part[SK_WAVES][MT][16][64];  // [wave][m tile][acc reg][lane]; part[0][0][0][0] doubles as the "last" flag
+  // X chunk [MT*32 rows][256 k] during the K loop; afterwards reused as the
+  // [wave][m tile][acc reg][lane] partial-sum exchange (slot 0 doubles as the "last" flag)
+  constexpr int X_BYTES = MT * 32 * SK_XSTR, PART_BYTES = SK_WAVES * MT * 16 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) char lds[X_BYTES > PART_BYTES ? X_BYTES : PART_BYTES];
+  float(*part)[MT][16][64] = reinterpret_cast<float(*)[MT][16][64]>(lds);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int tile = blockIdx.x, slice = blockIdx.y;
   const int n0 = tile * 32;
 
-  // contiguous range of 16-wide K-steps for this (slice, wave)
-  const int steps = p.K / 16;
-  const int parts = p.slices * SK_WAVES;
-  const int per = (steps + parts - 1) / parts;
-  const int q = slice * SK_WAVES + wave;
-  const int s0 = min(q * per, steps), s1 = min(s0 + per, steps);
+  // this workgroup's K range: whole chunks, contiguous
+  const int chunks = (p.K + SK_CHUNK - 1) / SK_CHUNK;
+  const int per = (chunks + p.slices - 1) / p.slices;
+  const int c0 = min(slice * per, chunks), c1 = min(c0 + per, chunks);
 
   const bf16_t* wrow = p.W + (int64_t)min(n0 + l31, p.n_pad - 1) * p.ldw + 8 * hi;
-  const bf16_t* xrow[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) xrow[mt] = p.X + (int64_t)min(mt * 32 + l31, p.M - 1) * p.ldx + 8 * hi;
 
   f32x16 acc[MT];
 #pragma unroll
@@ -65,25 +65,42 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const Skinny
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  for (int s = s0; s < s1; s += SK_U) {
-    bf16x8 wf[SK_U];
+  for (int c = c0; c < c1; ++c) {
+    const int k0 = c * SK_CHUNK;
+    const int ksteps = min(SK_CHUNK, p.K - k0) / 16;  // K is a multiple of 64
+    // weights first: four 1 KiB loads per wave (a full 128-byte line per row) fly
+    // while the activations are staged
+    bf16x8 wf[4];
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) {
-      const int ss = min(s + u, s1 - 1);  // tail: replay the last step's address, result discarded below
-      wf[u] = __builtin_nontemporal_load((const bf16x8*)(wrow + ss * 16));
+    for (int u = 0; u < 4; ++u) {
+      const int st = min(4 * wave + u, ksteps - 1);
+      wf[u] = __builtin_nontemporal_load((const bf16x8*)(wrow + k0 + st * 16));
     }
+    // X chunk -> LDS in whole 16-byte pieces, coalesced along K (L2-resident, shared
+    // by all four waves; fragment-shaped global loads of X would triple the traffic
+    // through the per-CU load path)
+    __syncthreads();  // previous chunk fully consumed
+    for (int i = tid; i < MT * 32 * (SK_CHUNK / 8); i += SK_WAVES * 64) {
+      const int row = i / (SK_CHUNK / 8), ch = i % (SK_CHUNK / 8);
+      u32x4 v = {0, 0, 0, 0};
+      if (ch * 8 < ksteps * 16) v = *(const u32x4*)(p.X + (int64_t)min(row, p.M - 1) * p.ldx + k0 + ch * 8);
+      *(u32x4*)(lds + row * SK_XSTR + ch * 16) = v;
+    }
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) {
-      if (s + u < s1) {
+    for (int u = 0; u < 4; ++u) {
+      const int st = 4 * wave + u;
+      if (st < ksteps) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const bf16x8 xf = *(const bf16x8*)(xrow[mt] + (s + u) * 16);
+          const bf16x8 xf = *(const bf16x8*)(lds + (mt * 32 + l31) * SK_XSTR + st * 32 + hi * 16);
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf, acc[mt], 0, 0, 0);
         }
       }
     }
   }
 
+  __syncthreads();  // X buffer is dead; reuse it for the partials
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -113,7 +130,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const Skinny
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned t = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      part[0][0][0][0] = (t == (unsigned)p.slices - 1u) ? 1.f : 0.f;
+      part[0][0][0][0] = (t == (unsigned)p.slices - 1u) ? 1.f : 0.f;  // part[] was consumed before the barrier above
     }
     __syncthreads();
     if (part[0][0][0][0] == 0.f) return;
@@ -167,7 +184,8 @@ md_status launch(const SkinnyK& k, hipStream_t s) {
 int pick_slices(int n_store, int k_pad) {
   const int tiles = (n_store + 31) / 32;
   int s = 1;
-  while (s < 8 && tiles * s * 2 <= 1024 && k_pad / (16 * SK_WAVES * s * 2) >= 2) s *= 2;
+  const int chunks = (k_pad + SK_CHUNK - 1) / SK_CHUNK;
+  while (s < 8 && tiles * s * 2 <= 1024 && s * 2 <= chunks) s *= 2;
   return s;
 }
 

@@ -205,7 +205,7 @@ def main():
             "share_of_step": (ms.value * 1e-3) / elapsed if elapsed > 0 else None,
         },
         "decode_gemm": {
-            "bound": "hbm", "kernel": "gemm_skinny_kernel (m <= 64 weight stream)", "achieved": stream_gbs,
+            "bound": "hbm", "kernel": "gemm_bf16_kernel<64,128> split-K (m <= 64 weight stream)", "achieved": stream_gbs,
             "peak": 8000.0, "unit": "GB/s", "frac": stream_gbs / 8000.0, "launches": int(n1.value),
             "share_of_step": (ms1.value * 1e-3) / elapsed if elapsed > 0 else None,
         },

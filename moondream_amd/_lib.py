@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_skinny.hip", "attention.hip", "elementwise.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "attention.hip", "elementwise.hip", "api.hip"]
 
 MD_OK = 0
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2

@@ -30,9 +30,6 @@
 #include <type_traits>
 #include <vector>
 
-md_status md_gemm_skinny(const md_gemm_args* a, hipStream_t stream);  // gemm_skinny.hip
-size_t md_gemm_skinny_ws_bytes(const md_linear* lin, int store_pad);
-
 namespace {
 
 // Optional live timing (bench.py's roofline leg): HIP events recorded on the
@@ -55,6 +52,10 @@ struct GemmK {
   int M, n_store, n_pad, K;
   int tiles_m, tiles_n;
   int res_row_mod;
+  // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
+  int slices;
+  float* slabs;
+  unsigned* tickets;
 };
 
 constexpr int BK = 64;           // K slice (elements) = 128 B per row
@@ -79,7 +80,7 @@ __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -156,8 +157,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   const uint32_t b_row_off = A_BYTES + (wn * TN + l31) * ROW_BYTES;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  const int nk = p.K / BK;
-  static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, 0); });
+  int nk = p.K / BK;
+  if constexpr (SPLITK) {
+    // this workgroup's contiguous range of K slices (a function of the layer shape only)
+    const int per = (nk + p.slices - 1) / p.slices;
+    const int t0 = min((int)blockIdx.y * per, nk);
+    nk = min(t0 + per, nk) - t0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a_src[j] += (int64_t)t0 * ROW_BYTES;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b_src[j] += (int64_t)t0 * ROW_BYTES;
+  }
+  if (nk > 0) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, 0); });
   for (int t = 0; t < nk; ++t) {
     // slice t has landed (own DMA: vmcnt; everybody's: barrier); the barrier also
     // fences the previous iteration's reads of the buffer refilled during this one
@@ -211,6 +222,54 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       });
       __builtin_amdgcn_sched_barrier(0);
     });
+  }
+
+  if constexpr (SPLITK) {
+    // Cross-workgroup split-K, deterministic: every slice publishes its fp32
+    // accumulators as a slab in accumulator-register order (coalesced, and each
+    // lane later reads back exactly its own registers); the LAST workgroup to
+    // arrive (agent-scope release -> ticket -> acquire, cdna guide 6 G16) sums the
+    // slabs in slice order and runs the epilogue.  The summation tree depends on
+    // the layer shape only, never on how many rows are live.
+    constexpr int SLAB = NT * MI * NI * 16;  // floats per workgroup
+    const int tile_id = tm * p.tiles_n + tn;
+    float* slab = p.slabs + ((int64_t)tile_id * p.slices + blockIdx.y) * SLAB;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[((i * NI + j) * 16 + r) * NT + tid] = acc[i][j][r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = (unsigned*)smem;  // operand ring is dead after the barrier
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned tk = __hip_atomic_fetch_add(p.tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (tk == (unsigned)p.slices - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave zero for the next launch
+    }
+    __syncthreads();
+    const float* base = p.slabs + (int64_t)tile_id * p.slices * SLAB;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int sl = 0; sl < p.slices; ++sl)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += base[(int64_t)sl * SLAB + ((i * NI + j) * 16 + r) * NT + tid];
   }
 
   // ---- epilogue -----------------------------------------------------------
@@ -269,13 +328,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false>
 md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int ring = 2 * (BM + BN) * ROW_BYTES;
   constexpr int epi = WM * WN * 4096;
   constexpr int lds = ring > epi ? ring : epi;
-  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -287,7 +346,7 @@ md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   GemmK kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.n_store + BN - 1) / BN;
-  hipLaunchKernelGGL(fn, dim3(kk.tiles_m * kk.tiles_n), dim3(NT), lds, stream, kk);
+  hipLaunchKernelGGL(fn, dim3(kk.tiles_m * kk.tiles_n, SPLITK ? kk.slices : 1), dim3(NT), lds, stream, kk);
   return md_launch_status();
 }
 
@@ -296,8 +355,23 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
   switch (tile) {
     case 0: return launch_cfg<256, 256, 2, 4, EPI>(k, stream);
     case 1: return launch_cfg<256, 128, 4, 2, EPI>(k, stream);
+    case 3: return k.slices > 1 ? launch_cfg<64, 128, 1, 2, EPI, true>(k, stream) : launch_cfg<64, 128, 1, 2, EPI>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
+}
+
+// Decode regime (m <= 64): the layer is a weight stream.  64 x 128 tiles keep the
+// activation traffic at half the weight traffic through the per-CU load path; K is
+// split over S workgroups per tile so that ~256+ workgroups pull from HBM.  S is a
+// function of (n, k) only.
+constexpr size_t TICKET_BYTES = 8192;
+constexpr int DEC_BN = 128, DEC_SLAB_FLOATS = 128 * 2 * 2 * 16;  // NT * MI * NI * 16
+
+int decode_slices(int n_store, int k_pad) {
+  const int tiles = (n_store + DEC_BN - 1) / DEC_BN, nk = k_pad / BK;
+  int s = 1;
+  while (s < 32 && tiles * s < 256 && s * 2 <= nk / 2) s *= 2;
+  return s;
 }
 
 // Tile choice: estimated time ~ (waves of workgroups over 256 CUs) x tile area /
@@ -352,7 +426,22 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.res_row_mod = a->res_row_mod;
   k.tiles_m = k.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
-  const int tile = pick_tile(k.M, k.n_store);
+  int tile = pick_tile(k.M, k.n_store);
+  k.slices = 1;
+  k.slabs = nullptr;
+  k.tickets = nullptr;
+  const char* forced = getenv("MD_GEMM_TILE");
+  if (a->m <= 64 && !(forced && *forced)) {
+    tile = 3;
+    const int sl = decode_slices(k.n_store, k.K);
+    const size_t tiles = (k.n_store + DEC_BN - 1) / DEC_BN;
+    const size_t need = TICKET_BYTES + tiles * sl * DEC_SLAB_FLOATS * sizeof(float);
+    if (sl > 1 && a->splitk_ws != nullptr && a->splitk_ws_bytes >= need && tiles * 4 <= TICKET_BYTES) {
+      k.slices = sl;
+      k.tickets = (unsigned*)a->splitk_ws;
+      k.slabs = (float*)((char*)a->splitk_ws + TICKET_BYTES);
+    }
+  }
   if (a->epilogue == MD_EPI_RESIDUAL)
     MD_CHECK_ARG(a->r != nullptr && a->ldr % 8 == 0 && ((uintptr_t)a->r & 15) == 0);
   ProfRec rec;
@@ -365,11 +454,6 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
     (void)hipEventRecord(rec.start, s);
   }
   md_status st;
-  // decode regime: <= 64 rows is a weight stream, not a matrix-core problem
-  const char* forced = getenv("MD_GEMM_TILE");
-  if (a->m <= 64 && !(forced && *forced)) {
-    st = md_gemm_skinny(a, s);
-  } else
   switch (a->epilogue) {
     case MD_EPI_BIAS: st = launch_epi<MD_EPI_BIAS>(k, tile, s); break;
     case MD_EPI_GELU: st = launch_epi<MD_EPI_GELU>(k, tile, s); break;
@@ -385,7 +469,11 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
 
 extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols) {
   if (!lin || m > 64) return 0;
-  return md_gemm_skinny_ws_bytes(lin, store_pad_cols);
+  const int n_store = store_pad_cols ? lin->n_pad : lin->n;
+  const int sl = decode_slices(n_store, lin->k_pad);
+  if (sl == 1) return 0;
+  const size_t tiles = (n_store + DEC_BN - 1) / DEC_BN;
+  return TICKET_BYTES + tiles * sl * DEC_SLAB_FLOATS * sizeof(float);
 }
 
 extern "C" void md_profile_gemm(int32_t enable) {

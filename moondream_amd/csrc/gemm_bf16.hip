@@ -206,19 +206,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       // The LDS-DMA pieces of slice t+1 are spread over the four K-steps and issued
       // BETWEEN MFMAs: an LDS-DMA issue costs the wave 60-180 cycles, which hides
       // under the 32-cycle-per-MFMA matrix pipe instead of idling it at the head
-      // of the slice.  Piece p goes to step p % 4.
+      // of the slice.  Piece p goes to step p % 4, slot p / 4.
+      constexpr int PPS = (NA + NB + 3) / 4;  // pieces per K-step
       static_for<0, MI * NI>([&](auto mc) {
         constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
         acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
-        constexpr int SLOT = (Mx == 1) ? 0 : (Mx == MI * NI / 2 + 1 ? 1 : -1);  // after MFMA #1 and #(half+1)
-        if constexpr (SLOT >= 0) {
-          constexpr int P = S + 4 * SLOT;
-          if constexpr (P < NA + NB) {
+        static_for<0, PPS>([&](auto qc) {
+          constexpr int Q = decltype(qc)::value, P = S + 4 * Q;
+          // slot Q of this step sits behind MFMA number Q * (MI*NI) / PPS
+          if constexpr ((Q * MI * NI) / PPS == Mx && P < NA + NB) {
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) issue_piece(std::integral_constant<int, P>{}, nstage);
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        });
       });
       __builtin_amdgcn_sched_barrier(0);
     });

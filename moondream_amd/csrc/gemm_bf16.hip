@@ -27,6 +27,7 @@
 //     tiles and share A/W slices through their private L2.
 #include "md_common.hpp"
 
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -80,7 +81,15 @@ __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false>
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// STAGES = depth of the LDS operand ring: 2 for the MFMA-bound big tiles (one slice
+// in flight under ~2000 cycles of MFMA work), deeper for the decode-regime config
+// whose per-slice compute is far shorter than the DMA latency.
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -168,14 +177,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) b_src[j] += (int64_t)t0 * ROW_BYTES;
   }
-  if (nk > 0) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, 0); });
+  static_assert((STAGES - 2) * (NA + NB) < 64, "vmcnt is a 6-bit counter");
+  // prologue: slices 0 .. STAGES-2 in flight
+  static_for<0, STAGES - 1>([&](auto sc) {
+    constexpr int SL = decltype(sc)::value;
+    if (SL < nk) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, SL); });
+  });
   for (int t = 0; t < nk; ++t) {
-    // slice t has landed (own DMA: vmcnt; everybody's: barrier); the barrier also
-    // fences the previous iteration's reads of the buffer refilled during this one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool has_next = t + 1 < nk;
-    const int nstage = (t + 1) & 1;
+    // slice t has landed: own DMA by a COUNTED vmcnt (the min(STAGES-2, nk-1-t)
+    // younger slices stay in flight), everybody's by the barrier, which also fences
+    // the previous iteration's reads of the ring slot refilled during this one
+    if constexpr (STAGES == 2) {
+      wait_vm<0>();
+    } else {
+      const int ahead = min(STAGES - 2, nk - 1 - t);
+      static_for<0, STAGES - 1>([&](auto ac) {
+        constexpr int A = decltype(ac)::value;
+        if (ahead == A) wait_vm<A*(NA + NB)>();
+      });
+    }
+    // raw s_barrier: __syncthreads() would add a vmcnt(0) and drain the DMA ring.
+    // Every ds_read of this wave was waited for (wait_lgkm<0>) before its last MFMAs.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool has_next = t + STAGES - 1 < nk;
+    const int nstage = (t + STAGES - 1) % STAGES;
     // LDS -> register fragments, software pipelined by hand: the six ds_read_b128 of
     // K-step s+1 are issued BEFORE the eight MFMAs of step s and waited for with a
     // counted lgkmcnt (LDS returns in order), so the matrix pipe never waits on LDS
@@ -184,7 +211,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
     // read next to its use and waits lgkmcnt(0) in front of each MFMA group.)
     // Inline asm: the compiler neither counts these reads nor moves MFMAs across
     // the sched_barrier that follows each wait (cdna guide 5.7, form iii).
-    const uint32_t st = lds_base + (t & 1) * STAGE;
+    const uint32_t st = lds_base + (t % STAGES) * STAGE;
     bf16x8 af[2][MI], bfr[2][NI];
     auto issue_reads = [&](auto set_c, auto step_c) {
       constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
@@ -329,13 +356,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2>
 md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  constexpr int ring = 2 * (BM + BN) * ROW_BYTES;
+  constexpr int ring = STAGES * (BM + BN) * ROW_BYTES;
   constexpr int epi = WM * WN * 4096;
   constexpr int lds = ring > epi ? ring : epi;
-  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK>;
+  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -351,12 +378,15 @@ md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   return md_launch_status();
 }
 
+constexpr int DEC_STAGES = 4;  // decode-regime ring: 3 x 24 KiB slices in flight per workgroup
+
 template <int EPI>
 md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
   switch (tile) {
     case 0: return launch_cfg<256, 256, 2, 4, EPI>(k, stream);
     case 1: return launch_cfg<256, 128, 4, 2, EPI>(k, stream);
-    case 3: return k.slices > 1 ? launch_cfg<64, 128, 1, 2, EPI, true>(k, stream) : launch_cfg<64, 128, 1, 2, EPI>(k, stream);
+    case 3: return k.slices > 1 ? launch_cfg<64, 128, 1, 2, EPI, true, DEC_STAGES>(k, stream)
+                                : launch_cfg<64, 128, 1, 2, EPI, false, DEC_STAGES>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }
@@ -370,6 +400,10 @@ constexpr int DEC_BN = 128, DEC_SLAB_FLOATS = 128 * 2 * 2 * 16;  // NT * MI * NI
 
 int decode_slices(int n_store, int k_pad) {
   const int tiles = (n_store + DEC_BN - 1) / DEC_BN, nk = k_pad / BK;
+  if (const char* e = getenv("MD_DECODE_SLICES")) {  // experiments
+    const int v = atoi(e);
+    if (v >= 1) return std::min(v, std::max(1, nk));
+  }
   int s = 1;
   while (s < 32 && tiles * s < 256 && s * 2 <= nk / 2) s *= 2;
   return s;

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Sweep the split-K slice count of the decode-regime GEMM on the GPU."""
+import ctypes as C, math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from moondream_amd import _lib
+from moondream_amd.weights import PackedLinear
+from tools.kernel_bench import timeit, stream
+lib = _lib.load()
+BF16 = torch.bfloat16
+for (m, k, n, epi) in [(64, 2048, 6144, 0), (64, 2048, 2048, 2), (64, 2048, 8192, 1), (64, 8192, 2048, 2), (1, 2048, 6144, 0), (1, 8192, 2048, 2)]:
+    a = (torch.randn(m, k, device="cuda") * 0.5).to(BF16)
+    w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(BF16)
+    lin = PackedLinear(w, torch.zeros(n, dtype=BF16), "cuda")
+    c = torch.empty(m, lin.n_pad, dtype=BF16, device="cuda")
+    r = torch.randn(m, lin.n_pad, device="cuda").to(BF16)
+    st = lin.struct()
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, ws.data_ptr(), ws.numel())
+    out = []
+    for s in (1, 2, 4, 8, 16, 32):
+        os.environ["MD_DECODE_SLICES"] = str(s)
+        dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=20)
+        out.append(f"S={s}: {dt*1e6:6.1f}us")
+    os.environ.pop("MD_DECODE_SLICES")
+    print(f"m={m} k={k} n={n}: " + "  ".join(out) + f"   (ideal {2*n*k/6e12*1e6:.1f}us @6TB/s)", flush=True)

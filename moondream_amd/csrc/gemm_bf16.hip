@@ -404,8 +404,11 @@ int decode_slices(int n_store, int k_pad) {
     const int v = atoi(e);
     if (v >= 1) return std::min(v, std::max(1, nk));
   }
+  // measured model (profiles/r01_decode_gemm_sweep.txt): one workgroup saturates its
+  // CU's load path (~40 GB/s), the last arriver pays ~1 us per 32 KiB slab, so
+  // t ~ 2 us + bytes / (tiles * S * 40 GB/s) + S * 1 us: aim for >= 128 workgroups, S <= 8
   int s = 1;
-  while (s < 32 && tiles * s < 256 && s * 2 <= nk / 2) s *= 2;
+  while (s < 8 && tiles * s < 128 && s * 2 <= nk / 2) s *= 2;
   return s;
 }
 

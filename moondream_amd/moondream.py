@@ -367,31 +367,84 @@ class MoondreamModel:
     def _decode_greedy(self, first: torch.Tensor, pos: int, max_tokens: int, suppress_id: int, slot0: int = 0,
                        eos_id: Optional[int] = None, check_every: int = 16) -> torch.Tensor:
         """Device-resident greedy loop: returns int32 [steps+1, B] (row 0 = ``first``).
-        reference: the generator of moondream.py:471-530 without its per-token host sync."""
+        reference: the generator of moondream.py:471-530 without its per-token host sync.
+        With ``compile()`` the steps are replayed from a captured hipGraph in chunks."""
         b = first.shape[0]
         t = self.config.text
         self._ensure_batch(slot0 + b)
+        max_tokens = max(0, min(max_tokens, t.max_context - 1 - pos))
         hist = torch.zeros(max_tokens + 1, b, dtype=torch.int32, device=self._device)
         hist[0] = first
-        pos_t = torch.full((b,), pos, dtype=torch.int32, device=self._device)
-        logits = torch.empty(b, t.vocab_size, dtype=BF16, device=self._device)
+        if max_tokens == 0:
+            return hist
+        logits = self._decode_logits(b)
         need = self.lib.md_decode_workspace_bytes(C.byref(self.w.text), b)
         ws = self._workspace(need)
         kv = self._kv_struct(slot0)
-        steps = 0
-        while steps < max_tokens and pos + steps < t.max_context - 1:
+
+        def one_step(tok_in, tok_out, pos_buf):
             _lib.check(
                 self.lib.md_decode_step(
-                    C.byref(self.w.text), hist[steps].data_ptr(), hist[steps + 1].data_ptr(), pos_t.data_ptr(), b,
-                    C.byref(kv), suppress_id, logits.data_ptr(), t.vocab_size, ws.data_ptr(), ws.numel(), self._stream(),
+                    C.byref(self.w.text), tok_in.data_ptr(), tok_out.data_ptr(), pos_buf.data_ptr(), b, C.byref(kv),
+                    suppress_id, logits.data_ptr(), t.vocab_size, ws.data_ptr(), ws.numel(), self._stream(),
                 ),
                 "md_decode_step",
             )
-            steps += 1
-            if eos_id is not None and check_every and steps % check_every == 0:
-                if bool((hist[: steps + 1] == eos_id).any(dim=0).all()):
+
+        def all_done(upto):
+            return eos_id is not None and bool((hist[: upto + 1] == eos_id).any(dim=0).all())
+
+        steps = 0
+        if not self.use_graphs:
+            pos_t = torch.full((b,), pos, dtype=torch.int32, device=self._device)
+            while steps < max_tokens:
+                one_step(hist[steps], hist[steps + 1], pos_t)
+                steps += 1
+                if check_every and steps % check_every == 0 and all_done(steps):
                     break
+            return hist[: steps + 1]
+
+        # ---- hipGraph path: one graph = `chunk` consecutive steps over fixed buffers
+        chunk = max(1, min(check_every or 16, max_tokens))
+        while steps < max_tokens:
+            n = min(chunk, max_tokens - steps)
+            key = ("decode", b, slot0, n, suppress_id, ws.data_ptr(), self._kv_k.data_ptr())
+            entry = self._graphs.get(key)
+            if entry is None:
+                buf = torch.zeros(n + 1, b, dtype=torch.int32, device=self._device)
+                pos_buf = torch.zeros(b, dtype=torch.int32, device=self._device)
+                # eager warm-up on scratch state is not possible (KV side effects), so the
+                # first chunk of a new shape runs eagerly and the graph is captured afterwards
+                buf[0] = hist[steps]
+                pos_buf.fill_(pos + steps)
+                for i in range(n):
+                    one_step(buf[i], buf[i + 1], pos_buf)
+                hist[steps + 1 : steps + n + 1] = buf[1:]
+                torch.cuda.synchronize(self._device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(n):
+                        one_step(buf[i], buf[i + 1], pos_buf)
+                # the capture did not execute; nothing to undo
+                self._graphs[key] = (g, buf, pos_buf)
+            else:
+                g, buf, pos_buf = entry
+                buf[0] = hist[steps]
+                pos_buf.fill_(pos + steps)
+                g.replay()
+                hist[steps + 1 : steps + n + 1] = buf[1:]
+            steps += n
+            if all_done(steps):
+                break
         return hist[: steps + 1]
+
+    def _decode_logits(self, b: int) -> torch.Tensor:
+        buf = getattr(self, "_logits_buf", None)
+        if buf is None or buf.shape[0] < b:
+            buf = torch.empty(max(b, self._max_batch), self.config.text.vocab_size, dtype=BF16, device=self._device)
+            self._logits_buf = buf
+            self._graphs.clear()
+        return buf
 
     @staticmethod
     def _truncate(seq: List[int], eos_id: Optional[int], max_tokens: int) -> List[int]:

@@ -107,6 +107,26 @@ def test_batched_equals_sequential_and_reference(tiny):
         assert batched[i] == model.batch_generate_ids([images[i]], [prompts[i]], max_tokens=n)[0]
 
 
+def test_hipgraph_decode_equals_eager(tiny):
+    """compile() replays the device-resident decode steps from a captured hipGraph:
+    same ids as the eager path, on first use (capture) and on replay."""
+    g, cfg, sd, model = tiny
+    images = [golden_image(g, i) for i in range(3)]
+    prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(3)]
+    n = len(g["img0.cap.tokens"])
+    eager = model.batch_generate_ids(images, prompts, max_tokens=n)
+    model.compile()
+    try:
+        first = model.batch_generate_ids(images, prompts, max_tokens=n)   # eager chunk + capture
+        replay = model.batch_generate_ids(images, prompts, max_tokens=n)  # graph replay
+        single = model.batch_generate_ids(images[:1], prompts[:1], max_tokens=n)
+        single2 = model.batch_generate_ids(images[:1], prompts[:1], max_tokens=n)
+    finally:
+        model.use_graphs = False
+    assert first == eager and replay == eager
+    assert single[0] == eager[0] and single2[0] == eager[0]
+
+
 def test_teacher_forced_logits_vs_reference(tiny):
     g, cfg, sd, model = tiny
     enc = model.encode_image(golden_image(g, 0))

@@ -109,26 +109,57 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
   const bf16_t* kbase = p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
   const bf16_t* vbase = p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
 
-  for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K (row-major, padded stride) and V (transposed) -------------
-    for (int c = tid; c < 64 * C::CPR; c += 256) {
-      const int row = c / C::CPR, ch = c % C::CPR;
-      const int j = kv0 + row;
-      u32x4 kq = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
-      if (j < kv_len) {
-        kq = *(const u32x4*)(kbase + (int64_t)j * p.k_ts + ch * 8);
-        vq = *(const u32x4*)(vbase + (int64_t)j * p.v_ts + ch * 8);
-      }
-      *(u32x4*)(Ks + row * C::KSTR * 2 + ch * 16) = kq;
-      bf16_t* vt = (bf16_t*)Vt + (ch * 8) * C::VSTR + row;
+  // ---- K/V staging, split (cdna guide T14): the global loads of tile t+1 are issued
+  // before tile t is computed and written to LDS after it, so their latency hides
+  // under the MFMA/softmax work.  A thread owns (key-row PAIR, 16-byte chunk) items:
+  // K goes to LDS row-major, V transposed -- two adjacent keys of one feature pack
+  // into a single 4-byte LDS store.
+  constexpr int ITEMS = 32 * C::CPR, NIT = (ITEMS + 255) / 256;
+  u32x4 kreg[NIT][2], vreg[NIT][2];
+  auto stage_load = [&](int kv0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vt[(2 * e) * C::VSTR] = (bf16_t)(vq[e] & 0xffffu);
-        vt[(2 * e + 1) * C::VSTR] = (bf16_t)(vq[e] >> 16);
+    for (int u = 0; u < NIT; ++u) {
+      const int it = tid + 256 * u;
+      const int rp = it / C::CPR, ch = it % C::CPR;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = kv0 + 2 * rp + e;
+        kreg[u][e] = u32x4{0, 0, 0, 0};
+        vreg[u][e] = u32x4{0, 0, 0, 0};
+        if (it < ITEMS && j < kv_len) {
+          kreg[u][e] = *(const u32x4*)(kbase + (int64_t)j * p.k_ts + ch * 8);
+          vreg[u][e] = *(const u32x4*)(vbase + (int64_t)j * p.v_ts + ch * 8);
+        }
       }
     }
-    __syncthreads();
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int it = tid + 256 * u;
+      if (it < ITEMS) {
+        const int rp = it / C::CPR, ch = it % C::CPR;
+        *(u32x4*)(Ks + (2 * rp) * C::KSTR * 2 + ch * 16) = kreg[u][0];
+        *(u32x4*)(Ks + (2 * rp + 1) * C::KSTR * 2 + ch * 16) = kreg[u][1];
+        char* vt = Vt + (ch * 8) * C::VSTR * 2 + rp * 4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t a = vreg[u][0][w], bq = vreg[u][1][w];
+          *(uint32_t*)(vt + (2 * w) * C::VSTR * 2) = (a & 0xffffu) | (bq << 16);
+          *(uint32_t*)(vt + (2 * w + 1) * C::VSTR * 2) = (a >> 16) | (bq & 0xffff0000u);
+        }
+      }
+    }
+  };
+
+  if (kv_end > 0) {
+    stage_load(0);
+    stage_write();
+  }
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
+    __syncthreads();  // tile kv0 is in LDS
+    const bool more = kv0 + 64 < kv_end;
+    if (more) stage_load(kv0 + 64);
 
     // ---- S^T = K Q^T : two 32-key blocks ------------------------------------
     f32x16 sacc[2];
@@ -203,6 +234,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
                                                             oacc[d], 0, 0, 0);
         }
       }
+    if (more) {
+      __syncthreads();  // every wave is done reading tile kv0
+      stage_write();
+    }
   }
 
   // ---- finalize: O / l, transpose through LDS, coalesced row stores ---------

@@ -53,14 +53,14 @@ struct GemmK {
   int M, n_store, n_pad, K;
   int tiles_m, tiles_n;
   int res_row_mod;
+  int group_m;  // tile-order grouping (row panels per group)
   // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
   int slices;
   float* slabs;
   unsigned* tickets;
 };
 
-constexpr int BK = 64;           // K slice (elements) = 128 B per row
-constexpr int ROW_BYTES = BK * 2;
+constexpr int BK = 64;  // K granularity of the packing contract (k_pad % 64 == 0) and default slice width
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -89,16 +89,23 @@ __device__ __forceinline__ void wait_vm() {
 // STAGES = depth of the LDS operand ring: 2 for the MFMA-bound big tiles (one slice
 // in flight under ~2000 cycles of MFMA work), deeper for the decode-regime config
 // whose per-slice compute is far shorter than the DMA latency.
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2>
+// BKT = K elements per slice (64: 128-byte rows, 8 chunks; 32: 64-byte rows, 4 chunks,
+// which lets the 256x256 tile keep three 32 KiB slices in flight in a 4-deep ring).
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
+  constexpr int ROW_BYTES = BKT * 2;
+  constexpr int CH = BKT / 8;                 // 16-byte chunks per row
+  constexpr int CH_SHIFT = (CH == 8) ? 3 : 2;
+  constexpr int KSTEPS = BKT / 16;            // MFMA K-steps per slice
+  static_assert(BKT == 64 || BKT == 32, "slice width");
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   static_assert(TN == 64, "epilogue transposes 32 x 64 wave tiles");
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;  // 16-byte LDS-DMA pieces per thread
-  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  constexpr int NA = BM * CH / NT, NB = BN * CH / NT;  // 16-byte LDS-DMA pieces per thread
+  static_assert(BM * CH % NT == 0 && BN * CH % NT == 0, "tile/threads mismatch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   // ---- workgroup -> tile -------------------------------------------------
   const int nwg = p.tiles_m * p.tiles_n;
   const int L = xcd_remap(blockIdx.x, nwg);
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = p.group_m;
   const int per_group = GROUP_M * p.tiles_n;
   const int first_m = (L / per_group) * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
@@ -124,13 +131,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   const char* b_src[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int slot = j * NT + tid, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
     const int64_t row = min(m0 + r, p.M - 1);
     a_src[j] = (const char*)(p.A + row * p.lda + c * 8);
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    const int slot = j * NT + tid, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
     const int64_t row = min(n0 + r, p.n_pad - 1);
     b_src[j] = (const char*)(p.W + row * p.ldw + c * 8);
   }
@@ -160,13 +167,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment read offsets: row = (tile row base, multiple of 32) + l31, so the
-  // swizzle term (row >> 1) & 7 depends on the lane only
-  const int swz = (l31 >> 1) & 7;
+  // swizzle term depends on the lane only: (row >> 1) & 7 for 128-byte rows, (row >> 2) & 3 for 64-byte rows
+  const int swz = (l31 >> (4 - CH_SHIFT)) & (CH - 1);
   const uint32_t a_row_off = (wm * TM + l31) * ROW_BYTES;
   const uint32_t b_row_off = A_BYTES + (wn * TN + l31) * ROW_BYTES;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  int nk = p.K / BK;
+  int nk = p.K / BKT;
   if constexpr (SPLITK) {
     // this workgroup's contiguous range of K slices (a function of the layer shape only)
     const int per = (nk + p.slices - 1) / p.slices;
@@ -221,9 +228,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       static_for<0, MI>([&](auto i) { ds_read_b128<decltype(i)::value * 32 * ROW_BYTES>(af[SET][decltype(i)::value], a_addr); });
     };
     issue_reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    static_for<0, BK / 16>([&](auto sc) {
+    static_for<0, KSTEPS>([&](auto sc) {
       constexpr int S = decltype(sc)::value, SET = S & 1;
-      if constexpr (S + 1 < BK / 16) {
+      if constexpr (S + 1 < KSTEPS) {
         issue_reads(std::integral_constant<int, (S + 1) & 1>{}, std::integral_constant<int, S + 1>{});
         wait_lgkm<MI + NI>();  // everything but the reads just issued has landed
       } else {
@@ -233,13 +240,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       // The LDS-DMA pieces of slice t+1 are spread over the four K-steps and issued
       // BETWEEN MFMAs: an LDS-DMA issue costs the wave 60-180 cycles, which hides
       // under the 32-cycle-per-MFMA matrix pipe instead of idling it at the head
-      // of the slice.  Piece p goes to step p % 4, slot p / 4.
-      constexpr int PPS = (NA + NB + 3) / 4;  // pieces per K-step
+      // of the slice.  Piece p goes to step p % KSTEPS, slot p / KSTEPS.
+      constexpr int PPS = (NA + NB + KSTEPS - 1) / KSTEPS;  // pieces per K-step
       static_for<0, MI * NI>([&](auto mc) {
         constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
         acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
         static_for<0, PPS>([&](auto qc) {
-          constexpr int Q = decltype(qc)::value, P = S + 4 * Q;
+          constexpr int Q = decltype(qc)::value, P = S + KSTEPS * Q;
           // slot Q of this step sits behind MFMA number Q * (MI*NI) / PPS
           if constexpr ((Q * MI * NI) / PPS == Mx && P < NA + NB) {
             __builtin_amdgcn_sched_barrier(0);
@@ -320,6 +327,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       bias_v[j][g][3] = hi_bf(bw[1]);
     }
 
+  // residual operand: all MI x 4 16-byte pieces of this lane are requested up front
+  // (one exposed memory latency per tile instead of one per 32-row block); r may
+  // alias c, each piece is read and later written by the same lane
+  u32x4 rres[EPI == MD_EPI_RESIDUAL ? MI : 1][4];
+  if constexpr (EPI == MD_EPI_RESIDUAL) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+        const int m = m0 + wm * TM + 32 * i + row;
+        const int n = wn0 + ch * 8;
+        rres[i][q] = u32x4{0, 0, 0, 0};
+        if (m < p.M && n < p.n_store) {
+          const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
+          rres[i][q] = *(const u32x4*)(p.R + rrow * p.ldr + n);
+        }
+      }
+  }
+
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -344,8 +371,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
           for (int e = 0; e < 4; ++e)
             v[e] = pack_bf16x2(gelu_tanh_f32(lo_bf(v[e])), gelu_tanh_f32(hi_bf(v[e])));
         } else if constexpr (EPI == MD_EPI_RESIDUAL) {
-          const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
-          const u32x4 rv = *(const u32x4*)(p.R + rrow * p.ldr + n);
+          const u32x4 rv = rres[i][q];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             v[e] = pack_bf16x2(lo_bf(rv[e]) + lo_bf(v[e]), hi_bf(rv[e]) + hi_bf(v[e]));
@@ -356,13 +382,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64>
 md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  constexpr int ring = STAGES * (BM + BN) * ROW_BYTES;
+  constexpr int ring = STAGES * (BM + BN) * BKT * 2;
   constexpr int epi = WM * WN * 4096;
   constexpr int lds = ring > epi ? ring : epi;
-  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES>;
+  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -385,6 +411,9 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
   switch (tile) {
     case 0: return launch_cfg<256, 256, 2, 4, EPI>(k, stream);
     case 1: return launch_cfg<256, 128, 4, 2, EPI>(k, stream);
+    case 4: return launch_cfg<256, 128, 4, 2, EPI, false, 3>(k, stream);      // 3-deep ring
+    case 5: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32>(k, stream);  // 32-wide slices, 4-deep ring
+    case 6: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32>(k, stream);  // 32-wide slices, 5-deep ring
     case 3: return k.slices > 1 ? launch_cfg<64, 128, 1, 2, EPI, true, DEC_STAGES>(k, stream)
                                 : launch_cfg<64, 128, 1, 2, EPI, false, DEC_STAGES>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
@@ -463,6 +492,8 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.K = a->lin.k_pad;
   k.res_row_mod = a->res_row_mod;
   k.tiles_m = k.tiles_n = 0;
+  k.group_m = 8;
+  if (const char* e = getenv("MD_GEMM_GROUP_M")) k.group_m = std::max(1, atoi(e));  // experiments
   hipStream_t s = (hipStream_t)stream;
   int tile = pick_tile(k.M, k.n_store);
   k.slices = 1;

@@ -93,6 +93,7 @@ typedef struct {
   int32_t m;
   int32_t epilogue;
   int32_t store_pad_cols; /* 1: also store columns [n, n_pad) */
+  int32_t gelu_from_col;  /* MD_EPI_GELU only: GELU applies to columns >= this (multiple of 8; 0 = all) */
   /* Scratch for the decode regime (m <= 64), where K is split over several
    * workgroups per output tile: md_gemm_workspace_bytes() bytes, or NULL (then K
    * is not split across workgroups: slower, and a different -- still
@@ -267,6 +268,12 @@ md_status md_vision_project_grid(const md_vit_model* m, const void* global_feats
 typedef struct {
   md_layernorm ln;
   md_linear qkv, proj, fc1, fc2;
+  /* Optional fusion: qkv and fc1 read the same LayerNorm output (text.py:145-157), so
+   * their weights may be packed as ONE matrix [qkv rows | fc1 rows] and run as one
+   * GEMM (GELU on the fc1 columns only); every output element is computed exactly
+   * as by the two separate layers.  w == NULL: not packed, the two layers run
+   * separately. */
+  md_linear qkv_fc1;
 } md_text_block;
 
 typedef struct {

@@ -37,7 +37,8 @@ class MdGemmArgs(C.Structure):
     _fields_ = [
         ("a", c_void_p), ("lda", c_int64), ("lin", MdLinear), ("c", c_void_p), ("ldc", c_int64),
         ("r", c_void_p), ("ldr", c_int64), ("res_row_mod", c_int32), ("m", c_int32),
-        ("epilogue", c_int32), ("store_pad_cols", c_int32), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_size_t),
+        ("epilogue", c_int32), ("store_pad_cols", c_int32), ("gelu_from_col", c_int32), ("splitk_ws", c_void_p),
+        ("splitk_ws_bytes", c_size_t),
     ]
 
 
@@ -68,7 +69,8 @@ class MdVitModel(C.Structure):
 
 
 class MdTextBlock(C.Structure):
-    _fields_ = [("ln", MdLayerNorm), ("qkv", MdLinear), ("proj", MdLinear), ("fc1", MdLinear), ("fc2", MdLinear)]
+    _fields_ = [("ln", MdLayerNorm), ("qkv", MdLinear), ("proj", MdLinear), ("fc1", MdLinear), ("fc2", MdLinear),
+                ("qkv_fc1", MdLinear)]
 
 
 class MdTextModel(C.Structure):

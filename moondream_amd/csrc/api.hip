@@ -40,6 +40,7 @@ md_status gemm(const void* a, int64_t lda, const md_linear& lin, void* c, int64_
                const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s,
                void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
   md_gemm_args g;
+  g.gelu_from_col = 0;
   g.splitk_ws = splitk_ws;
   g.splitk_ws_bytes = splitk_bytes;
   g.a = a;
@@ -92,9 +93,15 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
   Arena a{(char*)base, 0};
   TextWs w;
   w.h = a.take(M * m->blocks[0].qkv.k_pad * 2);
-  w.qkv = a.take(M * (m->n_heads + 2 * m->n_kv_heads) * hd * 2);
+  if (m->blocks[0].qkv_fc1.w) {
+    // fused qkv|fc1 activation: one buffer, fc1's GELU output starts at column qkv_w
+    w.qkv = a.take(M * (size_t)m->blocks[0].qkv_fc1.n_pad * 2);
+    w.ff = (char*)w.qkv + (m->n_heads + 2 * m->n_kv_heads) * hd * 2;
+  } else {
+    w.qkv = a.take(M * (m->n_heads + 2 * m->n_kv_heads) * hd * 2);
+    w.ff = a.take(M * m->blocks[0].fc1.n_pad * 2);
+  }
   w.att = a.take(M * m->blocks[0].proj.k_pad * 2);
-  w.ff = a.take(M * m->blocks[0].fc1.n_pad * 2);
   w.pos_kv = a.take((size_t)batch * 4);
   // decode regime: split-K scratch shared by the layer's four linears (stream-ordered)
   size_t sk = 0;
@@ -102,6 +109,7 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
     const md_text_block& b0 = m->blocks[0];
     sk = std::max(std::max(md_gemm_workspace_bytes(&b0.qkv, (int)M, 0), md_gemm_workspace_bytes(&b0.proj, (int)M, 0)),
                   std::max(md_gemm_workspace_bytes(&b0.fc1, (int)M, 1), md_gemm_workspace_bytes(&b0.fc2, (int)M, 0)));
+    if (b0.qkv_fc1.w) sk = std::max(sk, md_gemm_workspace_bytes(&b0.qkv_fc1, (int)M, 1));
   }
   w.splitk_bytes = sk;
   w.splitk = a.take(sk);
@@ -290,18 +298,31 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     // l_in = ln(x)                                            (text.py:145)
     MD_TRY(md_layernorm_bf16(x, D, w.h, Dp, &b.ln, M, D, 1e-5f, s));
     // qkv, rope(q), rope(k), cache update                      (text.py:30-46)
-    MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s, w.splitk, w.splitk_bytes));
-    MD_TRY(md_rope_kv_write(w.qkv, qkv_w, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
+    const bool fused = b.qkv_fc1.w != nullptr;
+    const int64_t qld = fused ? b.qkv_fc1.n_pad : qkv_w;  // leading dimension of the qkv activation
+    const int64_t ffld = fused ? b.qkv_fc1.n_pad : b.fc1.n_pad;
+    if (fused) {
+      // one GEMM for both consumers of l_in: [qkv | gelu(fc1)]   (text.py:30 and layers.py:130-138)
+      MD_CHECK_ARG(b.qkv_fc1.n_pad == qkv_w + b.fc1.n_pad && qkv_w % 64 == 0);
+      md_gemm_args g;
+      g.a = w.h; g.lda = Dp; g.lin = b.qkv_fc1; g.c = w.qkv; g.ldc = qld; g.r = nullptr; g.ldr = 0;
+      g.res_row_mod = 0; g.m = M; g.epilogue = MD_EPI_GELU; g.store_pad_cols = 1; g.gelu_from_col = qkv_w;
+      g.splitk_ws = w.splitk; g.splitk_ws_bytes = w.splitk_bytes;
+      MD_TRY(md_gemm_bf16(&g, s));
+    } else {
+      MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s, w.splitk, w.splitk_bytes));
+    }
+    MD_TRY(md_rope_kv_write(w.qkv, qld, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
                             q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
     // attention over the slab                                   (text.py:48-51)
     if (q_len == 1) {
-      MD_TRY(md_attention_decode(w.qkv, qkv_w, w.att, Dp, kl, vl, kv->batch_stride, kv->ctx, kv_len, batch,
+      MD_TRY(md_attention_decode(w.qkv, qld, w.att, Dp, kl, vl, kv->batch_stride, kv->ctx, kv_len, batch,
                                  m->n_heads, m->n_kv_heads, hd, scale, s));
     } else {
       md_attn_args a;
       a.q = w.qkv;
-      a.q_bs = (int64_t)q_len * qkv_w;
-      a.q_ts = qkv_w;
+      a.q_bs = (int64_t)q_len * qld;
+      a.q_ts = qld;
       a.q_hs = hd;
       a.k = kl;
       a.v = vl;
@@ -326,9 +347,10 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     }
     // x = (x + proj(att)) + fc2(gelu(fc1(l_in)))               (text.py:53,157-158)
     MD_TRY(gemm(w.att, Dp, b.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
-    MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, b.fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, w.splitk, w.splitk_bytes));
+    if (!fused)
+      MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, ffld, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, w.splitk, w.splitk_bytes));
     MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad);
-    MD_TRY(gemm(w.ff, b.fc1.n_pad, b.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
+    MD_TRY(gemm(w.ff, ffld, b.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
   }
   return MD_OK;
 }

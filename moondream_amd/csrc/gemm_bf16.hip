@@ -54,6 +54,7 @@ struct GemmK {
   int tiles_m, tiles_n;
   int res_row_mod;
   int group_m;  // tile-order grouping (row panels per group)
+  int gelu_from;  // EPI_GELU: columns >= gelu_from get the GELU
   // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
   int slices;
   float* slabs;
@@ -367,9 +368,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       const int n = wn0 + ch * 8;
       if (m < p.M && n < p.n_store) {
         if constexpr (EPI == MD_EPI_GELU) {
+          if (n >= p.gelu_from) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = pack_bf16x2(gelu_tanh_f32(lo_bf(v[e])), gelu_tanh_f32(hi_bf(v[e])));
+            for (int e = 0; e < 4; ++e)
+              v[e] = pack_bf16x2(gelu_tanh_f32(lo_bf(v[e])), gelu_tanh_f32(hi_bf(v[e])));
+          }
         } else if constexpr (EPI == MD_EPI_RESIDUAL) {
           const u32x4 rv = rres[i][q];
 #pragma unroll
@@ -473,6 +476,7 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   MD_CHECK_ARG(a->lin.k_pad % BK == 0 && a->lin.k_pad >= a->lin.k);
   MD_CHECK_ARG(a->lin.n_pad % 64 == 0 && a->lin.n_pad >= a->lin.n);
   MD_CHECK_ARG(a->store_pad_cols || a->lin.n % 8 == 0);  // rows are stored in 16-byte pieces
+  MD_CHECK_ARG(a->gelu_from_col >= 0 && a->gelu_from_col % 8 == 0);
   MD_CHECK_ARG(a->lda >= a->lin.k_pad && a->lda % 8 == 0 && a->ldc % 8 == 0);
   MD_CHECK_ARG(((uintptr_t)a->a & 15) == 0 && ((uintptr_t)a->c & 15) == 0 && ((uintptr_t)a->lin.w & 15) == 0);
   GemmK k;
@@ -493,6 +497,7 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.res_row_mod = a->res_row_mod;
   k.tiles_m = k.tiles_n = 0;
   k.group_m = 8;
+  k.gelu_from = a->gelu_from_col;
   if (const char* e = getenv("MD_GEMM_GROUP_M")) k.group_m = std::max(1, atoi(e));  // experiments
   hipStream_t s = (hipStream_t)stream;
   int tile = pick_tile(k.M, k.n_store);

@@ -61,6 +61,37 @@ class PackedLinear:
         return _lib.MdLinear(self.w.data_ptr(), self.b.data_ptr(), self.n, self.k, self.n_pad, self.k_pad)
 
 
+class FusedLinear:
+    """[rows of a | rows of b] over the same input: ONE packed matrix; ``a`` and ``b``
+    are exposed as row-range views of it (no second copy of the weights)."""
+
+    def __init__(self, wa, ba, wb, bb, device):
+        na, k = wa.shape
+        nb = wb.shape[0]
+        assert wb.shape[1] == k and na % 64 == 0, "the first layer's rows must end on a 64-row boundary"
+        self.k, self.k_pad = k, _round_up(k, 64)
+        self.na, self.nb = na, nb
+        self.nb_pad = _round_up(nb, 64)
+        self.n, self.n_pad = na + nb, na + self.nb_pad
+        self.w = torch.zeros(self.n_pad, self.k_pad, dtype=BF16, device=device)
+        self.w[:na, :k] = wa.to(device=device, dtype=BF16)
+        self.w[na : na + nb, :k] = wb.to(device=device, dtype=BF16)
+        self.b = torch.zeros(self.n_pad, dtype=BF16, device=device)
+        self.b[:na] = ba.to(device=device, dtype=BF16)
+        self.b[na : na + nb] = bb.to(device=device, dtype=BF16)
+
+    def struct(self) -> _lib.MdLinear:
+        return _lib.MdLinear(self.w.data_ptr(), self.b.data_ptr(), self.n, self.k, self.n_pad, self.k_pad)
+
+    def struct_a(self) -> _lib.MdLinear:
+        return _lib.MdLinear(self.w.data_ptr(), self.b.data_ptr(), self.na, self.k, self.na, self.k_pad)
+
+    def struct_b(self) -> _lib.MdLinear:
+        off = self.na
+        return _lib.MdLinear(self.w.data_ptr() + off * self.k_pad * 2, self.b.data_ptr() + off * 2, self.nb, self.k,
+                             self.nb_pad, self.k_pad)
+
+
 class PackedLayerNorm:
     def __init__(self, w: torch.Tensor, b: torch.Tensor, device):
         self.w = w.to(device=device, dtype=BF16).contiguous()
@@ -174,9 +205,16 @@ class PackedModel:
             p = f"text.blocks.{i}"
             blk = self.text_blocks[i]
             blk.ln = ln(p + ".ln").struct()
-            blk.qkv = lin(p + ".attn.qkv").struct()
+            if t.qkv_dim % 64 == 0:
+                # qkv and fc1 share their input: pack once, run as one GEMM
+                fused = FusedLinear(sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"],
+                                    sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"], dev)
+                self._keep.append(fused)
+                blk.qkv, blk.fc1, blk.qkv_fc1 = fused.struct_a(), fused.struct_b(), fused.struct()
+            else:
+                blk.qkv = lin(p + ".attn.qkv").struct()
+                blk.fc1 = lin(p + ".mlp.fc1").struct()
             blk.proj = lin(p + ".attn.proj").struct()
-            blk.fc1 = lin(p + ".mlp.fc1").struct()
             blk.fc2 = lin(p + ".mlp.fc2").struct()
         self.text_post_ln = ln("text.post_ln")
         self.lm_head = lin("text.lm_head")

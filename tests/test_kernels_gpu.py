@@ -45,7 +45,7 @@ def gemm(lib, a, lin, epi=0, r=None, res_row_mod=0, store_pad=0, out=None, use_w
     ws = _SPLITK_WS.setdefault(need, torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")) if use_ws else None
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0),
                            r.data_ptr() if r is not None else None, r.stride(0) if r is not None else 0,
-                           res_row_mod, m, epi, store_pad, ws.data_ptr() if ws is not None else None,
+                           res_row_mod, m, epi, store_pad, 0, ws.data_ptr() if ws is not None else None,
                            need if ws is not None else 0)
     _lib.check(lib.md_gemm_bf16(C.byref(args), stream()), "gemm")
     torch.cuda.synchronize()
@@ -93,6 +93,42 @@ def test_gemm_gelu_writes_zero_pad_columns(lib):
     ref = torch.nn.functional.gelu(ref_linear(a, w, b).float(), approximate="tanh").to(BF16)
     compare("gemm_gelu", c[:, :n], ref, 3e-3, 2e-2)
     assert torch.count_nonzero(c[:, n:]) == 0
+
+
+def test_gemm_fused_pair_gelu_from_column(lib):
+    """[qkv | fc1] over one input as ONE GEMM: bias-only for the first block of
+    columns, bias+GELU from column na on; element-for-element what the two
+    separate layers give."""
+    from moondream_amd.weights import FusedLinear
+
+    for m in (730, 64, 5):
+        k, na, nb = 256, 768, 704
+        a = randn(m, k, seed=50)
+        wa, ba = randn(na, k, scale=1 / 16, seed=51), randn(na, scale=0.1, seed=52)
+        wb, bb = randn(nb, k, scale=1 / 16, seed=53), randn(nb, scale=0.1, seed=54)
+        f = FusedLinear(wa, ba, wb, bb, "cuda")
+        st = f.struct()
+        c = torch.full((m, f.n_pad), float("nan"), dtype=BF16, device="cuda")
+        need = lib.md_gemm_workspace_bytes(C.byref(st), m, 1)
+        ws = torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")
+        args = _lib.MdGemmArgs(a.data_ptr(), k, st, c.data_ptr(), f.n_pad, None, 0, 0, m, _lib.MD_EPI_GELU, 1, na, ws.data_ptr(), need)
+        _lib.check(lib.md_gemm_bf16(C.byref(args), stream()))
+        torch.cuda.synchronize()
+        # the same two layers run separately through their row-range views
+        la, lb = f.struct_a(), f.struct_b()
+        ca = torch.empty(m, na, dtype=BF16, device="cuda")
+        cb = torch.empty(m, f.nb_pad, dtype=BF16, device="cuda")
+        for stv, out, epi, sp in ((la, ca, 0, 0), (lb, cb, 1, 1)):
+            nd = lib.md_gemm_workspace_bytes(C.byref(stv), m, sp)
+            w2 = torch.zeros(max(nd, 16), dtype=torch.uint8, device="cuda")
+            ar = _lib.MdGemmArgs(a.data_ptr(), k, stv, out.data_ptr(), out.stride(0), None, 0, 0, m, epi, sp, 0, w2.data_ptr(), nd)
+            _lib.check(lib.md_gemm_bf16(C.byref(ar), stream()))
+        torch.cuda.synchronize()
+        compare("fused qkv part", c[:, :na], ref_linear(a, wa, ba), 3e-3, 2e-2)
+        ref_b = torch.nn.functional.gelu(ref_linear(a, wb, bb).float(), approximate="tanh").to(BF16)
+        compare("fused fc1 part", c[:, na : na + nb], ref_b, 3e-3, 2e-2)
+        if m > 64:  # same tile kernel, same K order -> bit-identical to the separate layers
+            assert torch.equal(c[:, :na], ca) and torch.equal(c[:, na:], cb)
 
 
 def test_gemm_residual_in_place_and_row_mod(lib):

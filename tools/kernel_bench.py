@@ -45,7 +45,7 @@ def bench_gemm(m, k, n, epi=0, tiles=("0", "1", "2")):
     st = lin.struct()
     need = lib.md_gemm_workspace_bytes(C.byref(st), m, 0)
     ws = torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")
-    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, ws.data_ptr(), need)
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, ws.data_ptr(), need)
     res = []
     for t in tiles:
         os.environ["MD_GEMM_TILE"] = t

@@ -16,7 +16,7 @@ for (m, k, n, epi) in [(64, 2048, 6144, 0), (64, 2048, 2048, 2), (64, 2048, 8192
     r = torch.randn(m, lin.n_pad, device="cuda").to(BF16)
     st = lin.struct()
     ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
-    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, ws.data_ptr(), ws.numel())
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, ws.data_ptr(), ws.numel())
     out = []
     for s in (1, 2, 4, 8, 16, 32):
         os.environ["MD_DECODE_SLICES"] = str(s)

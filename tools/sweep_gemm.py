@@ -12,7 +12,7 @@ def run(m,k,n,epi,env):
     w = (torch.randn(n,k,device="cuda")/math.sqrt(k)).to(BF16)
     lin = PackedLinear(w, torch.zeros(n,dtype=BF16), "cuda")
     c = torch.empty(m, lin.n_pad, dtype=BF16, device="cuda"); r = torch.randn(m, lin.n_pad, device="cuda").to(BF16)
-    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), lin.struct(), c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, None, 0)
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), lin.struct(), c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, None, 0)
     for kk,v in env.items(): os.environ[kk]=v
     dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())))
     for kk in env: os.environ.pop(kk)

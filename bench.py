@@ -228,6 +228,11 @@ def main():
             lat.append(time.perf_counter() - t1)
     if lat:
         result["p50_caption_latency_ms"] = float(np.median(lat) * 1e3)
+    # GPU time per phase of one extra (untimed) step, HIP events on the model's stream
+    model.collect_timing = True
+    model.batch_generate_ids(images, prompts, max_tokens=T, ignore_eos=True)
+    model.collect_timing = False
+    result["phase_ms"] = {k: round(v, 2) for k, v in model.last_phase_ms.items()}
 
     if world == 1 and not args.no_cpu_baseline:
         est, cores, note = cpu_baseline(cfg, sd, args.seed, T)

@@ -104,6 +104,8 @@ class MoondreamModel:
         self._kv_k = self._kv_v = None
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = False
+        self.collect_timing = False
+        self.last_phase_ms: Dict[str, float] = {}
         if setup_caches:
             self._setup_caches(max_batch)
 
@@ -257,13 +259,26 @@ class MoondreamModel:
         return oc["crops"], tuple(oc["tiling"])
 
     def _run_vision_encoder_batch(self, images: Sequence[Image.Image]) -> torch.Tensor:
-        """images -> [B,729,D] projected embeddings (reference: moondream.py:206-228, per image)."""
+        """images -> [B,729,D] projected embeddings (reference: moondream.py:206-228, per image).
+
+        Host tiling (PIL, reference image_crops.py:58-167) runs on a thread pool and is
+        pipelined against the GPU: the ViT of image chunk k is enqueued (async) while
+        the crops of chunk k+1 are still being cut."""
         v = self.config.vision
-        cropped = [self._crop(im) for im in images]
-        all_crops = np.concatenate([c for c, _ in cropped], axis=0)
-        dev_crops = torch.from_numpy(all_crops).to(self._device, non_blocking=True)
-        feats = self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC)  # [sum crops, 729, Dv]
-        out = torch.empty(len(images), v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
+        n_img = len(images)
+        pool = self._crop_pool()
+        futures = [pool.submit(self._crop, im) for im in images]
+        per_chunk = max(1, self.vit_chunk_crops // 2)  # images per ViT launch group
+        cropped: List[Tuple[np.ndarray, Tuple[int, int]]] = []
+        feat_parts = []
+        for i0 in range(0, n_img, per_chunk):
+            part = [f.result() for f in futures[i0 : i0 + per_chunk]]
+            cropped.extend(part)
+            host = np.concatenate([c for c, _ in part], axis=0)
+            dev_crops = torch.from_numpy(host).to(self._device, non_blocking=True)
+            feat_parts.append(self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC))
+        feats = feat_parts[0] if len(feat_parts) == 1 else torch.cat(feat_parts, dim=0)  # [sum crops, 729, Dv]
+        out = torch.empty(n_img, v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
         # images with the same tiling are projected together
         offsets, off = [], 0
         for c, _ in cropped:
@@ -292,6 +307,19 @@ class MoondreamModel:
             if not contiguous:
                 out[torch.tensor(idxs, device=self._device)] = o
         return out
+
+    def _crop_pool(self):
+        pool = getattr(self, "_pool", None)
+        if pool is None:
+            import os
+            from concurrent.futures import ThreadPoolExecutor
+
+            try:
+                n = len(os.sched_getaffinity(0))
+            except AttributeError:
+                n = os.cpu_count() or 1
+            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(16, n)))
+        return pool
 
     def _run_vision_encoder(self, image: Image.Image) -> torch.Tensor:
         return self._run_vision_encoder_batch([image])[0]
@@ -475,11 +503,23 @@ class MoondreamModel:
         assert b == len(prompts) and b > 0
         tk = self.config.tokenizer
         eos = tk.eos_id if eos_id is None else eos_id
+        marks = []
+
+        def mark(name):
+            if self.collect_timing:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream(self._device))
+                marks.append((name, e))
+
         with torch.inference_mode():
             self._ensure_batch(b)
             raw = [im for im in images if not isinstance(im, EncodedImage)]
+            mark("start")
             if len(raw) == b:
-                pos = self._prefill_images(self._run_vision_encoder_batch(raw), 0)
+                img_emb = self._run_vision_encoder_batch(raw)
+                mark("vision")
+                pos = self._prefill_images(img_emb, 0)
+                mark("image_prefill")
             else:
                 pos = None
                 for i, im in enumerate(images):
@@ -491,7 +531,9 @@ class MoondreamModel:
             if len(lens) == 1:
                 logits, _, p1 = self._prefill_prompts(prompts, pos, 0)
                 first = self._pick(logits, 0.0, 0.0)
+                mark("prompt_prefill")
                 hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, 0, None if ignore_eos else eos)
+                mark("decode")
                 cols = hist.t().tolist()
                 for i in range(b):
                     results[i] = self._truncate(cols[i], None if ignore_eos else eos, max_tokens)
@@ -502,6 +544,9 @@ class MoondreamModel:
                     first = self._pick(logits, 0.0, 0.0)
                     hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, i, None if ignore_eos else eos)
                     results[i] = self._truncate(hist[:, 0].tolist(), None if ignore_eos else eos, max_tokens)
+        if self.collect_timing and len(marks) > 1:
+            torch.cuda.synchronize(self._device)
+            self.last_phase_ms = {marks[i][0]: marks[i - 1][1].elapsed_time(marks[i][1]) for i in range(1, len(marks))}
         return results  # type: ignore[return-value]
 
     def batch_caption(self, images, length: str = "normal", settings: Optional[dict] = None) -> List[str]:

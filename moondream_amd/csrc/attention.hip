@@ -119,17 +119,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
   auto stage_load = [&](int kv0) {
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
-      const int it = tid + 256 * u;
+      const int it = min(tid + 256 * u, ITEMS - 1);  // surplus threads replay the last item (never written)
       const int rp = it / C::CPR, ch = it % C::CPR;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int j = kv0 + 2 * rp + e;
-        kreg[u][e] = u32x4{0, 0, 0, 0};
-        vreg[u][e] = u32x4{0, 0, 0, 0};
-        if (it < ITEMS && j < kv_len) {
-          kreg[u][e] = *(const u32x4*)(kbase + (int64_t)j * p.k_ts + ch * 8);
-          vreg[u][e] = *(const u32x4*)(vbase + (int64_t)j * p.v_ts + ch * 8);
-        }
+        // rows past kv_len replay the last valid row: their scores are masked to -inf
+        // below, so P is exactly 0 and the (finite) V values never contribute
+        const int j = min(kv0 + 2 * rp + e, kv_len - 1);
+        kreg[u][e] = *(const u32x4*)(kbase + (int64_t)j * p.k_ts + ch * 8);
+        vreg[u][e] = *(const u32x4*)(vbase + (int64_t)j * p.v_ts + ch * 8);
       }
     }
   };
@@ -174,28 +172,46 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
       }
     }
 
-    // ---- scale, mask, online softmax (per lane = per query row) ------------
+    // ---- mask, online softmax (per lane = per query row) --------------------
+    // Scores stay raw; the softmax scale is folded into the exp2 argument as one FMA:
+    // p = 2^(s*c - m*c), c = scale*log2(e) > 0 (so the row max can be taken on raw s).
     const bool full_vis = (kv0 + 63 <= w_qpos_lo) || (w_qpos_hi < p.prefix && kv0 + 64 <= p.prefix);
     const bool need_mask = !(full_vis && kv0 + 64 <= kv_len);
     float mx = -INFINITY;
+    if (need_mask) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kv0 + 32 * sub + 8 * (r >> 2) + 4 * hi + (r & 3);
+          const bool ok = (j < kv_len) && (j <= qpos || (qpos < p.prefix && j < p.prefix));
+          sacc[sub][r] = ok ? sacc[sub][r] : -INFINITY;
+        }
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = sacc[sub][r] * p.scale_log2;
-        if (need_mask) {
-          const int j = kv0 + 32 * sub + 8 * (r >> 2) + 4 * hi + (r & 3);
-          const bool ok = (j < kv_len) && (j <= qpos || (qpos < p.prefix && j < p.prefix));
-          s = ok ? s : -INFINITY;
-        }
-        sacc[sub][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // m_new is finite from the first tile on: key 0 is visible to every query
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale: the running reference m_run only moves when some row's max
+    // has grown by more than 2^RESCALE_THR in the exp2 domain (wave-uniform branch).
+    // Until then P = 2^((s - m_run) c) <= 2^RESCALE_THR, which bf16 P and the fp32
+    // accumulators hold without loss; O, l and P always share one reference, so the
+    // result is the same softmax.  Saves the 48-register accumulator rescale (and
+    // its AGPR round trip) on almost every tile.
+    constexpr float RESCALE_THR = 6.0f;
+    if (__any((mx - m_run) * p.scale_log2 > RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);  // finite from the first tile on: key 0 is visible to every query
+      // (a row with no visible key yet keeps alpha = 1: it has nothing accumulated)
+      const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    const float mc = (m_run == -INFINITY) ? 0.f : -m_run * p.scale_log2;
     float psum = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
@@ -205,18 +221,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
         u32x4 w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p0 = __builtin_amdgcn_exp2f(sacc[sub][8 * u + 2 * e] - m_new);
-          const float p1 = __builtin_amdgcn_exp2f(sacc[sub][8 * u + 2 * e + 1] - m_new);
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[sub][8 * u + 2 * e], p.scale_log2, mc));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[sub][8 * u + 2 * e + 1], p.scale_log2, mc));
           psum += p0 + p1;
           w[e] = pack_bf16x2(p0, p1);
         }
         pf[sub][u] = __builtin_bit_cast(bf16x8, w);
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < C::ND; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T ------------------------------------------------------
 #pragma unroll

@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--no-graphs", action="store_true", help="launch decode steps eagerly instead of hipGraph replay")
+    ap.add_argument("--no-pipeline", action="store_true", help="run each step's encode and decode back to back on one stream")
     return ap.parse_args()
 
 
@@ -149,19 +150,29 @@ def main():
     prompt = cfg.tokenizer.templates["caption"]["normal"]
     prompts = [prompt] * len(images)
 
-    def step():
-        ids = model.batch_generate_ids(images, prompts, max_tokens=T, ignore_eos=True)
+    def finish(ids):
         local_ids = torch.tensor(ids, dtype=torch.int32, device=dev)
         return mdist.gather_token_ids(local_ids)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(k):
+        """k steps = k full passes over this rank's batch.  Pipelined mode overlaps the
+        decode of step i with the encode of step i+1 (two HIP streams); every step's
+        work, including its gather, completes inside the call."""
+        if args.no_pipeline:
+            outs = [finish(model.batch_generate_ids(images, prompts, max_tokens=T, ignore_eos=True)) for _ in range(k)]
+        else:
+            gen = model.batch_generate_ids_pipelined(((images, prompts) for _ in range(k)), max_tokens=T, ignore_eos=True)
+            outs = [finish(ids) for ids in gen]
+        return outs
+
+    if args.warmup:
+        # pipelined mode alternates two KV slot groups: warm both (graph capture) before timing
+        run_steps(args.warmup if args.no_pipeline else max(2, args.warmup))
     mdist.barrier()
     torch.cuda.synchronize()
     lib.md_profile_gemm(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     torch.cuda.synchronize()
     mdist.barrier()
     elapsed = time.perf_counter() - t0
@@ -195,6 +206,7 @@ def main():
             "workload": f"Moondream-{args.model.upper()} bf16 batch_generate (caption): {B} images/GPU x 378x378 "
                         f"(2 crops each, both encoded), 5-token prompt, {T} greedy decode tokens, seeded synthetic weights",
             "batch_per_gpu": B, "decode_tokens": T, "parallelism": f"dp{world}",
+            "step_overlap": "none" if args.no_pipeline else "decode(step i) || encode(step i+1) on two HIP streams",
         },
         "roofline": {
             "bound": "mfma",

@@ -98,8 +98,7 @@ class MoondreamModel:
         self.tokenizer = tokenizer if tokenizer is not None else _load_tokenizer()
         self.w = PackedModel(config, state_dict, self._device)
         self.vit_chunk_crops = int(vit_chunk_crops)
-        self._ws = None
-        self._ws2 = None
+        self._arenas: Dict[int, torch.Tensor] = {}
         self._max_batch = 0
         self._kv_k = self._kv_v = None
         self._graphs: Dict[Any, Any] = {}
@@ -139,11 +138,13 @@ class MoondreamModel:
         )
 
     def _workspace(self, nbytes: int, which: int = 0) -> torch.Tensor:
-        attr = "_ws" if which == 0 else "_ws2"
-        ws = getattr(self, attr)
+        """Caller-owned arenas for the C ABI.  0: encode-side stages, 1: lm_head of the
+        prompt prefill, 2: the decode loop (its own arena so that a decode running on
+        the decode stream never shares scratch with an encode on the encode stream)."""
+        ws = self._arenas.get(which)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=self._device)
-            setattr(self, attr, ws)
+            self._arenas[which] = ws
             self._graphs.clear()
         return ws
 
@@ -407,7 +408,7 @@ class MoondreamModel:
             return hist
         logits = self._decode_logits(b)
         need = self.lib.md_decode_workspace_bytes(C.byref(self.w.text), b)
-        ws = self._workspace(need)
+        ws = self._workspace(need, 2)
         kv = self._kv_struct(slot0)
 
         def one_step(tok_in, tok_out, pos_buf):
@@ -548,6 +549,60 @@ class MoondreamModel:
             torch.cuda.synchronize(self._device)
             self.last_phase_ms = {marks[i][0]: marks[i - 1][1].elapsed_time(marks[i][1]) for i in range(1, len(marks))}
         return results  # type: ignore[return-value]
+
+    # ------------------------------------------------------ pipelined batches
+    def _streams(self):
+        st = getattr(self, "_pipe_streams", None)
+        if st is None:
+            enc = torch.cuda.Stream(device=self._device)
+            dec = torch.cuda.Stream(device=self._device, priority=-1)  # short decode kernels jump the queue
+            st = self._pipe_streams = (enc, dec)
+        return st
+
+    def batch_generate_ids_pipelined(self, batches, max_tokens: int = DEFAULT_MAX_TOKENS, ignore_eos: bool = False):
+        """Generator over an iterable of (images, prompt-id lists) batches; yields each
+        batch's greedy ids in order.  Two HIP streams: the MFMA-bound encode (vision +
+        image prefill + prompt prefill) of batch k+1 runs on the encode stream while
+        the HBM-bound lockstep decode of batch k runs on the high-priority decode
+        stream, over disjoint KV-slab slot groups and disjoint workspaces.  Per batch the
+        result is identical to ``batch_generate_ids`` (same kernels, same order)."""
+        tk = self.config.tokenizer
+        eos = tk.eos_id
+        enc_s, dec_s = self._streams()
+        pending = []
+        group = 0
+        for images, prompts in batches:
+            b = len(images)
+            assert b == len(prompts) and b > 0 and len({len(p) for p in prompts}) == 1
+            self._ensure_batch(2 * b)
+            slot0 = group * b
+            group ^= 1
+            with torch.inference_mode():
+                enc_s.wait_stream(torch.cuda.current_stream(self._device))
+                with torch.cuda.stream(enc_s):
+                    img_emb = self._run_vision_encoder_batch(list(images))
+                    pos = self._prefill_images(img_emb, slot0)
+                    logits, _, p1 = self._prefill_prompts(prompts, pos, slot0)
+                    first = self._pick(logits, 0.0, 0.0)
+                    ev = torch.cuda.Event()
+                    ev.record(enc_s)
+                with torch.cuda.stream(dec_s):
+                    dec_s.wait_event(ev)
+                    first.record_stream(dec_s)
+                    hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, slot0, None, check_every=16)
+                    done = torch.cuda.Event()
+                    done.record(dec_s)
+            pending.append((hist, done, b))
+            if len(pending) > 1:
+                yield self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
+        while pending:
+            yield self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
+
+    def _collect(self, item, eos, max_tokens):
+        hist, done, b = item
+        done.synchronize()
+        cols = hist.t().tolist()
+        return [self._truncate(cols[i], eos, max_tokens) for i in range(b)]
 
     def batch_caption(self, images, length: str = "normal", settings: Optional[dict] = None) -> List[str]:
         tpl = self.config.tokenizer.templates["caption"]

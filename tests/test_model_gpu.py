@@ -127,6 +127,26 @@ def test_hipgraph_decode_equals_eager(tiny):
     assert single[0] == eager[0] and single2[0] == eager[0]
 
 
+def test_pipelined_batches_equal_sequential(tiny):
+    """Encode of batch k+1 overlapped with the decode of batch k on two streams:
+    every batch's ids equal the sequential path's (and the reference's)."""
+    g, cfg, sd, model = tiny
+    images = [golden_image(g, i) for i in range(3)]
+    prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(3)]
+    n = len(g["img0.cap.tokens"])
+    ref = [g[f"img{i}.cap.tokens"].tolist() for i in range(3)]
+    batches = [(images, prompts), (images[::-1], prompts[::-1]), (images[:2] + images[:1], prompts[:2] + prompts[:1]), (images, prompts)]
+    for use_graphs in (False, True):
+        model.use_graphs = use_graphs
+        try:
+            outs = list(model.batch_generate_ids_pipelined(batches, max_tokens=n))
+        finally:
+            model.use_graphs = False
+        assert outs[0] == ref and outs[3] == ref
+        assert outs[1] == ref[::-1]
+        assert outs[2] == ref[:2] + ref[:1]
+
+
 def test_teacher_forced_logits_vs_reference(tiny):
     g, cfg, sd, model = tiny
     enc = model.encode_image(golden_image(g, 0))

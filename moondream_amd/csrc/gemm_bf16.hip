@@ -331,8 +331,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   // residual operand: all MI x 4 16-byte pieces of this lane are requested up front
   // (one exposed memory latency per tile instead of one per 32-row block); r may
   // alias c, each piece is read and later written by the same lane
-  u32x4 rres[EPI == MD_EPI_RESIDUAL ? MI : 1][4];
-  if constexpr (EPI == MD_EPI_RESIDUAL) {
+  constexpr bool PREFETCH_R = (EPI == MD_EPI_RESIDUAL) && MI > 1;  // small decode tiles keep their register budget low
+  u32x4 rres[PREFETCH_R ? MI : 1][4];
+  if constexpr (PREFETCH_R) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -374,7 +375,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
               v[e] = pack_bf16x2(gelu_tanh_f32(lo_bf(v[e])), gelu_tanh_f32(hi_bf(v[e])));
           }
         } else if constexpr (EPI == MD_EPI_RESIDUAL) {
-          const u32x4 rv = rres[i][q];
+          u32x4 rv;
+          if constexpr (PREFETCH_R) {
+            rv = rres[i][q];
+          } else {
+            const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
+            rv = *(const u32x4*)(p.R + rrow * p.ldr + n);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             v[e] = pack_bf16x2(lo_bf(rv[e]) + lo_bf(v[e]), hi_bf(rv[e]) + hi_bf(v[e]));
@@ -419,6 +426,12 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     case 6: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32>(k, stream);  // 32-wide slices, 5-deep ring
     case 3: return k.slices > 1 ? launch_cfg<64, 128, 1, 2, EPI, true, DEC_STAGES>(k, stream)
                                 : launch_cfg<64, 128, 1, 2, EPI, false, DEC_STAGES>(k, stream);
+    // decode regime, co-residency friendly: 4 waves of 32x64, 32-wide slices, 2-deep ring
+    // = 24 KiB LDS and <= 96 VGPRs, so these workgroups fit NEXT TO a resident 256x256
+    // encode tile (128 KiB LDS, 2 x 204 VGPRs per SIMD) when decode and encode overlap
+    // on two streams, instead of waiting for a CU to drain
+    case 7: return k.slices > 1 ? launch_cfg<64, 128, 2, 2, EPI, true, 2, 32>(k, stream)
+                                : launch_cfg<64, 128, 2, 2, EPI, false, 2, 32>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }
@@ -428,7 +441,7 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
 // split over S workgroups per tile so that ~256+ workgroups pull from HBM.  S is a
 // function of (n, k) only.
 constexpr size_t TICKET_BYTES = 8192;
-constexpr int DEC_BN = 128, DEC_SLAB_FLOATS = 128 * 2 * 2 * 16;  // NT * MI * NI * 16
+constexpr int DEC_BN = 128, DEC_SLAB_FLOATS = 128 * 2 * 2 * 16;  // NT * MI * NI * 16 (same for both decode configs)
 
 int decode_slices(int n_store, int k_pad) {
   const int tiles = (n_store + DEC_BN - 1) / DEC_BN, nk = k_pad / BK;
@@ -506,7 +519,8 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.tickets = nullptr;
   const char* forced = getenv("MD_GEMM_TILE");
   if (a->m <= 64 && !(forced && *forced)) {
-    tile = 3;
+    const char* dc = getenv("MD_DECODE_CFG");  // "deep": 2 waves, 64-wide slices, 4-deep ring (96 KiB LDS)
+    tile = (dc && dc[0] == 'd') ? 3 : 7;
     const int sl = decode_slices(k.n_store, k.K);
     const size_t tiles = (k.n_store + DEC_BN - 1) / DEC_BN;
     const size_t need = TICKET_BYTES + tiles * sl * DEC_SLAB_FLOATS * sizeof(float);

@@ -21,5 +21,5 @@ shapes=[(23328,588,1152,2),(23328,1152,4304,1),(23328,1152,3456,0),(23328,1152,1
 for (m,k,n,epi) in shapes:
     out=[]
     t1=run(m,k,n,epi,{'MD_GEMM_TILE':'1'}); t4=run(m,k,n,epi,{'MD_GEMM_TILE':'4'})
-    t5=run(m,k,n,epi,{'MD_GEMM_TILE':'5'}); t6=run(m,k,n,epi,{'MD_GEMM_TILE':'6'}); t0=run(m,k,n,epi,{'MD_GEMM_TILE':'0'})
-    print(f"m={m} k={k} n={n}: 256x256 bk64x2 {t0:6.0f} | bk32x4 {t5:6.0f} | bk32x5 {t6:6.0f} | 256x128: 2-stage {t1:6.0f}  3-stage {t4:6.0f}", flush=True)
+    t8=run(m,k,n,epi,{'MD_GEMM_TILE':'8'}); t9=run(m,k,n,epi,{'MD_GEMM_TILE':'9'}); t0=run(m,k,n,epi,{'MD_GEMM_TILE':'0'}); t2=run(m,k,n,epi,{'MD_GEMM_TILE':'2'})
+    print(f"m={m} k={k} n={n}: 256x256 {t0:6.0f} | 128x256 bk32x3 {t8:6.0f} | 128x256 bk64x2 {t9:6.0f} | 256x128x3 {t4:6.0f} | 128x128 {t2:6.0f}", flush=True)

@@ -299,24 +299,46 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
     }
     __syncthreads();
     const float* base = p.slabs + (int64_t)tile_id * S * SLAB;
-    const int per = SL / S;  // S is a power of two <= SL
-    for (int q = slice * per; q < (slice + 1) * per; ++q) {
-      float v = 0.f;
-      for (int sl = 0; sl < S; ++sl) v += base[(int64_t)sl * SLAB + q * NT + tid];  // fixed slice order
-      const int i = q / (NI * 16), j = (q / 16) % NI, r = q % 16;
-      const int m = m0 + wm * TM + 32 * i + l31;
-      const int n = n0 + wn * TN + 32 * j + 8 * (r >> 2) + 4 * hi + (r & 3);
-      if (m < p.M && n < p.n_store) {
-        if (p.bias != nullptr) v += bf2f(p.bias[n]);
-        float y = bf2f(f2bf(v));  // the reference's rounding point: bf16(acc + bias)
-        if constexpr (EPI == MD_EPI_GELU) {
-          if (n >= p.gelu_from) y = gelu_tanh_f32(y);
-        } else if constexpr (EPI == MD_EPI_RESIDUAL) {
-          const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
-          y = bf2f(p.R[rrow * p.ldr + n]) + y;
+    // This workgroup's share: SL / S slots, each summed over the S slabs in slice
+    // order.  SL loads per lane in total whatever S is; the compile-time S makes them
+    // all independent and in flight together (a runtime-S loop would issue one
+    // dependent load at a time, each a post-invalidate miss).
+    auto reduce_share = [&](auto s_c) {
+      constexpr int SC = decltype(s_c)::value, PER = SL / SC;
+      float vals[PER][SC];
+#pragma unroll
+      for (int ql = 0; ql < PER; ++ql)
+#pragma unroll
+        for (int sl = 0; sl < SC; ++sl)
+          vals[ql][sl] = base[(int64_t)sl * SLAB + (slice * PER + ql) * NT + tid];
+#pragma unroll
+      for (int ql = 0; ql < PER; ++ql) {
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < SC; ++sl) v += vals[ql][sl];  // fixed slice order
+        const int q = slice * PER + ql;
+        const int i = q / (NI * 16), j = (q / 16) % NI, r = q % 16;
+        const int m = m0 + wm * TM + 32 * i + l31;
+        const int n = n0 + wn * TN + 32 * j + 8 * (r >> 2) + 4 * hi + (r & 3);
+        if (m < p.M && n < p.n_store) {
+          if (p.bias != nullptr) v += bf2f(p.bias[n]);
+          float y = bf2f(f2bf(v));  // the reference's rounding point: bf16(acc + bias)
+          if constexpr (EPI == MD_EPI_GELU) {
+            if (n >= p.gelu_from) y = gelu_tanh_f32(y);
+          } else if constexpr (EPI == MD_EPI_RESIDUAL) {
+            const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
+            y = bf2f(p.R[rrow * p.ldr + n]) + y;
+          }
+          p.C[(int64_t)m * p.ldc + n] = f2bf(y);
         }
-        p.C[(int64_t)m * p.ldc + n] = f2bf(y);
       }
+    };
+    switch (S) {
+      case 2: reduce_share(std::integral_constant<int, 2>{}); break;
+      case 4: reduce_share(std::integral_constant<int, 4>{}); break;
+      case 8: reduce_share(std::integral_constant<int, 8>{}); break;
+      case 16: reduce_share(std::integral_constant<int, 16>{}); break;
+      default: reduce_share(std::integral_constant<int, 32>{}); break;
     }
     // the last workgroup to leave re-arms the tile's counters for the next launch
     __syncthreads();
@@ -473,7 +495,11 @@ int decode_slices(int n_store, int k_pad) {
   const int tiles = (n_store + DEC_BN - 1) / DEC_BN, nk = k_pad / BK;
   if (const char* e = getenv("MD_DECODE_SLICES")) {  // experiments
     const int v = atoi(e);
-    if (v >= 1) return std::min(std::min(v, 32), std::max(1, nk));
+    if (v >= 1) {
+      int s2 = 1;
+      while (s2 * 2 <= std::min(std::min(v, 32), std::max(1, nk))) s2 *= 2;
+      return s2;  // power of two <= 32
+    }
   }
   // measured model (profiles/r01_decode_gemm_sweep.txt): one workgroup saturates its
   // CU's load path (~40 GB/s), the last arriver pays ~1 us per 32 KiB slab, so

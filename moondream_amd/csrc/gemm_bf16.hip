@@ -55,7 +55,6 @@ struct GemmK {
   int res_row_mod;
   int group_m;  // tile-order grouping (row panels per group)
   int gelu_from;  // EPI_GELU: columns >= gelu_from get the GELU
-  int xcd;        // 1: XCD-contiguous remap of the workgroup id
   // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
   int slices;
   float* slabs;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 
   // ---- workgroup -> tile -------------------------------------------------
   const int nwg = p.tiles_m * p.tiles_n;
-  const int L = p.xcd ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+  const int L = xcd_remap(blockIdx.x, nwg);
   const int GROUP_M = p.group_m;
   const int per_group = GROUP_M * p.tiles_n;
   const int first_m = (L / per_group) * GROUP_M;
@@ -262,21 +261,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   }
 
   if constexpr (SPLITK) {
-    // Cross-workgroup split-K, deterministic and PARALLEL: every slice publishes its
-    // fp32 accumulators as a slab in accumulator-register order (coalesced), signals
-    // arrival (agent-scope release -> counter, cdna guide 6 G16) and waits until all
-    // S slices of its tile have arrived (bounded relaxed poll by one lane, then ONE
-    // agent-scope acquire).  Then slice s reduces ITS share of the accumulator slots
-    // -- slots [s*SL/S, (s+1)*SL/S) -- over all S slabs in slice order and applies the
-    // epilogue to those elements.  The reduction cost is independent of S, and the
-    // summation tree depends on the layer shape only, never on how many rows are live.
-    // All tiles*S workgroups are co-resident by construction (<= 1024 workgroups of
-    // <= 256 threads, 24-96 KiB LDS), which the wait relies on.
-    constexpr int SL = MI * NI * 16;       // accumulator slots per lane
-    constexpr int SLAB = NT * SL;          // floats per workgroup
-    const int S = p.slices, slice = blockIdx.y;
+    // Cross-workgroup split-K, deterministic: every slice publishes its fp32
+    // accumulators as a slab in accumulator-register order (coalesced, and each
+    // lane later reads back exactly its own registers); the LAST workgroup to
+    // arrive (agent-scope release -> ticket -> acquire, cdna guide 6 G16) sums the
+    // slabs in slice order and runs the epilogue.  The summation tree depends on
+    // the layer shape only, never on how many rows are live.
+    constexpr int SLAB = NT * MI * NI * 16;  // floats per workgroup
     const int tile_id = tm * p.tiles_n + tn;
-    float* slab = p.slabs + ((int64_t)tile_id * S + slice) * SLAB;
+    float* slab = p.slabs + ((int64_t)tile_id * p.slices + blockIdx.y) * SLAB;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -285,71 +278,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
         for (int r = 0; r < 16; ++r) slab[((i * NI + j) * 16 + r) * NT + tid] = acc[i][j][r];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned* arrive = p.tickets + tile_id;
-    unsigned* depart = p.tickets + 1024 + tile_id;
+    unsigned* flag = (unsigned*)smem;  // operand ring is dead after the barrier
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (unsigned spins = 0; spins < (1u << 22); ++spins) {  // bounded: never hang the GPU
-        if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)S) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const unsigned tk = __hip_atomic_fetch_add(p.tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (tk == (unsigned)p.slices - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    const float* base = p.slabs + (int64_t)tile_id * S * SLAB;
-    // This workgroup's share: SL / S slots, each summed over the S slabs in slice
-    // order.  SL loads per lane in total whatever S is; the compile-time S makes them
-    // all independent and in flight together (a runtime-S loop would issue one
-    // dependent load at a time, each a post-invalidate miss).
-    auto reduce_share = [&](auto s_c) {
-      constexpr int SC = decltype(s_c)::value, PER = SL / SC;
-      float vals[PER][SC];
-#pragma unroll
-      for (int ql = 0; ql < PER; ++ql)
-#pragma unroll
-        for (int sl = 0; sl < SC; ++sl)
-          vals[ql][sl] = base[(int64_t)sl * SLAB + (slice * PER + ql) * NT + tid];
-#pragma unroll
-      for (int ql = 0; ql < PER; ++ql) {
-        float v = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < SC; ++sl) v += vals[ql][sl];  // fixed slice order
-        const int q = slice * PER + ql;
-        const int i = q / (NI * 16), j = (q / 16) % NI, r = q % 16;
-        const int m = m0 + wm * TM + 32 * i + l31;
-        const int n = n0 + wn * TN + 32 * j + 8 * (r >> 2) + 4 * hi + (r & 3);
-        if (m < p.M && n < p.n_store) {
-          if (p.bias != nullptr) v += bf2f(p.bias[n]);
-          float y = bf2f(f2bf(v));  // the reference's rounding point: bf16(acc + bias)
-          if constexpr (EPI == MD_EPI_GELU) {
-            if (n >= p.gelu_from) y = gelu_tanh_f32(y);
-          } else if constexpr (EPI == MD_EPI_RESIDUAL) {
-            const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
-            y = bf2f(p.R[rrow * p.ldr + n]) + y;
-          }
-          p.C[(int64_t)m * p.ldc + n] = f2bf(y);
-        }
-      }
-    };
-    switch (S) {
-      case 2: reduce_share(std::integral_constant<int, 2>{}); break;
-      case 4: reduce_share(std::integral_constant<int, 4>{}); break;
-      case 8: reduce_share(std::integral_constant<int, 8>{}); break;
-      case 16: reduce_share(std::integral_constant<int, 16>{}); break;
-      default: reduce_share(std::integral_constant<int, 32>{}); break;
-    }
-    // the last workgroup to leave re-arms the tile's counters for the next launch
-    __syncthreads();
+    if (*flag == 0u) return;
     if (tid == 0) {
-      const unsigned d = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d == (unsigned)S - 1u) {
-        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave zero for the next launch
     }
-    return;
+    __syncthreads();
+    const float* base = p.slabs + (int64_t)tile_id * p.slices * SLAB;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int sl = 0; sl < p.slices; ++sl)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += base[(int64_t)sl * SLAB + ((i * NI + j) * 16 + r) * NT + tid];
   }
 
   // ---- epilogue -----------------------------------------------------------
@@ -468,10 +424,6 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     case 4: return launch_cfg<256, 128, 4, 2, EPI, false, 3>(k, stream);      // 3-deep ring
     case 5: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32>(k, stream);  // 32-wide slices, 4-deep ring
     case 6: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32>(k, stream);  // 32-wide slices, 5-deep ring
-    // two independent 4-wave workgroups per CU (each 128x256, per-wave work as in the
-    // 256x256 config): their barriers are not in lockstep, one computes while the other waits
-    case 8: return launch_cfg<128, 256, 1, 4, EPI, false, 3, 32>(k, stream);
-    case 9: return launch_cfg<128, 256, 1, 4, EPI, false, 2, 64>(k, stream);
     case 3: return k.slices > 1 ? launch_cfg<64, 128, 1, 2, EPI, true, DEC_STAGES>(k, stream)
                                 : launch_cfg<64, 128, 1, 2, EPI, false, DEC_STAGES>(k, stream);
     // decode regime, co-residency friendly: 4 waves of 32x64, 32-wide slices, 2-deep ring
@@ -495,19 +447,13 @@ int decode_slices(int n_store, int k_pad) {
   const int tiles = (n_store + DEC_BN - 1) / DEC_BN, nk = k_pad / BK;
   if (const char* e = getenv("MD_DECODE_SLICES")) {  // experiments
     const int v = atoi(e);
-    if (v >= 1) {
-      int s2 = 1;
-      while (s2 * 2 <= std::min(std::min(v, 32), std::max(1, nk))) s2 *= 2;
-      return s2;  // power of two <= 32
-    }
+    if (v >= 1) return std::min(v, std::max(1, nk));
   }
   // measured model (profiles/r01_decode_gemm_sweep.txt): one workgroup saturates its
   // CU's load path (~40 GB/s), the last arriver pays ~1 us per 32 KiB slab, so
   // t ~ 2 us + bytes / (tiles * S * 40 GB/s) + S * 1 us: aim for >= 128 workgroups, S <= 8
-  // with the parallel reduction the cost of a slice no longer grows with S: aim for
-  // ~512 workgroups (two per CU), S a power of two <= 32 (accumulator slots per lane)
   int s = 1;
-  while (s < 32 && tiles * s < 512 && s * 2 <= nk / 2) s *= 2;
+  while (s < 8 && tiles * s < 128 && s * 2 <= nk / 2) s *= 2;
   return s;
 }
 
@@ -565,8 +511,6 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.tiles_m = k.tiles_n = 0;
   k.group_m = 8;
   k.gelu_from = a->gelu_from_col;
-  k.xcd = 1;
-  if (const char* e = getenv("MD_GEMM_XCD")) k.xcd = atoi(e);  // experiments
   if (const char* e = getenv("MD_GEMM_GROUP_M")) k.group_m = std::max(1, atoi(e));  // experiments
   hipStream_t s = (hipStream_t)stream;
   int tile = pick_tile(k.M, k.n_store);
@@ -580,7 +524,7 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
     const int sl = decode_slices(k.n_store, k.K);
     const size_t tiles = (k.n_store + DEC_BN - 1) / DEC_BN;
     const size_t need = TICKET_BYTES + tiles * sl * DEC_SLAB_FLOATS * sizeof(float);
-    if (sl > 1 && a->splitk_ws != nullptr && a->splitk_ws_bytes >= need && tiles <= 1024) {
+    if (sl > 1 && a->splitk_ws != nullptr && a->splitk_ws_bytes >= need && tiles * 4 <= TICKET_BYTES) {
       k.slices = sl;
       k.tickets = (unsigned*)a->splitk_ws;
       k.slabs = (float*)((char*)a->splitk_ws + TICKET_BYTES);

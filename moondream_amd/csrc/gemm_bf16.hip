@@ -92,7 +92,7 @@ __device__ __forceinline__ void wait_vm() {
 // whose per-slice compute is far shorter than the DMA latency.
 // BKT = K elements per slice (64: 128-byte rows, 8 chunks; 32: 64-byte rows, 4 chunks,
 // which lets the 256x256 tile keep three 32 KiB slices in flight in a 4-deep ring).
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, bool PP = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   constexpr int ROW_BYTES = BKT * 2;
   constexpr int CH = BKT / 8;                 // 16-byte chunks per row
@@ -185,79 +185,166 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) b_src[j] += (int64_t)t0 * ROW_BYTES;
   }
-  static_assert((STAGES - 2) * (NA + NB) < 64, "vmcnt is a 6-bit counter");
-  // prologue: slices 0 .. STAGES-2 in flight
-  static_for<0, STAGES - 1>([&](auto sc) {
-    constexpr int SL = decltype(sc)::value;
-    if (SL < nk) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, SL); });
-  });
-  for (int t = 0; t < nk; ++t) {
-    // slice t has landed: own DMA by a COUNTED vmcnt (the min(STAGES-2, nk-1-t)
-    // younger slices stay in flight), everybody's by the barrier, which also fences
-    // the previous iteration's reads of the ring slot refilled during this one
-    if constexpr (STAGES == 2) {
-      wait_vm<0>();
-    } else {
-      const int ahead = min(STAGES - 2, nk - 1 - t);
-      static_for<0, STAGES - 1>([&](auto ac) {
-        constexpr int A = decltype(ac)::value;
-        if (ahead == A) wait_vm<A*(NA + NB)>();
-      });
-    }
-    // raw s_barrier: __syncthreads() would add a vmcnt(0) and drain the DMA ring.
-    // Every ds_read of this wave was waited for (wait_lgkm<0>) before its last MFMAs.
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const bool has_next = t + STAGES - 1 < nk;
-    const int nstage = (t + STAGES - 1) % STAGES;
-    // LDS -> register fragments, software pipelined by hand: the six ds_read_b128 of
-    // K-step s+1 are issued BEFORE the eight MFMAs of step s and waited for with a
-    // counted lgkmcnt (LDS returns in order), so the matrix pipe never waits on LDS
-    // latency inside a slice.  (The two waves of a SIMD leave the barrier in
-    // lockstep and cannot cover for each other; left to itself hipcc sinks every
-    // read next to its use and waits lgkmcnt(0) in front of each MFMA group.)
-    // Inline asm: the compiler neither counts these reads nor moves MFMAs across
-    // the sched_barrier that follows each wait (cdna guide 5.7, form iii).
-    const uint32_t st = lds_base + (t % STAGES) * STAGE;
+  if constexpr (PP) {
+    // ---- ping-pong schedule -------------------------------------------------
+    // 32-wide slices, one slice = one PHASE (barrier + 2 K-steps).  The second half
+    // of the waves (one per SIMD, like the first half) runs ONE PHASE BEHIND the
+    // first: in phase ph the leading group works on slice ph, the lagging group on
+    // slice ph-1.  The lagging group prefetches the first fragments of its NEXT slice
+    // across the barrier (that slice was made visible one phase earlier), so right
+    // after every barrier it can issue MFMAs while the leading group is still
+    // fetching from LDS, and before the barrier the roles are reversed: the matrix
+    // pipe is not idle at slice boundaries the way it is when all eight waves stop,
+    // fetch and restart together.  The DMA of slice ph+DEPTH is issued in phase ph
+    // into the ring slot whose slice (ph-2) the lagging group finished in phase ph-1.
+    static_assert(KSTEPS == 2 && STAGES >= 4 && !SPLITK, "ping-pong config");
+    constexpr int PIECES = NA + NB;
+    constexpr int DEPTH = STAGES - 2;
+    static_assert((DEPTH - 1) * PIECES < 64, "vmcnt is a 6-bit counter");
+    const int lag = (wave >= (WM * WN) / 2) ? 1 : 0;  // wave is an SGPR value: uniform
+    static_for<0, DEPTH>([&](auto sc) {
+      constexpr int SL0 = decltype(sc)::value;
+      if (SL0 < nk) static_for<0, PIECES>([&](auto pc) { issue_piece(pc, SL0); });
+    });
     bf16x8 af[2][MI], bfr[2][NI];
-    auto issue_reads = [&](auto set_c, auto step_c) {
+    auto issue_reads = [&](auto set_c, auto step_c, uint32_t st) {
       constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
       const uint32_t coff = (uint32_t)(((2 * S + hi) ^ swz) * 16);
       const uint32_t a_addr = st + a_row_off + coff, b_addr = st + b_row_off + coff;
       static_for<0, NI>([&](auto j) { ds_read_b128<decltype(j)::value * 32 * ROW_BYTES>(bfr[SET][decltype(j)::value], b_addr); });
       static_for<0, MI>([&](auto i) { ds_read_b128<decltype(i)::value * 32 * ROW_BYTES>(af[SET][decltype(i)::value], a_addr); });
     };
-    issue_reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    static_for<0, KSTEPS>([&](auto sc) {
-      constexpr int S = decltype(sc)::value, SET = S & 1;
-      if constexpr (S + 1 < KSTEPS) {
-        issue_reads(std::integral_constant<int, (S + 1) & 1>{}, std::integral_constant<int, S + 1>{});
-        wait_lgkm<MI + NI>();  // everything but the reads just issued has landed
-      } else {
-        wait_lgkm<0>();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // The LDS-DMA pieces of slice t+1 are spread over the four K-steps and issued
-      // BETWEEN MFMAs: an LDS-DMA issue costs the wave 60-180 cycles, which hides
-      // under the 32-cycle-per-MFMA matrix pipe instead of idling it at the head
-      // of the slice.  Piece p goes to step p % KSTEPS, slot p / KSTEPS.
-      constexpr int PPS = (NA + NB + KSTEPS - 1) / KSTEPS;  // pieces per K-step
-      static_for<0, MI * NI>([&](auto mc) {
-        constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
-        acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
-        static_for<0, PPS>([&](auto qc) {
-          constexpr int Q = decltype(qc)::value, P = S + KSTEPS * Q;
-          // slot Q of this step sits behind MFMA number Q * (MI*NI) / PPS
-          if constexpr ((Q * MI * NI) / PPS == Mx && P < NA + NB) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) issue_piece(std::integral_constant<int, P>{}, nstage);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        });
+    bool prefetched = false;
+    for (int ph = 0; ph <= nk; ++ph) {
+      const int ahead = max(0, min(DEPTH - 1, nk - 1 - ph));
+      static_for<0, DEPTH>([&](auto ac) {
+        constexpr int A = decltype(ac)::value;
+        if (ahead == A) wait_vm<A * PIECES>();
       });
-      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const bool has_next = ph + DEPTH < nk;
+      const int nstage = (ph + DEPTH) % STAGES;
+      const int sl = ph - lag;
+      auto mfma_step = [&](auto set_c, auto step_c) {
+        constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
+        constexpr int PPS = (PIECES + KSTEPS - 1) / KSTEPS;
+        static_for<0, MI * NI>([&](auto mc) {
+          constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
+          acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
+          static_for<0, PPS>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value, P = S + KSTEPS * Q;
+            if constexpr ((Q * MI * NI) / PPS == Mx && P < PIECES) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (has_next) issue_piece(std::integral_constant<int, P>{}, nstage);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+        });
+      };
+      if (sl >= 0 && sl < nk) {
+        const uint32_t st = lds_base + (sl % STAGES) * STAGE;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        if (!prefetched) issue_reads(I0{}, I0{}, st);
+        issue_reads(I1{}, I1{}, st);
+        wait_lgkm<MI + NI>();  // step-0 fragments are in; step-1 reads still in flight
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(I0{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        const bool pf = lag && (sl + 1 < nk);
+        if (pf) {
+          // next slice's first fragments, across the coming barrier (set 0 is free again)
+          issue_reads(I0{}, I0{}, lds_base + ((sl + 1) % STAGES) * STAGE);
+          wait_lgkm<MI + NI>();
+        } else {
+          wait_lgkm<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        prefetched = pf;
+      } else if (has_next) {
+        // this group idles in the first / last phase but still owes its DMA pieces
+        static_for<0, PIECES>([&](auto pc) { issue_piece(pc, nstage); });
+      }
+    }
+  } else {
+    static_assert((STAGES - 2) * (NA + NB) < 64, "vmcnt is a 6-bit counter");
+    // prologue: slices 0 .. STAGES-2 in flight
+    static_for<0, STAGES - 1>([&](auto sc) {
+      constexpr int SL = decltype(sc)::value;
+      if (SL < nk) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, SL); });
     });
+    for (int t = 0; t < nk; ++t) {
+      // slice t has landed: own DMA by a COUNTED vmcnt (the min(STAGES-2, nk-1-t)
+      // younger slices stay in flight), everybody's by the barrier, which also fences
+      // the previous iteration's reads of the ring slot refilled during this one
+      if constexpr (STAGES == 2) {
+        wait_vm<0>();
+      } else {
+        const int ahead = min(STAGES - 2, nk - 1 - t);
+        static_for<0, STAGES - 1>([&](auto ac) {
+          constexpr int A = decltype(ac)::value;
+          if (ahead == A) wait_vm<A*(NA + NB)>();
+        });
+      }
+      // raw s_barrier: __syncthreads() would add a vmcnt(0) and drain the DMA ring.
+      // Every ds_read of this wave was waited for (wait_lgkm<0>) before its last MFMAs.
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const bool has_next = t + STAGES - 1 < nk;
+      const int nstage = (t + STAGES - 1) % STAGES;
+      // LDS -> register fragments, software pipelined by hand: the six ds_read_b128 of
+      // K-step s+1 are issued BEFORE the eight MFMAs of step s and waited for with a
+      // counted lgkmcnt (LDS returns in order), so the matrix pipe never waits on LDS
+      // latency inside a slice.  (The two waves of a SIMD leave the barrier in
+      // lockstep and cannot cover for each other; left to itself hipcc sinks every
+      // read next to its use and waits lgkmcnt(0) in front of each MFMA group.)
+      // Inline asm: the compiler neither counts these reads nor moves MFMAs across
+      // the sched_barrier that follows each wait (cdna guide 5.7, form iii).
+      const uint32_t st = lds_base + (t % STAGES) * STAGE;
+      bf16x8 af[2][MI], bfr[2][NI];
+      auto issue_reads = [&](auto set_c, auto step_c) {
+        constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
+        const uint32_t coff = (uint32_t)(((2 * S + hi) ^ swz) * 16);
+        const uint32_t a_addr = st + a_row_off + coff, b_addr = st + b_row_off + coff;
+        static_for<0, NI>([&](auto j) { ds_read_b128<decltype(j)::value * 32 * ROW_BYTES>(bfr[SET][decltype(j)::value], b_addr); });
+        static_for<0, MI>([&](auto i) { ds_read_b128<decltype(i)::value * 32 * ROW_BYTES>(af[SET][decltype(i)::value], a_addr); });
+      };
+      issue_reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      static_for<0, KSTEPS>([&](auto sc) {
+        constexpr int S = decltype(sc)::value, SET = S & 1;
+        if constexpr (S + 1 < KSTEPS) {
+          issue_reads(std::integral_constant<int, (S + 1) & 1>{}, std::integral_constant<int, S + 1>{});
+          wait_lgkm<MI + NI>();  // everything but the reads just issued has landed
+        } else {
+          wait_lgkm<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // The LDS-DMA pieces of slice t+1 are spread over the four K-steps and issued
+        // BETWEEN MFMAs: an LDS-DMA issue costs the wave 60-180 cycles, which hides
+        // under the 32-cycle-per-MFMA matrix pipe instead of idling it at the head
+        // of the slice.  Piece p goes to step p % KSTEPS, slot p / KSTEPS.
+        constexpr int PPS = (NA + NB + KSTEPS - 1) / KSTEPS;  // pieces per K-step
+        static_for<0, MI * NI>([&](auto mc) {
+          constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
+          acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
+          static_for<0, PPS>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value, P = S + KSTEPS * Q;
+            // slot Q of this step sits behind MFMA number Q * (MI*NI) / PPS
+            if constexpr ((Q * MI * NI) / PPS == Mx && P < NA + NB) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (has_next) issue_piece(std::integral_constant<int, P>{}, nstage);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
   }
 
   if constexpr (SPLITK) {
@@ -392,13 +479,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, bool PP = false>
 md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int ring = STAGES * (BM + BN) * BKT * 2;
   constexpr int epi = WM * WN * 4096;
   constexpr int lds = ring > epi ? ring : epi;
-  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT>;
+  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -432,6 +519,8 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     // on two streams, instead of waiting for a CU to drain
     case 7: return k.slices > 1 ? launch_cfg<64, 128, 2, 2, EPI, true, 2, 32>(k, stream)
                                 : launch_cfg<64, 128, 2, 2, EPI, false, 2, 32>(k, stream);
+    case 8: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, true>(k, stream);  // ping-pong wave groups
+    case 9: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, true>(k, stream);  // same, 5-deep ring
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }

@@ -20,6 +20,5 @@ def run(m,k,n,epi,env):
 shapes=[(23328,588,1152,2),(23328,1152,4304,1),(23328,1152,3456,0),(23328,1152,1152,2),(23328,4304,1152,2),(46720,2048,6144,0),(46720,2048,2048,2),(8192,8192,8192,0)]
 for (m,k,n,epi) in shapes:
     out=[]
-    t1=run(m,k,n,epi,{'MD_GEMM_TILE':'1'}); t4=run(m,k,n,epi,{'MD_GEMM_TILE':'4'})
-    t8=run(m,k,n,epi,{'MD_GEMM_TILE':'8'}); t9=run(m,k,n,epi,{'MD_GEMM_TILE':'9'}); t0=run(m,k,n,epi,{'MD_GEMM_TILE':'0'}); t2=run(m,k,n,epi,{'MD_GEMM_TILE':'2'})
-    print(f"m={m} k={k} n={n}: 256x256 {t0:6.0f} | 128x256 bk32x3 {t8:6.0f} | 128x256 bk64x2 {t9:6.0f} | 256x128x3 {t4:6.0f} | 128x128 {t2:6.0f}", flush=True)
+    r={t:run(m,k,n,epi,{'MD_GEMM_TILE':t}) for t in ('0','5','8','9')}
+    print(f"m={m} k={k} n={n}: 256x256 bk64x2 {r['0']:6.0f} | bk32x4 lockstep {r['5']:6.0f} | PING-PONG bk32x4 {r['8']:6.0f} | PING-PONG bk32x5 {r['9']:6.0f}", flush=True)

@@ -519,6 +519,10 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     // on two streams, instead of waiting for a CU to drain
     case 7: return k.slices > 1 ? launch_cfg<64, 128, 2, 2, EPI, true, 2, 32>(k, stream)
                                 : launch_cfg<64, 128, 2, 2, EPI, false, 2, 32>(k, stream);
+    // decode regime, 64x64 tiles: twice the tiles of 64x128 -> the wide fused layer needs no
+    // split-K, the N = 2048 layers get 16 KiB slabs
+    case 10: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4>(k, stream)
+                                 : launch_cfg<64, 64, 2, 1, EPI, false, 4>(k, stream);
     case 8: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, true>(k, stream);  // ping-pong wave groups
     case 9: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, true>(k, stream);  // same, 5-deep ring
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
@@ -530,9 +534,19 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
 // split over S workgroups per tile so that ~256+ workgroups pull from HBM.  S is a
 // function of (n, k) only.
 constexpr size_t TICKET_BYTES = 8192;
-constexpr int DEC_BN = 128, DEC_SLAB_FLOATS = 128 * 2 * 2 * 16;  // NT * MI * NI * 16 (same for both decode configs)
+
+// decode-regime config: "64" = 64x64 tiles (default), "deep" = 64x128 / 4-deep ring, "co" = 64x128 / 24 KiB
+int decode_cfg() {
+  const char* dc = getenv("MD_DECODE_CFG");
+  if (dc && dc[0] == 'd') return 3;
+  if (dc && dc[0] == 'c') return 7;
+  return 10;
+}
+int decode_bn() { return decode_cfg() == 10 ? 64 : 128; }
+int decode_slab_floats() { return decode_cfg() == 10 ? 128 * 1 * 2 * 16 : 128 * 2 * 2 * 16; }  // NT * MI * NI * 16
 
 int decode_slices(int n_store, int k_pad) {
+  const int DEC_BN = decode_bn();
   const int tiles = (n_store + DEC_BN - 1) / DEC_BN, nk = k_pad / BK;
   if (const char* e = getenv("MD_DECODE_SLICES")) {  // experiments
     const int v = atoi(e);
@@ -608,11 +622,10 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.tickets = nullptr;
   const char* forced = getenv("MD_GEMM_TILE");
   if (a->m <= 64 && !(forced && *forced)) {
-    const char* dc = getenv("MD_DECODE_CFG");  // "deep": 2 waves, 64-wide slices, 4-deep ring (96 KiB LDS)
-    tile = (dc && dc[0] == 'd') ? 3 : 7;
+    tile = decode_cfg();
     const int sl = decode_slices(k.n_store, k.K);
-    const size_t tiles = (k.n_store + DEC_BN - 1) / DEC_BN;
-    const size_t need = TICKET_BYTES + tiles * sl * DEC_SLAB_FLOATS * sizeof(float);
+    const size_t tiles = (k.n_store + decode_bn() - 1) / decode_bn();
+    const size_t need = TICKET_BYTES + tiles * sl * decode_slab_floats() * sizeof(float);
     if (sl > 1 && a->splitk_ws != nullptr && a->splitk_ws_bytes >= need && tiles * 4 <= TICKET_BYTES) {
       k.slices = sl;
       k.tickets = (unsigned*)a->splitk_ws;
@@ -649,8 +662,8 @@ extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32
   const int n_store = store_pad_cols ? lin->n_pad : lin->n;
   const int sl = decode_slices(n_store, lin->k_pad);
   if (sl == 1) return 0;
-  const size_t tiles = (n_store + DEC_BN - 1) / DEC_BN;
-  return TICKET_BYTES + tiles * sl * DEC_SLAB_FLOATS * sizeof(float);
+  const size_t tiles = (n_store + decode_bn() - 1) / decode_bn();
+  return TICKET_BYTES + tiles * sl * decode_slab_floats() * sizeof(float);
 }
 
 extern "C" void md_profile_gemm(int32_t enable) {

@@ -8,7 +8,7 @@ from moondream_amd.weights import PackedLinear
 from tools.kernel_bench import timeit, stream
 lib = _lib.load()
 BF16 = torch.bfloat16
-for (m, k, n, epi) in [(64, 2048, 6144, 0), (64, 2048, 2048, 2), (64, 2048, 8192, 1), (64, 8192, 2048, 2), (1, 2048, 6144, 0), (1, 8192, 2048, 2)]:
+for (m, k, n, epi) in [(64, 2048, 14336, 1), (64, 2048, 6144, 0), (64, 2048, 2048, 2), (64, 2048, 8192, 1), (64, 8192, 2048, 2), (1, 2048, 6144, 0), (1, 8192, 2048, 2)]:
     a = (torch.randn(m, k, device="cuda") * 0.5).to(BF16)
     w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(BF16)
     lin = PackedLinear(w, torch.zeros(n, dtype=BF16), "cuda")

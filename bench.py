@@ -234,7 +234,7 @@ def main():
             "measured_on": "one non-overlapped, eagerly launched step after the timed region",
         },
         "decode_gemm": {
-            "bound": "hbm", "kernel": "gemm_bf16_kernel<64,128> split-K (m <= 64 weight stream)",
+            "bound": "hbm", "kernel": "gemm_bf16_kernel<64,64> decode-regime config (m <= 64 weight stream, split-K where N is small)",
             "achieved": stream_gbs if n1.value else None, "peak": 8000.0, "unit": "GB/s",
             "frac": stream_gbs / 8000.0 if n1.value else None, "launches": int(n1.value),
             "share_of_step": (ms1.value * 1e-3) / step_gpu_s if step_gpu_s > 0 and n1.value else None,

@@ -182,6 +182,16 @@ md_status md_attention_decode(const void* q, int64_t ldq, void* o, int64_t ldo, 
                               int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
                               float scale, void* stream);
 
+/* The decode step's RoPE + KV-slab write + attention in ONE launch (MHA, head_dim 64):
+ * qkv rows are the UN-rotated fused activation [q heads | k heads | v heads]; each
+ * (sequence, head) workgroup rotates its q and k (rope.py:20-48), stores rotated k and v
+ * at slot kv_len[b]-1 (moondream.py:74-78) and attends over keys [0, kv_len[b])
+ * (text.py:48-50).  Bit-identical to md_rope_kv_write followed by md_attention_decode. */
+md_status md_attention_decode_rope(const void* qkv, int64_t ld, void* o, int64_t ldo, const float* freqs,
+                                   void* k_slab, void* v_slab, int64_t slab_batch_stride, int32_t ctx,
+                                   const int32_t* kv_len, int32_t batch, int32_t n_heads, int32_t head_dim,
+                                   int32_t rot_dim, float scale, void* stream);
+
 /* Partial RoPE + KV-cache write (reference: rope.py:20-48, text.py:42-46,
  * moondream.py:74-78).  qkv: bf16 [batch*q_len][ld] rows laid out q|k|v.  The
  * first rot_dim features of every q and k head are read half-split, rotated in

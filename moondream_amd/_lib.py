@@ -101,6 +101,8 @@ SIGNATURES = {
     "md_attention_prefill": (C.c_int, [P(MdAttnArgs), c_void_p]),
     "md_attention_decode": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                       c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "md_attention_decode_rope": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "md_rope_kv_write": (C.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "md_embed_tokens": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),

@@ -312,10 +312,15 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     } else {
       MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s, w.splitk, w.splitk_bytes));
     }
-    MD_TRY(md_rope_kv_write(w.qkv, qld, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
-                            q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
+    const bool fuse_rope = (q_len == 1) && (m->n_kv_heads == m->n_heads);  // decode step: rope + KV write inside attention
+    if (!fuse_rope)
+      MD_TRY(md_rope_kv_write(w.qkv, qld, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
+                              q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
     // attention over the slab                                   (text.py:48-51)
-    if (q_len == 1) {
+    if (fuse_rope) {
+      MD_TRY(md_attention_decode_rope(w.qkv, qld, w.att, Dp, m->freqs, kl, vl, kv->batch_stride, kv->ctx, kv_len,
+                                      batch, m->n_heads, hd, m->rot_dim, scale, s));
+    } else if (q_len == 1) {
       MD_TRY(md_attention_decode(w.qkv, qld, w.att, Dp, kl, vl, kv->batch_stride, kv->ctx, kv_len, batch,
                                  m->n_heads, m->n_kv_heads, hd, scale, s));
     } else {

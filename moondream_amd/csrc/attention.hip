@@ -287,37 +287,71 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
 // Pass 1 streams K (scores -> LDS, running max), pass 2 streams V.
 constexpr int DEC_MAX_CTX = 2048;
 
+// FUSED: q points at the un-rotated fused activation row (q | k | v heads); the kernel
+// applies the partial RoPE to this head's q and k itself (rope.py:20-48), stores the
+// rotated k and v at slot pos = kv_len - 1 of the slab (moondream.py:74-78) and treats
+// that newest key from LDS -- one launch instead of rope_kv_kernel + attention, same
+// arithmetic (bf16-rounded rotated values), MHA only.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                           bf16_t* __restrict__ o, int64_t ldo,
-                                                          const bf16_t* __restrict__ kslab,
-                                                          const bf16_t* __restrict__ vslab,
+                                                          bf16_t* __restrict__ kslab,
+                                                          bf16_t* __restrict__ vslab,
                                                           int64_t slab_bs, int ctx, const int32_t* kv_len_p,
-                                                          int n_heads, int kv_group, float scale_log2) {
+                                                          int n_heads, int kv_group, float scale_log2,
+                                                          const float* __restrict__ freqs, int rot) {
   __shared__ float sc[DEC_MAX_CTX];
   __shared__ float red[4][8][64 + 1];
   __shared__ float red_m[4], red_l[4];
+  __shared__ __attribute__((aligned(16))) bf16_t newrow[3][64];  // FUSED: rotated q, rotated k, v of the new token
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 3, c = lane & 7;
   const int b = blockIdx.y, h = blockIdx.x, hk = h / kv_group;
   const int kv_len = kv_len_p[b];
+  const int pos = kv_len - 1;
+  bf16_t* kb = kslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
+  bf16_t* vb = vslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
+
+  if constexpr (FUSED) {
+    // row layout: [q heads | k heads | v heads], 64 features per head
+    const bf16_t* row = q + (int64_t)b * ldq;
+    const int half = rot >> 1;
+    if (tid < 2 * half) {  // rotated pairs of q (tid < half) and k
+      const int which = tid / half, j = tid % half;
+      const bf16_t* hp = row + (which ? (n_heads + h) : h) * 64;
+      const float re = bf2f(hp[j]), im = bf2f(hp[half + j]);
+      const float cs = freqs[((int64_t)pos * half + j) * 2], sn = freqs[((int64_t)pos * half + j) * 2 + 1];
+      // separately rounded mul, mul, sub / add, as torch evaluates them; interleaved output
+      newrow[which][2 * j] = f2bf(__fsub_rn(__fmul_rn(re, cs), __fmul_rn(im, sn)));
+      newrow[which][2 * j + 1] = f2bf(__fadd_rn(__fmul_rn(re, sn), __fmul_rn(im, cs)));
+    } else if (tid >= 64 && tid < 64 + 2 * (64 - rot)) {  // pass-through features of q and k
+      const int t2 = tid - 64, which = t2 / (64 - rot), i = rot + t2 % (64 - rot);
+      newrow[which][i] = row[(which ? (n_heads + h) : h) * 64 + i];
+    } else if (tid >= 192) {  // v
+      const int i = tid - 192;
+      newrow[2][i] = row[(2 * n_heads + h) * 64 + i];
+    }
+    __syncthreads();
+    if (tid < 64) kb[(int64_t)pos * 64 + tid] = newrow[1][tid];
+    else if (tid < 128) vb[(int64_t)pos * 64 + tid - 64] = newrow[2][tid - 64];
+  }
 
   float qv[8];
   {
-    const u32x4 qq = *(const u32x4*)(q + (int64_t)b * ldq + h * 64 + c * 8);
+    const u32x4 qq = FUSED ? *(const u32x4*)(&newrow[0][c * 8]) : *(const u32x4*)(q + (int64_t)b * ldq + h * 64 + c * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       qv[2 * e] = lo_bf(qq[e]) * scale_log2;
       qv[2 * e + 1] = hi_bf(qq[e]) * scale_log2;
     }
   }
-  const bf16_t* kb = kslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
-  const bf16_t* vb = vslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
 
   // ---- pass 1: scores --------------------------------------------------------
   float mx = -INFINITY;
   for (int j = wave * 8 + g; j < kv_len; j += 32) {
-    const u32x4 kq = *(const u32x4*)(kb + (int64_t)j * 64 + c * 8);
+    // (FUSED: the newest key is not yet visible in global memory to this CU: take it from LDS)
+    const u32x4 kq = (FUSED && j == pos) ? *(const u32x4*)(&newrow[1][c * 8]) : *(const u32x4*)(kb + (int64_t)j * 64 + c * 8);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) s += qv[2 * e] * lo_bf(kq[e]) + qv[2 * e + 1] * hi_bf(kq[e]);
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const float pj = __builtin_amdgcn_exp2f(sc[j] - mx);
     l += pj;
     const float pr = bf2f(f2bf(pj));  // probabilities enter the second contraction as bf16
-    const u32x4 vq = *(const u32x4*)(vb + (int64_t)j * 64 + c * 8);
+    const u32x4 vq = (FUSED && j == pos) ? *(const u32x4*)(&newrow[2][c * 8]) : *(const u32x4*)(vb + (int64_t)j * 64 + c * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[2 * e] += pr * lo_bf(vq[e]);
@@ -408,9 +442,24 @@ extern "C" md_status md_attention_decode(const void* q, int64_t ldq, void* o, in
   MD_CHECK_ARG(q && o && k_slab && v_slab && kv_len);
   MD_CHECK_ARG(head_dim == 64 && ctx <= DEC_MAX_CTX && batch > 0 && n_heads % n_kv_heads == 0);
   MD_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && ldq >= n_heads * 64 && ldo >= n_heads * 64);
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (const bf16_t*)k_slab, (const bf16_t*)v_slab,
+  hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
                      slab_batch_stride, ctx, kv_len, n_heads, n_heads / n_kv_heads,
-                     scale * 1.4426950408889634f);
+                     scale * 1.4426950408889634f, (const float*)nullptr, 0);
+  return md_launch_status();
+}
+
+extern "C" md_status md_attention_decode_rope(const void* qkv, int64_t ld, void* o, int64_t ldo,
+                                              const float* freqs, void* k_slab, void* v_slab,
+                                              int64_t slab_batch_stride, int32_t ctx, const int32_t* kv_len,
+                                              int32_t batch, int32_t n_heads, int32_t head_dim,
+                                              int32_t rot_dim, float scale, void* stream) {
+  MD_CHECK_ARG(qkv && o && freqs && k_slab && v_slab && kv_len);
+  MD_CHECK_ARG(head_dim == 64 && ctx <= DEC_MAX_CTX && batch > 0 && n_heads > 0);
+  MD_CHECK_ARG(rot_dim % 2 == 0 && rot_dim > 0 && rot_dim <= 64 && ld % 8 == 0 && ldo % 8 == 0);
+  MD_CHECK_ARG(ld >= 3 * n_heads * 64 && ldo >= n_heads * 64);
+  hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                     slab_batch_stride, ctx, kv_len, n_heads, 1, scale * 1.4426950408889634f, freqs, rot_dim);
   return md_launch_status();
 }

@@ -302,6 +302,34 @@ def test_attention_decode(lib):
         compare(f"decode attn len{n}", o[bi].view(h, 1, hd), ref, 6e-3, 4e-2)
 
 
+def test_decode_attention_with_fused_rope_equals_two_kernels(lib):
+    """md_attention_decode_rope == md_rope_kv_write + md_attention_decode, bit for bit
+    (outputs and the KV rows written at the new position)."""
+    b, h, hd, ctx, rot = 5, 4, 64, 2048, 32
+    qkv = randn(b, 3 * h * hd + 64, seed=60)  # leading dimension larger than the row
+    ld = qkv.stride(0)
+    freqs = rope_table(rot, ctx).cuda()
+    pos0 = torch.tensor([730, 0, 1, 2047, 915], dtype=torch.int32, device="cuda")
+    lens = pos0 + 1
+    k0, v0 = randn(b, h, ctx, hd, seed=61), randn(b, h, ctx, hd, seed=62)
+    # two kernels
+    qa, ka, va = qkv.clone(), k0.clone(), v0.clone()
+    oa = torch.zeros(b, h * hd, dtype=BF16, device="cuda")
+    _lib.check(lib.md_rope_kv_write(qa.data_ptr(), ld, freqs.data_ptr(), pos0.data_ptr(), ka.data_ptr(), va.data_ptr(),
+                                    h * ctx * hd, ctx, b, 1, h, h, hd, rot, stream()))
+    _lib.check(lib.md_attention_decode(qa.data_ptr(), ld, oa.data_ptr(), h * hd, ka.data_ptr(), va.data_ptr(),
+                                       h * ctx * hd, ctx, lens.data_ptr(), b, h, h, hd, 0.125, stream()))
+    # fused
+    qb, kb, vb = qkv.clone(), k0.clone(), v0.clone()
+    ob = torch.zeros(b, h * hd, dtype=BF16, device="cuda")
+    _lib.check(lib.md_attention_decode_rope(qb.data_ptr(), ld, ob.data_ptr(), h * hd, freqs.data_ptr(), kb.data_ptr(),
+                                            vb.data_ptr(), h * ctx * hd, ctx, lens.data_ptr(), b, h, hd, rot, 0.125, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob)
+    assert torch.equal(ka, kb) and torch.equal(va, vb)
+    assert torch.equal(qb, qkv)  # the fused kernel leaves the activation untouched
+
+
 def test_rope_kv_write(lib):
     from oracle.moondream_oracle import apply_rope, rope_table as o_rope_table
 

@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--no-graphs", action="store_true", help="launch decode steps eagerly instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true", help="run each step's encode and decode back to back on one stream")
+    ap.add_argument("--prompt", choices=["caption", "vqa32"], default="caption",
+                    help="caption: the 5-id caption template; vqa32: 32-id seeded question prompts (SURVEY 8d)")
+    ap.add_argument("--no-vqa-leg", action="store_true", help="skip the auxiliary 32-token-prompt measurement")
     return ap.parse_args()
 
 
@@ -147,14 +150,18 @@ def main():
     n_total = B * world
     mine = mdist.shard_range(n_total, rank, world)
     images = [synth.synthetic_image(i, args.seed) for i in mine]
-    prompt = cfg.tokenizer.templates["caption"]["normal"]
-    prompts = [prompt] * len(images)
+    caption_prompt = cfg.tokenizer.templates["caption"]["normal"]
+    vqa_prompts = [synth.synthetic_vqa_prompt(cfg, i, args.seed) for i in mine]
+    if args.prompt == "caption":
+        prompt, prompts = caption_prompt, [caption_prompt] * len(images)
+    else:
+        prompt, prompts = vqa_prompts[0], vqa_prompts
 
     def finish(ids):
         local_ids = torch.tensor(ids, dtype=torch.int32, device=dev)
         return mdist.gather_token_ids(local_ids)
 
-    def run_steps(k):
+    def run_steps(k, prompts=prompts):
         """k steps = k full passes over this rank's batch.  Pipelined mode overlaps the
         decode of step i with the encode of step i+1 (two HIP streams); every step's
         work, including its gather, completes inside the call."""
@@ -216,8 +223,9 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"Moondream-{args.model.upper()} bf16 batch_generate (caption): {B} images/GPU x 378x378 "
-                        f"(2 crops each, both encoded), 5-token prompt, {T} greedy decode tokens, seeded synthetic weights",
+            "workload": f"Moondream-{args.model.upper()} bf16 batch_generate ({args.prompt}): {B} images/GPU x 378x378 "
+                        f"(2 crops each, both encoded), {len(prompt)}-token prompt, {T} greedy decode tokens, "
+                        f"seeded synthetic weights",
             "batch_per_gpu": B, "decode_tokens": T, "parallelism": f"dp{world}",
             "step_overlap": "none" if args.no_pipeline else "decode(step i) || encode(step i+1) on two HIP streams",
         },
@@ -241,6 +249,15 @@ def main():
         },
         "phase_ms": phase_ms,
     }
+    if args.model == "2b" and phase_ms.get("vision"):
+        # the north star's "ViT encoder vs MFMA roofline": whole vision phase (patchify, 27 blocks incl.
+        # attention and layer norms, projector) against the algorithmic FLOPs of SURVEY 8d
+        vit_flops = len(images) * (2 * FLOP_VIT_PER_CROP + 51.98e9)
+        result["vit_encoder"] = {
+            "bound": "mfma", "achieved": vit_flops / (phase_ms["vision"] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": vit_flops / (phase_ms["vision"] * 1e-3) / 1e12 / 2500.0,
+            "note": "all kernels of the vision phase, 2 crops/image (666.45 GFLOP each) + projector (51.98 GFLOP/image)",
+        }
 
     # p50 single-image caption latency (B=1), outside the timed region
     lat = []
@@ -254,6 +271,28 @@ def main():
             lat.append(time.perf_counter() - t1)
     if lat:
         result["p50_caption_latency_ms"] = float(np.median(lat) * 1e3)
+
+    # auxiliary leg: the same batch with 32-id question prompts (north star "32-token prompts",
+    # BASELINE configs[1] single-image VQA latency); outside the timed region of `value`
+    if world == 1 and not args.no_vqa_leg and args.prompt == "caption":
+        run_steps(2, vqa_prompts)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(2, vqa_prompts)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 2
+        lat = []
+        for i in range(args.latency_runs + 1):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model.batch_generate_ids(one, [vqa_prompts[0]], max_tokens=T, ignore_eos=True)
+            torch.cuda.synchronize()
+            if i > 0:
+                lat.append(time.perf_counter() - t1)
+        result["vqa32"] = {
+            "images_per_sec": B / dt, "ms_per_step": dt * 1e3, "prompt_tokens": len(vqa_prompts[0]),
+            "p50_latency_ms": float(np.median(lat) * 1e3) if lat else None,
+        }
 
     if world == 1 and not args.no_cpu_baseline:
         est, cores, note = cpu_baseline(cfg, sd, args.seed, T)

@@ -55,6 +55,7 @@ struct GemmK {
   int res_row_mod;
   int group_m;  // tile-order grouping (row panels per group)
   int gelu_from;  // EPI_GELU: columns >= gelu_from get the GELU
+  int prio;       // experiment: raise the wave priority around MFMA groups
   // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
   int slices;
   float* slabs;
@@ -92,7 +93,7 @@ __device__ __forceinline__ void wait_vm() {
 // whose per-slice compute is far shorter than the DMA latency.
 // BKT = K elements per slice (64: 128-byte rows, 8 chunks; 32: 64-byte rows, 4 chunks,
 // which lets the 256x256 tile keep three 32 KiB slices in flight in a 4-deep ring).
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, bool PP = false>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   constexpr int ROW_BYTES = BKT * 2;
   constexpr int CH = BKT / 8;                 // 16-byte chunks per row
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) b_src[j] += (int64_t)t0 * ROW_BYTES;
   }
-  if constexpr (PP) {
+  if constexpr (PP == 1) {
     // ---- ping-pong schedule -------------------------------------------------
     // 32-wide slices, one slice = one PHASE (barrier + 2 K-steps).  The second half
     // of the waves (one per SIMD, like the first half) runs ONE PHASE BEHIND the
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       auto mfma_step = [&](auto set_c, auto step_c) {
         constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
         constexpr int PPS = (PIECES + KSTEPS - 1) / KSTEPS;
+        if (p.prio) __builtin_amdgcn_s_setprio(1);
         static_for<0, MI * NI>([&](auto mc) {
           constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
           acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
             }
           });
         });
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
       };
       if (sl >= 0 && sl < nk) {
         const uint32_t st = lds_base + (sl % STAGES) * STAGE;
@@ -270,6 +273,83 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
         static_for<0, PIECES>([&](auto pc) { issue_piece(pc, nstage); });
       }
     }
+  } else if constexpr (PP == 2) {
+    // ---- alternating wave groups (cdna guide 5: "8-phase" discipline) ----------
+    // 32-wide slices, two PHASES per slice (the wave's upper / lower 64 rows), eight
+    // MFMAs (256 matrix-pipe cycles) per phase on four independent accumulators.
+    // Every phase is   { ds_reads + 2 LDS-DMA pieces } barrier { MFMAs } barrier   and
+    // the second wave group (one wave per SIMD, like the first) runs ONE BARRIER
+    // behind: while one wave of a SIMD owns the matrix pipe (raised priority), the
+    // other fetches its next fragments and feeds the DMA ring, and the barriers
+    // enforce the alternation.  Nothing is software-pipelined inside a wave: the
+    // other group's MFMA phase is what hides the LDS latency.
+    //   slice u is read in phases (u,0) [B: 4 reads, A rows 0-63: 4 reads] and (u,1)
+    //   [A rows 64-127: 4 reads]; its ring slot is refilled with slice u+STAGES from
+    //   phase (u+2,0) on, i.e. >= 3 phases after its last read by either group.
+    //   The DMA of slice v is waited for (counted vmcnt, then the phase's first
+    //   barrier) in phase (v-1,1) and first read in phase (v,0), one phase later.
+    static_assert(KSTEPS == 2 && STAGES >= 4 && !SPLITK && MI == 4 && NI == 2, "alternating config");
+    constexpr int PIECES = NA + NB;  // 4 per thread and slice
+    static_assert(PIECES == 4, "two LDS-DMA pieces per phase");
+    constexpr int AHEAD = STAGES - 2;  // slices in flight ahead of the one being computed
+    static_assert((AHEAD - 1) * PIECES < 64, "vmcnt is a 6-bit counter");
+    const int lag = (wave >= (WM * WN) / 2) ? 1 : 0;  // SGPR: uniform per wave
+    static_for<0, AHEAD>([&](auto sc) {
+      constexpr int SL0 = decltype(sc)::value;
+      if (SL0 < nk) static_for<0, PIECES>([&](auto pc) { issue_piece(pc, SL0); });
+    });
+    if (nk >= AHEAD) wait_vm<(AHEAD - 1) * PIECES>(); else wait_vm<0>();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // slice 0 visible to everybody
+    if (lag) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 af[2][2], bfr[2][NI];
+    for (int u = 0; u < nk; ++u) {
+      const uint32_t st = lds_base + (u % STAGES) * STAGE;
+      const int v = u + AHEAD;              // slice whose DMA is issued during slice u
+      const bool has_next = v < nk;
+      const int nstage = v % STAGES;
+      static_for<0, 2>([&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        // fragments: K-step s -> 16-byte chunk (2s + hi) of the row, swizzled
+        static_for<0, 2>([&](auto sc) {
+          constexpr int S = decltype(sc)::value;
+          const uint32_t coff = (uint32_t)(((2 * S + hi) ^ swz) * 16);
+          if constexpr (H == 0)
+            static_for<0, NI>([&](auto j) { ds_read_b128<decltype(j)::value * 32 * ROW_BYTES>(bfr[S][decltype(j)::value], st + b_row_off + coff); });
+          static_for<0, 2>([&](auto i) { ds_read_b128<(2 * H + decltype(i)::value) * 32 * ROW_BYTES>(af[S][decltype(i)::value], st + a_row_off + coff); });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+          issue_piece(std::integral_constant<int, 2 * H>{}, nstage);
+          issue_piece(std::integral_constant<int, 2 * H + 1>{}, nstage);
+        }
+        if constexpr (H == 1) {
+          // slice u+1 (first read in the next phase) has landed; the AHEAD-1 younger slices stay in flight
+          if (has_next) wait_vm<(AHEAD - 1) * PIECES>(); else wait_vm<0>();
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        wait_lgkm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        static_for<0, 2>([&](auto sc) {
+          constexpr int S = decltype(sc)::value;
+          static_for<0, 2>([&](auto i) {
+            static_for<0, NI>([&](auto j) {
+              constexpr int I = 2 * H + decltype(i)::value, J = decltype(j)::value;
+              acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[S][J], af[S][decltype(i)::value], acc[I][J], 0, 0, 0);
+            });
+          });
+        });
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      });
+    }
+    if (!lag) __builtin_amdgcn_s_barrier();  // the leading group owes the barrier the lagging one took first
   } else {
     static_assert((STAGES - 2) * (NA + NB) < 64, "vmcnt is a 6-bit counter");
     // prologue: slices 0 .. STAGES-2 in flight
@@ -329,6 +409,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
         // under the 32-cycle-per-MFMA matrix pipe instead of idling it at the head
         // of the slice.  Piece p goes to step p % KSTEPS, slot p / KSTEPS.
         constexpr int PPS = (NA + NB + KSTEPS - 1) / KSTEPS;  // pieces per K-step
+        if (p.prio) __builtin_amdgcn_s_setprio(1);
         static_for<0, MI * NI>([&](auto mc) {
           constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
           acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
@@ -342,6 +423,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
             }
           });
         });
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -459,7 +541,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
           if (n >= p.gelu_from) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = pack_bf16x2(gelu_tanh_f32(lo_bf(v[e])), gelu_tanh_f32(hi_bf(v[e])));
+            {
+              const md_f32x2 g = gelu_tanh_f32x2(md_f32x2{lo_bf(v[e]), hi_bf(v[e])});
+              v[e] = pack_bf16x2(g[0], g[1]);
+            }
           }
         } else if constexpr (EPI == MD_EPI_RESIDUAL) {
           u32x4 rv;
@@ -479,7 +564,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, bool PP = false>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
 md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int ring = STAGES * (BM + BN) * BKT * 2;
@@ -523,8 +608,10 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     // split-K, the N = 2048 layers get 16 KiB slabs
     case 10: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4>(k, stream)
                                  : launch_cfg<64, 64, 2, 1, EPI, false, 4>(k, stream);
-    case 8: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, true>(k, stream);  // ping-pong wave groups
-    case 9: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, true>(k, stream);  // same, 5-deep ring
+    case 8: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 1>(k, stream);  // ping-pong wave groups
+    case 9: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 1>(k, stream);  // same, 5-deep ring
+    case 11: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 2>(k, stream);  // alternating wave groups, 2 slices ahead
+    case 12: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 2>(k, stream);  // same, 3 slices ahead (160 KiB LDS)
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }
@@ -581,6 +668,12 @@ int pick_tile(int M, int n_store) {
       best = c;
     }
   }
+  if (best == 0) {
+    // 256x256: the alternating-wave-group schedule (config 11) measured +5..13 % over the
+    // lockstep one on the model's shapes (profiles/r01_gemm_alternating_sweep.txt)
+    const char* alt = getenv("MD_GEMM_ALT");
+    if (!(alt && alt[0] == '0')) best = 11;
+  }
   return best;
 }
 
@@ -615,6 +708,8 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.group_m = 8;
   k.gelu_from = a->gelu_from_col;
   if (const char* e = getenv("MD_GEMM_GROUP_M")) k.group_m = std::max(1, atoi(e));  // experiments
+  k.prio = 0;
+  if (const char* e = getenv("MD_GEMM_PRIO")) k.prio = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   int tile = pick_tile(k.M, k.n_store);
   k.slices = 1;

@@ -62,7 +62,7 @@ def pad_k(a, k_pad):
     return out
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12"])
 def test_gemm_identity_detects_transposes(lib, tile, monkeypatch):
     """A = I with an ASYMMETRIC W: C must equal W^T bit for bit."""
     monkeypatch.setenv("MD_GEMM_TILE", tile)
@@ -74,7 +74,7 @@ def test_gemm_identity_detects_transposes(lib, tile, monkeypatch):
     assert torch.equal(c, w.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12"])
 @pytest.mark.parametrize("m,k,n", [(300, 588, 1152), (777, 1152, 3456), (1000, 2048, 6144), (64, 2048, 1024), (1, 256, 64)])
 def test_gemm_bias(lib, tile, m, k, n, monkeypatch):
     monkeypatch.setenv("MD_GEMM_TILE", tile)
@@ -82,6 +82,22 @@ def test_gemm_bias(lib, tile, m, k, n, monkeypatch):
     lin = PackedLinear(w, b, "cuda")
     c = gemm(lib, pad_k(a, lin.k_pad), lin)
     compare(f"gemm_bias {m}x{k}x{n} tile{tile}", c, ref_linear(a, w, b), 3e-3, 2e-2)
+
+
+def test_gemm_tile_configs_agree_bitwise(lib, monkeypatch):
+    """Every tile config accumulates K in the same order, so a layer's output does not
+    depend on which one the heuristic picks; repeated launches double as a race screen
+    for the hand-synchronised operand rings."""
+    m, k, n = 2100, 4096, 2304
+    a, w, b = randn(m, k, seed=11), randn(n, k, scale=1 / math.sqrt(k), seed=12), randn(n, scale=0.1, seed=13)
+    lin = PackedLinear(w, b, "cuda")
+    monkeypatch.setenv("MD_GEMM_TILE", "2")
+    want = gemm(lib, a, lin)
+    for tile in ("0", "1", "4", "5", "8", "11", "12"):
+        monkeypatch.setenv("MD_GEMM_TILE", tile)
+        for rep in range(6):
+            got = gemm(lib, a, lin)
+            assert torch.equal(got, want), f"tile {tile} rep {rep}"
 
 
 def test_gemm_gelu_writes_zero_pad_columns(lib):

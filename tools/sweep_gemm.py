@@ -6,10 +6,13 @@ from moondream_amd import _lib
 from moondream_amd.weights import PackedLinear
 from tools.kernel_bench import timeit, stream
 lib = _lib.load(); BF16 = torch.bfloat16
+ZERO = False
 def run(m,k,n,epi,env):
     a = (torch.randn(m, (k+63)//64*64, device="cuda")*0.5).to(BF16); 
+    if ZERO: a.zero_()
     if a.shape[1]>k: a[:,k:]=0
     w = (torch.randn(n,k,device="cuda")/math.sqrt(k)).to(BF16)
+    if ZERO: w.zero_()
     lin = PackedLinear(w, torch.zeros(n,dtype=BF16), "cuda")
     c = torch.empty(m, lin.n_pad, dtype=BF16, device="cuda"); r = torch.randn(m, lin.n_pad, device="cuda").to(BF16)
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), lin.struct(), c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, None, 0)
@@ -17,8 +20,17 @@ def run(m,k,n,epi,env):
     dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())))
     for kk in env: os.environ.pop(kk)
     return 2.0*m*n*k/dt/1e12
-shapes=[(23328,588,1152,2),(23328,1152,4304,1),(23328,1152,3456,0),(23328,1152,1152,2),(23328,4304,1152,2),(46720,2048,6144,0),(46720,2048,2048,2),(8192,8192,8192,0)]
-for (m,k,n,epi) in shapes:
-    out=[]
-    r={t:run(m,k,n,epi,{'MD_GEMM_TILE':t}) for t in ('0','5','8','9')}
-    print(f"m={m} k={k} n={n}: 256x256 bk64x2 {r['0']:6.0f} | bk32x4 lockstep {r['5']:6.0f} | PING-PONG bk32x4 {r['8']:6.0f} | PING-PONG bk32x5 {r['9']:6.0f}", flush=True)
+shapes=[(23328,1152,4304,1),(23328,1152,3456,0),(23328,4304,1152,2),(46720,2048,14336,1),(46720,2048,2048,2),(46720,8192,2048,2),(4096,4096,4096,0),(8192,8192,8192,0)]
+def line(m,k,n,epi):
+    r={t:run(m,k,n,epi,{'MD_GEMM_TILE':t,'MD_GEMM_PRIO':pr}) for t,pr in (('0','0'),('0','1'),('11','0'),('12','0'))}
+    return f"m={m} k={k} n={n}: 256x256 bk64x2 {r['0']:6.0f} | ALTERNATING bk32x4 {r['11']:6.0f} | ALTERNATING bk32x5 {r['12']:6.0f}"
+def run2(m,k,n,epi):
+    r={}
+    for key,t,pr in (('base','0','0'),('prio','0','1'),('alt4','11','0'),('alt5','12','0')):
+        r[key]=run(m,k,n,epi,{'MD_GEMM_TILE':t,'MD_GEMM_PRIO':pr})
+    return f"m={m} k={k} n={n}: 256x256 bk64x2 {r['base']:6.0f} (setprio {r['prio']:6.0f}) | ALTERNATING bk32x4 {r['alt4']:6.0f} | bk32x5 {r['alt5']:6.0f}"
+for sh in shapes:
+    print(run2(*sh), flush=True)
+ZERO = True
+for sh in [(4096,4096,4096,0),(8192,8192,8192,0)]:
+    print("ZERO-FILLED "+run2(*sh)+"  (guide 8-phase template: 1563@4k / 1728@8k zero-filled, ~1330 / ~1470 random)", flush=True)

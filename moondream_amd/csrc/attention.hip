@@ -25,6 +25,7 @@
 //   contraction (5 K-steps), 96 (3 x 32 rows of V^T) for PV; HBM layouts stay
 //   dense.
 #include "md_common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -280,6 +281,234 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
 }
 
 // ---------------------------------------------------------------------------
+// prefill, LDS-DMA staged (default): same math and fragment layouts as
+// attn_prefill_kernel above, different plumbing --
+//   * K and V tiles go global -> LDS by LDS-DMA (no staging registers, no VALU), both
+//     ROW-major, double buffered: one barrier per 64-key tile, the DMA of tile t+1
+//     runs under the MFMA/softmax work of tile t;
+//   * the V^T operand of O^T += V^T P^T is gathered with ds_read_b64_tr_b16 (the
+//     hardware 4x4 transpose read: in every 16-lane group, lane i points at 4
+//     consecutive features of key (i >> 2) and receives 4 consecutive keys of feature
+//     (i & 15)), so V is never transposed by ALU and never written with 4-byte stores.
+//   LDS image of a tile: K rows of 176 B (head_dim 72: 9 data + 2 pad chunks) / 144 B
+//   (head_dim 64) -- 16-byte slots rotate by 11 / 9 per row, b128 fragment reads are
+//   conflict-free; V rows of 192 B (12 chunks) -- four consecutive keys x 64 B cover
+//   the 256-byte bank row exactly once for the transpose read.  Pad chunks replay chunk
+//   0 of their row (finite data): K pads only ever meet the zero pad of the Q
+//   fragments, V pads only feed output rows >= head_dim, which are never stored.
+// ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int HD>
+struct CfgD {
+  static constexpr int HDP = (HD + 15) / 16 * 16;
+  static constexpr int KSTEPS = HDP / 16;
+  static constexpr int ND = (HD + 31) / 32;
+  static constexpr int CPR = HD / 8;                     // data chunks per global row
+  static constexpr int KCH = CPR + (HD == 72 ? 2 : 1);   // 11 / 9 chunks per LDS row of K
+  static constexpr int KROW = KCH * 16;
+  static constexpr int VCH = 12, VROW = VCH * 16;
+  static constexpr int K_BYTES = 64 * KROW;
+  static constexpr int V_BYTES = 64 * VROW;
+  static constexpr int BUF = K_BYTES + V_BYTES;
+  static constexpr int K_LAST_WAVES = (64 * KCH - 512) / 64;  // waves that own a third K piece
+  static constexpr int OSTR = HDP + 8;
+  static constexpr int O_BYTES = 4 * 32 * OSTR * 2;
+  static constexpr int LDS = (2 * BUF) > O_BYTES ? (2 * BUF) : O_BYTES;
+  static_assert((64 * KCH - 512) % 64 == 0 && K_LAST_WAVES >= 1 && K_LAST_WAVES <= 4, "K piece split");
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
+  using C = CfgD<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y, hk = h / p.kv_group;
+  const int q_pos0 = p.q_pos0 ? p.q_pos0[b] : 0;
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.kv_len_all;
+
+  const int q_blk0 = blockIdx.x * 128;
+  const int q_row0 = q_blk0 + wave * 32;
+  const int q_row = min(q_row0 + l31, p.q_len - 1);
+  const int qpos = q_pos0 + q_row;
+  const int blk_qpos_hi = q_pos0 + min(q_blk0 + 127, p.q_len - 1);
+  const int blk_vis = (blk_qpos_hi < p.prefix) ? max(blk_qpos_hi + 1, p.prefix) : blk_qpos_hi + 1;
+  const int kv_end = min(kv_len, blk_vis);
+  const int w_qpos_lo = q_pos0 + min(q_row0, p.q_len - 1);
+  const int w_qpos_hi = q_pos0 + min(q_row0 + 31, p.q_len - 1);
+
+  bf16x8 qf[C::KSTEPS];
+  {
+    const bf16_t* qrow = p.q + (int64_t)b * p.q_bs + (int64_t)q_row * p.q_ts + (int64_t)h * p.q_hs;
+#pragma unroll
+    for (int s = 0; s < C::KSTEPS; ++s) {
+      const int col = 16 * s + 8 * hi;
+      bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[s] = (col < HD) ? *(const bf16x8*)(qrow + col) : z;
+    }
+  }
+
+  f32x16 oacc[C::ND];
+#pragma unroll
+  for (int d = 0; d < C::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const bf16_t* kbase = p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const bf16_t* vbase = p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
+
+  // LDS-DMA pieces: chunk c = 256 j + tid of the tile image, lane-linear in LDS
+  int krow[3], kcol[3], vrow[3], vcol[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = 256 * j + tid;
+    const int kc = c % C::KCH, vc = c % C::VCH;
+    krow[j] = min(c / C::KCH, 63);
+    kcol[j] = (kc < C::CPR ? kc : 0) * 8;
+    vrow[j] = c / C::VCH;
+    vcol[j] = (vc < C::CPR ? vc : 0) * 8;
+  }
+  auto issue_tile = [&](int kv0, int buf) {
+    char* kb = smem + buf * C::BUF;
+    char* vb = kb + C::K_BYTES;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j < 2 || wave < C::K_LAST_WAVES) {
+        // rows past kv_len replay the last valid row: their scores are masked to -inf, P is exactly 0
+        const int r = min(kv0 + krow[j], kv_len - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (int64_t)r * p.k_ts + kcol[j]),
+                                         (__attribute__((address_space(3))) void*)(kb + (256 * j + 64 * wave) * 16), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int r = min(kv0 + vrow[j], kv_len - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (int64_t)r * p.v_ts + vcol[j]),
+                                       (__attribute__((address_space(3))) void*)(vb + (256 * j + 64 * wave) * 16), 16, 0, 0);
+    }
+  };
+
+  // per-lane offsets of the fragment reads
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int k_lane = l31 * C::KROW + hi * 16;
+  const int v_lane = (4 * hi + (i16 >> 2)) * C::VROW + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+
+  if (kv_end > 0) issue_tile(0, 0);
+  int buf = 0;
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 64, buf ^= 1) {
+    __syncthreads();  // own DMA of tile kv0 landed (vmcnt 0), everybody's visible, tile kv0-64 is no longer read
+    if (kv0 + 64 < kv_end) issue_tile(kv0 + 64, buf ^ 1);
+    const char* Ks = smem + buf * C::BUF;
+    const char* Vs = Ks + C::K_BYTES;
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C::KSTEPS; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + k_lane + 32 * sub * C::KROW + 32 * s);
+        sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[sub], 0, 0, 0);
+      }
+    }
+
+    const bool full_vis = (kv0 + 63 <= w_qpos_lo) || (w_qpos_hi < p.prefix && kv0 + 64 <= p.prefix);
+    const bool need_mask = !(full_vis && kv0 + 64 <= kv_len);
+    float mx = -INFINITY;
+    if (need_mask) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kv0 + 32 * sub + 8 * (r >> 2) + 4 * hi + (r & 3);
+          const bool ok = (j < kv_len) && (j <= qpos || (qpos < p.prefix && j < p.prefix));
+          sacc[sub][r] = ok ? sacc[sub][r] : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    constexpr float RESCALE_THR = 6.0f;  // deferred rescale, see attn_prefill_kernel
+    if (__any((mx - m_run) * p.scale_log2 > RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    const float mc = (m_run == -INFINITY) ? 0.f : -m_run * p.scale_log2;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[sub][8 * u + 2 * e], p.scale_log2, mc));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[sub][8 * u + 2 * e + 1], p.scale_log2, mc));
+          psum += p0 + p1;
+          w[e] = pack_bf16x2(p0, p1);
+        }
+        pf[sub][u] = __builtin_bit_cast(bf16x8, w);
+      }
+    l_run += psum;
+
+    // O^T += V^T P^T: MFMA K-slot (hi, j) <-> key 16u + 4hi + (j & 3) + 8 (j >> 2), so the two
+    // transpose reads of a fragment start at keys 16u + 4hi and 16u + 8 + 4hi
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int d = 0; d < C::ND; ++d) {
+          const char* va = Vs + v_lane + (32 * sub + 16 * u) * C::VROW + 64 * d;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)va);
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * C::VROW));
+          const bf16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pf[sub][u], oacc[d], 0, 0, 0);
+        }
+      }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  __syncthreads();
+  char* ot = smem + wave * 32 * C::OSTR * 2;
+#pragma unroll
+  for (int d = 0; d < C::ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 32 * d + 8 * g + 4 * hi;
+      if (col < HD) {
+        u32x2 w;
+        w[0] = pack_bf16x2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+        w[1] = pack_bf16x2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+        *(u32x2*)(ot + l31 * C::OSTR * 2 + col * 2) = w;
+      }
+    }
+  bf16_t* obase = p.o + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs;
+  for (int idx = lane; idx < 32 * C::CPR; idx += 64) {
+    const int row = idx / C::CPR, ch = idx % C::CPR;
+    if (q_row0 + row < p.q_len) {
+      const u32x4 v = *(const u32x4*)(ot + row * C::OSTR * 2 + ch * 16);
+      *(u32x4*)(obase + (int64_t)(q_row0 + row) * p.o_ts + ch * 8) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // decode: one query row per (sequence, head)
 // ---------------------------------------------------------------------------
 // 8 lanes cover one 128-byte key/value row (8 x 16 B); a wave covers 8 rows per
@@ -427,10 +656,18 @@ extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
   k.scale_log2 = a->scale * 1.4426950408889634f;
   dim3 grid((a->q_len + 127) / 128, a->n_heads, a->batch);
   hipStream_t s = (hipStream_t)stream;
-  if (a->head_dim == 72)
-    hipLaunchKernelGGL(attn_prefill_kernel<72>, grid, dim3(256), 0, s, k);
-  else
-    hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, s, k);
+  static const bool reg_staged = [] { const char* e = getenv("MD_ATTN_REG_STAGED"); return e && e[0] == '1'; }();  // A/B runs
+  if (reg_staged) {
+    if (a->head_dim == 72)
+      hipLaunchKernelGGL(attn_prefill_kernel<72>, grid, dim3(256), 0, s, k);
+    else
+      hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, s, k);
+  } else {
+    if (a->head_dim == 72)
+      hipLaunchKernelGGL(attn_prefill_dma_kernel<72>, grid, dim3(256), 0, s, k);
+    else
+      hipLaunchKernelGGL(attn_prefill_dma_kernel<64>, grid, dim3(256), 0, s, k);
+  }
   return md_launch_status();
 }
 

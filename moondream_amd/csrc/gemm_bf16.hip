@@ -56,6 +56,7 @@ struct GemmK {
   int group_m;  // tile-order grouping (row panels per group)
   int gelu_from;  // EPI_GELU: columns >= gelu_from get the GELU
   int prio;       // experiment: raise the wave priority around MFMA groups
+  int nt;         // decode regime: stream the weights with the non-temporal policy
   // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
   int slices;
   float* slabs;
@@ -154,8 +155,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       a_src[P] += ROW_BYTES;
     } else {
       constexpr int Q = P - NA;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[Q],
-                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + Q * NT * 16), 16, 0, 0);
+      if (BM == 64 && p.nt) {  // decode regime: every weight byte is read once by one CU
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[Q],
+                                         (__attribute__((address_space(3))) void*)(base + A_BYTES + Q * NT * 16), 16, 0, 2);
+      } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[Q],
+                                         (__attribute__((address_space(3))) void*)(base + A_BYTES + Q * NT * 16), 16, 0, 0);
+      }
       b_src[Q] += ROW_BYTES;
     }
   };
@@ -608,6 +614,12 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     // split-K, the N = 2048 layers get 16 KiB slabs
     case 10: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4>(k, stream)
                                  : launch_cfg<64, 64, 2, 1, EPI, false, 4>(k, stream);
+    // same tiles, deeper rings: a workgroup's stream is latency-bound (slices in flight x 16 KiB
+    // per ~1.3 us round trip), so 7 / 8 slices in flight instead of 3
+    case 13: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 8>(k, stream)
+                                 : launch_cfg<64, 64, 2, 1, EPI, false, 8>(k, stream);
+    case 14: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 9>(k, stream)
+                                 : launch_cfg<64, 64, 2, 1, EPI, false, 9>(k, stream);
     case 8: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 1>(k, stream);  // ping-pong wave groups
     case 9: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 1>(k, stream);  // same, 5-deep ring
     case 11: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 2>(k, stream);  // alternating wave groups, 2 slices ahead
@@ -627,10 +639,13 @@ int decode_cfg() {
   const char* dc = getenv("MD_DECODE_CFG");
   if (dc && dc[0] == 'd') return 3;
   if (dc && dc[0] == 'c') return 7;
+  if (dc && dc[0] == 'e') return 13;
+  if (dc && dc[0] == 'f') return 14;
   return 10;
 }
-int decode_bn() { return decode_cfg() == 10 ? 64 : 128; }
-int decode_slab_floats() { return decode_cfg() == 10 ? 128 * 1 * 2 * 16 : 128 * 2 * 2 * 16; }  // NT * MI * NI * 16
+bool decode_is64(int cfg) { return cfg == 10 || cfg == 13 || cfg == 14; }
+int decode_bn() { return decode_is64(decode_cfg()) ? 64 : 128; }
+int decode_slab_floats() { return decode_is64(decode_cfg()) ? 128 * 1 * 2 * 16 : 128 * 2 * 2 * 16; }  // NT * MI * NI * 16
 
 int decode_slices(int n_store, int k_pad) {
   const int DEC_BN = decode_bn();
@@ -641,28 +656,31 @@ int decode_slices(int n_store, int k_pad) {
   }
   // measured model (profiles/r01_decode_gemm_sweep.txt): one workgroup saturates its
   // CU's load path (~40 GB/s), the last arriver pays ~1 us per 32 KiB slab, so
-  // t ~ 2 us + bytes / (tiles * S * 40 GB/s) + S * 1 us: aim for >= 128 workgroups, S <= 8
+  // t ~ 2 us + bytes / (tiles * S * 40 GB/s) + S * 1 us: aim for ~256 workgroups, S <= 8
+  // (profiles/r01_decode_gemm_sweep_deep_ring_nt.txt: deeper rings do not help, the per-CU
+  // LDS-DMA rate is the limit, so the lever is the number of CUs pulling)
   int s = 1;
-  while (s < 8 && tiles * s < 128 && s * 2 <= nk / 2) s *= 2;
+  while (s < 8 && tiles * s < 192 && s * 2 <= nk / 2) s *= 2;
   return s;
 }
 
-// Tile choice: estimated time ~ (waves of workgroups over 256 CUs) x tile area /
-// per-config efficiency.  Independent of anything but (M, N), so a given layer
-// always runs the same kernel -- and every config accumulates K in the same
-// order (sequential 16-wide MFMA steps), so results do not depend on it.
+// Tile choice: every CU works through ceil(tiles / 256) tiles, a tile costs its area
+// over the config's measured efficiency (256x256 alternating schedule = 1; 256x128
+// ~0.78; 128x128 ~0.62 -- profiles/r01_gemm_alternating_sweep*.txt).  A function of
+// (M, N) only, so a given layer always runs the same kernel -- and every config
+// accumulates K in the same order (sequential 16-wide MFMA steps), so results do
+// not depend on it.
 int pick_tile(int M, int n_store) {
   const char* e = getenv("MD_GEMM_TILE");  // experiments / tests: force a tile config
   if (e && *e) return atoi(e);
   const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 128};
-  const double eff[3] = {1.0, 0.85, 0.7};
-  const int slots[3] = {256, 256, 512};
+  const double eff[3] = {1.0, 0.78, 0.62};
   int best = 2;
   double best_cost = 1e300;
   for (int c = 0; c < 3; ++c) {
     const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((n_store + bn[c] - 1) / bn[c]);
-    const long rounds = (tiles + slots[c] - 1) / slots[c];
-    const double cost = (double)rounds * slots[c] * bm[c] * bn[c] / eff[c];
+    const long per_cu = (tiles + 255) / 256;
+    const double cost = (double)per_cu * bm[c] * bn[c] / eff[c];
     if (cost < best_cost) {
       best_cost = cost;
       best = c;
@@ -710,6 +728,8 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   if (const char* e = getenv("MD_GEMM_GROUP_M")) k.group_m = std::max(1, atoi(e));  // experiments
   k.prio = 0;
   if (const char* e = getenv("MD_GEMM_PRIO")) k.prio = atoi(e);
+  k.nt = 1;  // decode regime: non-temporal weight stream (+2..10 % measured); MD_DECODE_NT=0 for A/B runs
+  if (const char* e = getenv("MD_DECODE_NT")) k.nt = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   int tile = pick_tile(k.M, k.n_store);
   k.slices = 1;

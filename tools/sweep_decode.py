@@ -18,9 +18,14 @@ for (m, k, n, epi) in [(64, 2048, 14336, 1), (64, 2048, 6144, 0), (64, 2048, 204
     ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, ws.data_ptr(), ws.numel())
     out = []
-    for s in (1, 2, 4, 8, 16, 32):
-        os.environ["MD_DECODE_SLICES"] = str(s)
-        dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=20)
-        out.append(f"S={s}: {dt*1e6:6.1f}us")
-    os.environ.pop("MD_DECODE_SLICES")
-    print(f"m={m} k={k} n={n}: " + "  ".join(out) + f"   (ideal {2*n*k/6e12*1e6:.1f}us @6TB/s)", flush=True)
+    for cfg, nt in (("64", "0"), ("64", "1"), ("e", "0"), ("e", "1"), ("f", "1")):
+        os.environ["MD_DECODE_CFG"] = cfg; os.environ["MD_DECODE_NT"] = nt
+        best = None
+        for sl in (1, 2, 4, 8):
+            os.environ["MD_DECODE_SLICES"] = str(sl)
+            dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=20)
+            if best is None or dt < best[0]: best = (dt, sl)
+        os.environ.pop("MD_DECODE_SLICES")
+        dflt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=20)
+        out.append(f"cfg={cfg}{'+nt' if nt=='1' else ''}: default {dflt*1e6:5.1f}us best {best[0]*1e6:5.1f}us@S={best[1]}")
+    print(f"m={m} k={k} n={n}: " + " | ".join(out) + f"   (ideal {2*n*k/6e12*1e6:.1f}us @6TB/s)", flush=True)

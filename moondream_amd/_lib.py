@@ -146,7 +146,11 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
             return LIB_PATH
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs.  Every kernel here fits
+    # in <= 256 registers per wave, and the softmax / epilogue code works on the accumulators with
+    # VALU instructions, so the default AGPR placement only adds v_accvgpr_read/write traffic
+    # (prefill attention: ~190 moves per 64-key tile, and 216 -> 158 registers).
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form"]
     procs = []
     objs = []
     for s in srcs:

@@ -361,8 +361,12 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   const bf16_t* kbase = p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
   const bf16_t* vbase = p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
 
-  // LDS-DMA pieces: chunk c = 256 j + tid of the tile image, lane-linear in LDS
+  // LDS-DMA pieces: chunk c = 256 j + tid of the tile image, lane-linear in LDS.  The source
+  // pointers run ahead one tile per issue; only a tile that reaches past kv_len (the last one)
+  // takes the clamped path.
   int krow[3], kcol[3], vrow[3], vcol[3];
+  const bf16_t* ksrc[3];
+  const bf16_t* vsrc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int c = 256 * j + tid;
@@ -371,24 +375,29 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     kcol[j] = (kc < C::CPR ? kc : 0) * 8;
     vrow[j] = c / C::VCH;
     vcol[j] = (vc < C::CPR ? vc : 0) * 8;
+    ksrc[j] = kbase + (int64_t)krow[j] * p.k_ts + kcol[j];
+    vsrc[j] = vbase + (int64_t)vrow[j] * p.v_ts + vcol[j];
   }
+  const int64_t k_step = 64 * p.k_ts, v_step = 64 * p.v_ts;
   auto issue_tile = [&](int kv0, int buf) {
     char* kb = smem + buf * C::BUF;
     char* vb = kb + C::K_BYTES;
+    const bool whole = kv0 + 64 <= kv_len;  // wave-uniform
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      if (j < 2 || wave < C::K_LAST_WAVES) {
-        // rows past kv_len replay the last valid row: their scores are masked to -inf, P is exactly 0
-        const int r = min(kv0 + krow[j], kv_len - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (int64_t)r * p.k_ts + kcol[j]),
+      // rows past kv_len replay the last valid row: their scores are masked to -inf, P is exactly 0
+      const bf16_t* src = whole ? ksrc[j] : kbase + (int64_t)min(kv0 + krow[j], kv_len - 1) * p.k_ts + kcol[j];
+      if (j < 2 || wave < C::K_LAST_WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(kb + (256 * j + 64 * wave) * 16), 16, 0, 0);
-      }
+      ksrc[j] += k_step;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int r = min(kv0 + vrow[j], kv_len - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (int64_t)r * p.v_ts + vcol[j]),
+      const bf16_t* src = whole ? vsrc[j] : vbase + (int64_t)min(kv0 + vrow[j], kv_len - 1) * p.v_ts + vcol[j];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(vb + (256 * j + 64 * wave) * 16), 16, 0, 0);
+      vsrc[j] += v_step;
     }
   };
 

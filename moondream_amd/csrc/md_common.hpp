@@ -25,8 +25,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(uint16_t, b);
 }
 
+// two roundings in ONE v_cvt_pk_bf16_f32 (converting the halves separately costs
+// two conversions plus a shift and an or per pair)
+typedef __bf16 md_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float md_f32pair __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const md_f32pair v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, md_bf16x2));
 }
 
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }

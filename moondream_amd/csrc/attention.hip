@@ -39,6 +39,7 @@ struct AttnK {
   const int32_t* q_pos0;
   const int32_t* kv_len;
   float scale_log2;  // scale * log2(e)
+  int n_qblk, n_bh, n_heads;  // XCD-aware 1-D grid of the LDS-DMA kernels
 };
 
 template <int HD>
@@ -318,7 +319,11 @@ struct CfgD {
   static_assert((64 * KCH - 512) % 64 == 0 && K_LAST_WAVES >= 1 && K_LAST_WAVES <= 4, "K piece split");
 };
 
-template <int HD>
+// PIPE: the K stream runs one tile ahead of the V stream and S(t+1) = K(t+1) Q^T is issued
+// in the same basic block as the exp2 / pack work of tile t and the P V MFMAs of tile t, so
+// one wave keeps the matrix pipe and the VALU busy at the same time (22 MFMAs x 32 cycles
+// against ~110 VALU instructions per tile) instead of alternating between them.
+template <int HD, bool PIPE>
 __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   using C = CfgD<HD>;
   __shared__ __attribute__((aligned(16))) char smem[C::LDS];
@@ -326,11 +331,17 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, h = blockIdx.y, hk = h / p.kv_group;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: all query
+  // blocks of one (batch, head) are mapped to ONE XCD (consecutive slots of it), so its K/V
+  // rows come over the fabric once instead of once per query block.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / p.n_qblk) * 8 + xcd;
+  if (bh >= p.n_bh) return;  // uniform per workgroup, before any barrier
+  const int b = bh / p.n_heads, h = bh % p.n_heads, hk = h / p.kv_group;
   const int q_pos0 = p.q_pos0 ? p.q_pos0[b] : 0;
   const int kv_len = p.kv_len ? p.kv_len[b] : p.kv_len_all;
 
-  const int q_blk0 = blockIdx.x * 128;
+  const int q_blk0 = (slot % p.n_qblk) * 128;
   const int q_row0 = q_blk0 + wave * 32;
   const int q_row = min(q_row0 + l31, p.q_len - 1);
   const int qpos = q_pos0 + q_row;
@@ -379,26 +390,38 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     vsrc[j] = vbase + (int64_t)vrow[j] * p.v_ts + vcol[j];
   }
   const int64_t k_step = 64 * p.k_ts, v_step = 64 * p.v_ts;
-  auto issue_tile = [&](int kv0, int buf) {
-    char* kb = smem + buf * C::BUF;
-    char* vb = kb + C::K_BYTES;
-    const bool whole = kv0 + 64 <= kv_len;  // wave-uniform
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
+  auto dma16 = [&](const bf16_t* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto issue_k = [&](int kv0, int buf) {
+    char* kb = smem + buf * C::BUF + 64 * wave * 16;
+    if (kv0 + 64 <= kv_len) {  // wave-uniform: every row of the tile exists
+      dma16(ksrc[0], kb);
+      dma16(ksrc[1], kb + 4096);
+      if (wave < C::K_LAST_WAVES) dma16(ksrc[2], kb + 8192);
+    } else {
       // rows past kv_len replay the last valid row: their scores are masked to -inf, P is exactly 0
-      const bf16_t* src = whole ? ksrc[j] : kbase + (int64_t)min(kv0 + krow[j], kv_len - 1) * p.k_ts + kcol[j];
-      if (j < 2 || wave < C::K_LAST_WAVES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(kb + (256 * j + 64 * wave) * 16), 16, 0, 0);
-      ksrc[j] += k_step;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < 2 || wave < C::K_LAST_WAVES)
+          dma16(kbase + (int64_t)min(kv0 + krow[j], kv_len - 1) * p.k_ts + kcol[j], kb + 4096 * j);
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const bf16_t* src = whole ? vsrc[j] : vbase + (int64_t)min(kv0 + vrow[j], kv_len - 1) * p.v_ts + vcol[j];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(vb + (256 * j + 64 * wave) * 16), 16, 0, 0);
-      vsrc[j] += v_step;
+    for (int j = 0; j < 3; ++j) ksrc[j] += k_step;
+  };
+  auto issue_v = [&](int kv0, int buf) {
+    char* vb = smem + buf * C::BUF + C::K_BYTES + 64 * wave * 16;
+    if (kv0 + 64 <= kv_len) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dma16(vsrc[j], vb + 4096 * j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        dma16(vbase + (int64_t)min(kv0 + vrow[j], kv_len - 1) * p.v_ts + vcol[j], vb + 4096 * j);
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) vsrc[j] += v_step;
   };
 
   // per-lane offsets of the fragment reads
@@ -406,25 +429,46 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   const int k_lane = l31 * C::KROW + hi * 16;
   const int v_lane = (4 * hi + (i16 >> 2)) * C::VROW + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
 
-  if (kv_end > 0) issue_tile(0, 0);
-  int buf = 0;
-  for (int kv0 = 0; kv0 < kv_end; kv0 += 64, buf ^= 1) {
-    __syncthreads();  // own DMA of tile kv0 landed (vmcnt 0), everybody's visible, tile kv0-64 is no longer read
-    if (kv0 + 64 < kv_end) issue_tile(kv0 + 64, buf ^ 1);
-    const char* Ks = smem + buf * C::BUF;
-    const char* Vs = Ks + C::K_BYTES;
-
-    f32x16 sacc[2];
+  auto compute_s = [&](f32x16 (&sa)[2], const char* Ks) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+      for (int r = 0; r < 16; ++r) sa[sub][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s) {
         const bf16x8 kf = *(const bf16x8*)(Ks + k_lane + 32 * sub * C::KROW + 32 * s);
-        sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[sub], 0, 0, 0);
+        sa[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sa[sub], 0, 0, 0);
       }
     }
+  };
+
+  f32x16 sacc[2];
+  if (kv_end > 0) {
+    issue_k(0, 0);
+    issue_v(0, 0);
+    if (PIPE) {
+      if (64 < kv_end) issue_k(64, 1);
+      __syncthreads();
+      compute_s(sacc, smem);
+    }
+  }
+  int buf = 0;
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 64, buf ^= 1) {
+    // own DMA of the previous iteration landed (vmcnt 0), everybody's is visible, and the
+    // buffers refilled below are no longer read by any wave
+    __syncthreads();
+    if (PIPE) {
+      if (kv0 + 128 < kv_end) issue_k(kv0 + 128, buf);      // K(t+2) over K(t), consumed one iteration ago
+      if (kv0 + 64 < kv_end) issue_v(kv0 + 64, buf ^ 1);    // V(t+1) over V(t-1)
+    } else if (kv0 + 64 < kv_end) {
+      issue_k(kv0 + 64, buf ^ 1);
+      issue_v(kv0 + 64, buf ^ 1);
+    }
+    const char* Ks = smem + buf * C::BUF;
+    const char* Vs = Ks + C::K_BYTES;
+    const char* Kn = smem + (buf ^ 1) * C::BUF;  // PIPE: K(t+1) (stale but finite data after the last tile; result unused)
+
+    if (!PIPE) compute_s(sacc, Ks);
 
     const bool full_vis = (kv0 + 63 <= w_qpos_lo) || (w_qpos_hi < p.prefix && kv0 + 64 <= p.prefix);
     const bool need_mask = !(full_vis && kv0 + 64 <= kv_len);
@@ -458,6 +502,8 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     const float mc = (m_run == -INFINITY) ? 0.f : -m_run * p.scale_log2;
     float psum = 0.f;
     bf16x8 pf[2][2];
+    f32x16 snext[2];
+    if (PIPE) compute_s(snext, Kn);  // independent of everything below: the scheduler interleaves it
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -489,6 +535,10 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pf[sub][u], oacc[d], 0, 0, 0);
         }
       }
+    if (PIPE) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) sacc[sub] = snext[sub];
+    }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -664,18 +714,33 @@ extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
   k.kv_len = a->kv_len;
   k.scale_log2 = a->scale * 1.4426950408889634f;
   dim3 grid((a->q_len + 127) / 128, a->n_heads, a->batch);
+  k.n_qblk = (a->q_len + 127) / 128;
+  k.n_bh = a->batch * a->n_heads;
+  k.n_heads = a->n_heads;
+  const dim3 grid1(8 * k.n_qblk * ((k.n_bh + 7) / 8));
   hipStream_t s = (hipStream_t)stream;
-  static const bool reg_staged = [] { const char* e = getenv("MD_ATTN_REG_STAGED"); return e && e[0] == '1'; }();  // A/B runs
-  if (reg_staged) {
+  // MD_ATTN_VARIANT = reg | dma (default) | pipe for A/B runs
+  static const int variant = [] {
+    const char* e = getenv("MD_ATTN_VARIANT");
+    if (e && e[0] == 'r') return 0;
+    if (e && e[0] == 'p') return 2;
+    return 1;
+  }();
+  if (variant == 0) {
     if (a->head_dim == 72)
       hipLaunchKernelGGL(attn_prefill_kernel<72>, grid, dim3(256), 0, s, k);
     else
       hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, s, k);
+  } else if (variant == 1) {
+    if (a->head_dim == 72)
+      hipLaunchKernelGGL((attn_prefill_dma_kernel<72, false>), grid1, dim3(256), 0, s, k);
+    else
+      hipLaunchKernelGGL((attn_prefill_dma_kernel<64, false>), grid1, dim3(256), 0, s, k);
   } else {
     if (a->head_dim == 72)
-      hipLaunchKernelGGL(attn_prefill_dma_kernel<72>, grid, dim3(256), 0, s, k);
+      hipLaunchKernelGGL((attn_prefill_dma_kernel<72, true>), grid1, dim3(256), 0, s, k);
     else
-      hipLaunchKernelGGL(attn_prefill_dma_kernel<64>, grid, dim3(256), 0, s, k);
+      hipLaunchKernelGGL((attn_prefill_dma_kernel<64, true>), grid1, dim3(256), 0, s, k);
   }
   return md_launch_status();
 }

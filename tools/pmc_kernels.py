@@ -4,9 +4,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tools import kernel_bench as kb
-os.environ["MD_GEMM_TILE"] = "0"
-kb.bench_gemm(8192, 8192, 8192, 0, tiles=("0",))
-kb.bench_gemm(23328, 1152, 3456, 0, tiles=("0",))
+os.environ["MD_GEMM_TILE"] = "11"
+kb.bench_gemm(8192, 8192, 8192, 0, tiles=("11",))
+kb.bench_gemm(23328, 1152, 3456, 0, tiles=("11",))
 os.environ.pop("MD_GEMM_TILE", None)
 kb.bench_attn(32, 16, 729, 72)
 kb.bench_attn(64, 32, 730, 64, prefix=730)

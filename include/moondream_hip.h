@@ -108,6 +108,26 @@ typedef struct {
 md_status md_gemm_bf16(const md_gemm_args* args, void* stream);
 size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols);
 
+/* Decode regime (m <= 64), launch-boundary split-K: instead of combining the K slices inside
+ * the launch (tickets + an agent-scope release/acquire per tile), every slice stores its
+ * fp32 partial products, partial[s][row][ld_partial] for s < md_gemm_partial_slices(lin)
+ * (slice_stride floats apart; no bias), and the consumer kernel below sums them in slice
+ * order.  Used for the two linears that feed the residual stream in a decode step
+ * (proj: text.py:53, fc2: layers.py:139). */
+int32_t md_gemm_partial_slices(const md_linear* lin);
+md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_linear* lin, int32_t m, float* partial,
+                              int64_t ld_partial, int64_t slice_stride, void* stream);
+
+/* Block tail of a decode step, one launch (text.py:53,157-158 and the next block's text.py:145):
+ *   x = bf16(bf16(x + bf16(sum_s A[s] + bias_a)) + bf16(sum_s B[s] + bias_b));  y = layer_norm(x)
+ * -- the same roundings, in the same order, as two md_gemm_bf16 MD_EPI_RESIDUAL launches
+ * followed by md_layernorm_bf16.  y == NULL skips the layer norm (last block). */
+md_status md_reduce_residual_layernorm(void* x, int64_t ldx, const float* partial_a, int32_t slices_a,
+                                       const void* bias_a, const float* partial_b, int32_t slices_b,
+                                       const void* bias_b, int64_t ld_partial, int64_t slice_stride,
+                                       void* y, int64_t ldy, const md_layernorm* ln, int32_t rows,
+                                       int32_t dim, float eps, void* stream);
+
 /* Live timing of the GEMM launches for the roofline report: while enabled,
  * md_gemm_bf16 brackets every launch with HIP events on the caller's stream.
  * md_profile_gemm(0|1) also resets the log.  md_profile_gemm_read waits for the

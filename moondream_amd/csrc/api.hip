@@ -3,6 +3,7 @@
 // in this library.  Nothing here allocates or synchronises; every buffer,
 // including the workspace, belongs to the caller.
 #include "md_common.hpp"
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -84,6 +85,9 @@ md_status zero_if_padded(void* p, size_t rows, int ld, int width, hipStream_t s)
 struct TextWs {
   void *h, *qkv, *att, *ff, *pos_kv, *splitk;
   size_t splitk_bytes;
+  // decode regime: fp32 partial products of proj / fc2 (launch-boundary split-K)
+  float *part_a, *part_b;
+  int64_t part_ld, part_stride;
   size_t total;
 };
 
@@ -113,6 +117,15 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
   }
   w.splitk_bytes = sk;
   w.splitk = a.take(sk);
+  w.part_a = w.part_b = nullptr;
+  w.part_ld = w.part_stride = 0;
+  if (M <= 64) {
+    const md_text_block& b0 = m->blocks[0];
+    w.part_ld = ((int64_t)m->dim + 3) / 4 * 4;
+    w.part_stride = (int64_t)M * w.part_ld;
+    w.part_a = (float*)a.take((size_t)md_gemm_partial_slices(&b0.proj) * w.part_stride * 4);
+    w.part_b = (float*)a.take((size_t)md_gemm_partial_slices(&b0.fc2) * w.part_stride * 4);
+  }
   w.total = a.off;
   return w;
 }
@@ -290,13 +303,19 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
   int32_t* kv_len = (int32_t*)w.pos_kv;
   hipLaunchKernelGGL(kv_len_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pos0, kv_len, q_len, batch);
   const float scale = 1.0f / sqrtf((float)hd);
+  // decode regime (<= 64 rows): launch-boundary split-K for proj / fc2 + fused block tail.
+  // A function of the row count only, like the choice of GEMM kernel.  MD_TEXT_TAIL=0: A/B runs.
+  static const bool tail_allowed = [] { const char* e = getenv("MD_TEXT_TAIL"); return !(e && e[0] == '0'); }();
+  const bool tail_fused = tail_allowed && M <= 64 && D % 8 == 0 && m->blocks[0].proj.b && m->blocks[0].fc2.b &&
+                          m->blocks[0].proj.n == D && m->blocks[0].fc2.n == D;
 
   for (int l = 0; l < m->n_layers; ++l) {
     const md_text_block& b = m->blocks[l];
     bf16_t* kl = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
     bf16_t* vl = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
     // l_in = ln(x)                                            (text.py:145)
-    MD_TRY(md_layernorm_bf16(x, D, w.h, Dp, &b.ln, M, D, 1e-5f, s));
+    // (decode regime: blocks > 0 get it from the previous block's tail kernel)
+    if (!tail_fused || l == 0) MD_TRY(md_layernorm_bf16(x, D, w.h, Dp, &b.ln, M, D, 1e-5f, s));
     // qkv, rope(q), rope(k), cache update                      (text.py:30-46)
     const bool fused = b.qkv_fc1.w != nullptr;
     const int64_t qld = fused ? b.qkv_fc1.n_pad : qkv_w;  // leading dimension of the qkv activation
@@ -351,11 +370,23 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       MD_TRY(md_attention_prefill(&a, s));
     }
     // x = (x + proj(att)) + fc2(gelu(fc1(l_in)))               (text.py:53,157-158)
-    MD_TRY(gemm(w.att, Dp, b.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
     if (!fused)
       MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, ffld, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, w.splitk, w.splitk_bytes));
     MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad);
-    MD_TRY(gemm(w.ff, ffld, b.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
+    if (tail_fused) {
+      // decode regime: both linears leave fp32 K-slice partials; ONE tail kernel sums them, applies
+      // bias / residual with the same roundings and writes the next block's ln(x)
+      MD_TRY(md_gemm_partial_f32(w.att, Dp, &b.proj, M, w.part_a, w.part_ld, w.part_stride, s));
+      MD_TRY(md_gemm_partial_f32(w.ff, ffld, &b.fc2, M, w.part_b, w.part_ld, w.part_stride, s));
+      const bool last = (l + 1 == m->n_layers);
+      MD_TRY(md_reduce_residual_layernorm(x, D, w.part_a, md_gemm_partial_slices(&b.proj), b.proj.b, w.part_b,
+                                          md_gemm_partial_slices(&b.fc2), b.fc2.b, w.part_ld, w.part_stride,
+                                          last ? nullptr : w.h, Dp, last ? nullptr : &m->blocks[l + 1].ln, M, D,
+                                          1e-5f, s));
+    } else {
+      MD_TRY(gemm(w.att, Dp, b.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
+      MD_TRY(gemm(w.ff, ffld, b.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s, w.splitk, w.splitk_bytes));
+    }
   }
   return MD_OK;
 }

@@ -69,6 +69,114 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// Decode-regime block tail: the launch-boundary reduction of the two split-K
+// linears that feed the residual stream, their bias / residual epilogues, and the
+// NEXT block's layer norm, one workgroup per row:
+//   t1 = bf16(sum_s A[s] + bias_a)   x1 = bf16(x + t1)        (proj,  text.py:53,157)
+//   t2 = bf16(sum_s B[s] + bias_b)   x  = bf16(x1 + t2)       (fc2,   text.py:158)
+//   y  = layer_norm(x) with the next block's weights         (text.py:145), optional
+// -- the roundings of md_gemm_bf16's MD_EPI_RESIDUAL epilogue, in the same order; the
+// slices are summed in index order, so the result depends on the layer shape only.
+// ---------------------------------------------------------------------------
+template <int NCH>  // 16-byte chunks per thread; covers dim <= 2048 * NCH
+__global__ __launch_bounds__(256) void reduce_residual_ln_kernel(
+    bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ pa, int sa,
+    const bf16_t* __restrict__ bias_a, const float* __restrict__ pb, int sb,
+    const bf16_t* __restrict__ bias_b, int64_t ldp, int64_t slice_stride, bf16_t* __restrict__ y,
+    int64_t ldy, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ lnb, int dim, float eps) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x;
+  const int nchunk = dim >> 3;
+  bf16_t* xr = x + (int64_t)row * ldx;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = tid + 256 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    if (ch < nchunk) {
+      float acc_a[8], acc_b[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc_a[e] = acc_b[e] = 0.f;
+      const float* qa = pa + (int64_t)row * ldp + ch * 8;
+      for (int s = 0; s < sa; ++s) {
+        const f32x4 lo = *(const f32x4*)(qa + (int64_t)s * slice_stride);
+        const f32x4 hi = *(const f32x4*)(qa + (int64_t)s * slice_stride + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc_a[e] += lo[e];
+          acc_a[4 + e] += hi[e];
+        }
+      }
+      const float* qb = pb + (int64_t)row * ldp + ch * 8;
+      for (int s = 0; s < sb; ++s) {
+        const f32x4 lo = *(const f32x4*)(qb + (int64_t)s * slice_stride);
+        const f32x4 hi = *(const f32x4*)(qb + (int64_t)s * slice_stride + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc_b[e] += lo[e];
+          acc_b[4 + e] += hi[e];
+        }
+      }
+      const u32x4 xq = *(const u32x4*)(xr + ch * 8);
+      const u32x4 ba = *(const u32x4*)(bias_a + ch * 8);
+      const u32x4 bb = *(const u32x4*)(bias_b + ch * 8);
+      u32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t t1 = pack_bf16x2(acc_a[2 * e] + lo_bf(ba[e]), acc_a[2 * e + 1] + hi_bf(ba[e]));
+        const uint32_t x1 = pack_bf16x2(lo_bf(xq[e]) + lo_bf(t1), hi_bf(xq[e]) + hi_bf(t1));
+        const uint32_t t2 = pack_bf16x2(acc_b[2 * e] + lo_bf(bb[e]), acc_b[2 * e + 1] + hi_bf(bb[e]));
+        out[e] = pack_bf16x2(lo_bf(x1) + lo_bf(t2), hi_bf(x1) + hi_bf(t2));
+        v[i][2 * e] = lo_bf(out[e]);
+        v[i][2 * e + 1] = hi_bf(out[e]);
+        sum += v[i][2 * e] + v[i][2 * e + 1];
+      }
+      *(u32x4*)(xr + ch * 8) = out;
+    }
+  }
+  if (y == nullptr) return;  // uniform
+  sum = wave_sum(sum);
+  if (lane == 0) red[0][wave] = sum;
+  __syncthreads();
+  const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)dim;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (tid + 256 * i < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[1][wave] = ss;
+  __syncthreads();
+  const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)dim + eps);
+  bf16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = tid + 256 * i;
+    if (ch < nchunk) {
+      const u32x4 wq = *(const u32x4*)(lnw + ch * 8);
+      const u32x4 bq = *(const u32x4*)(lnb + ch * 8);
+      u32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = (v[i][2 * e] - mean) * rstd * lo_bf(wq[e]) + lo_bf(bq[e]);
+        const float c = (v[i][2 * e + 1] - mean) * rstd * hi_bf(wq[e]) + hi_bf(bq[e]);
+        out[e] = pack_bf16x2(a, c);
+      }
+      *(u32x4*)(yr + ch * 8) = out;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Patch extraction.  One workgroup per patch row of the GEMM operand:
 // out[(n*G*G + gy*G + gx)][c*P*P + py*P + px]   (reference: vision.py:44-61)
 // ---------------------------------------------------------------------------
@@ -305,6 +413,33 @@ extern "C" md_status md_layernorm_bf16(const void* x, int64_t ldx, void* y, int6
     hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, s, xx, ldx, yy, ldy, w, b, rows, dim, eps);
   else
     hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, xx, ldx, yy, ldy, w, b, rows, dim, eps);
+  return md_launch_status();
+}
+
+extern "C" md_status md_reduce_residual_layernorm(void* x, int64_t ldx, const float* partial_a, int32_t slices_a,
+                                                  const void* bias_a, const float* partial_b, int32_t slices_b,
+                                                  const void* bias_b, int64_t ld_partial, int64_t slice_stride,
+                                                  void* y, int64_t ldy, const md_layernorm* ln, int32_t rows,
+                                                  int32_t dim, float eps, void* stream) {
+  MD_CHECK_ARG(x && partial_a && partial_b && bias_a && bias_b && rows > 0 && dim > 0 && dim % 8 == 0);
+  MD_CHECK_ARG(slices_a >= 1 && slices_b >= 1 && ldx % 8 == 0 && ldx >= dim && ld_partial % 4 == 0 && ld_partial >= dim);
+  MD_CHECK_ARG(slice_stride % 4 == 0 && dim <= 8192);
+  MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)partial_a | (uintptr_t)partial_b | (uintptr_t)bias_a | (uintptr_t)bias_b) & 15) == 0);
+  const bf16_t *lw = nullptr, *lb = nullptr;
+  if (y != nullptr) {
+    MD_CHECK_ARG(ln && ln->w && ln->b && ldy % 8 == 0 && ldy >= dim && ((uintptr_t)y & 15) == 0);
+    lw = (const bf16_t*)ln->w;
+    lb = (const bf16_t*)ln->b;
+  }
+  hipStream_t s = (hipStream_t)stream;
+#define MD_RRL(NCH)                                                                                          \
+  hipLaunchKernelGGL(reduce_residual_ln_kernel<NCH>, dim3(rows), dim3(256), 0, s, (bf16_t*)x, ldx, partial_a, \
+                     slices_a, (const bf16_t*)bias_a, partial_b, slices_b, (const bf16_t*)bias_b, ld_partial, \
+                     slice_stride, (bf16_t*)y, ldy, lw, lb, dim, eps)
+  if (dim <= 2048) MD_RRL(1);
+  else if (dim <= 4096) MD_RRL(2);
+  else MD_RRL(4);
+#undef MD_RRL
   return md_launch_status();
 }
 

@@ -57,6 +57,10 @@ struct GemmK {
   int gelu_from;  // EPI_GELU: columns >= gelu_from get the GELU
   int prio;       // experiment: raise the wave priority around MFMA groups
   int nt;         // decode regime: stream the weights with the non-temporal policy
+  // launch-boundary split-K: every K slice stores its fp32 partial tile [slice][m][ldp] and exits;
+  // the consumer kernel sums the slices (md_reduce_residual_layernorm)
+  float* partial;
+  int64_t partial_ld, partial_slice_stride;
   // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
   int slices;
   float* slabs;
@@ -436,6 +440,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   }
 
   if constexpr (SPLITK) {
+    if (p.partial != nullptr) {
+      // acc[i][j][r]: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)
+      float* dst = p.partial + (int64_t)blockIdx.y * p.partial_slice_stride;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * TM + 32 * i + l31;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * TN + 32 * j + 8 * g + 4 * hi;
+            if (m < p.M && n < p.n_store)
+              *(f32x4*)(dst + (int64_t)m * p.partial_ld + n) =
+                  f32x4{acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          }
+      }
+      return;
+    }
     // Cross-workgroup split-K, deterministic: every slice publishes its fp32
     // accumulators as a slab in accumulator-register order (coalesced, and each
     // lane later reads back exactly its own registers); the LAST workgroup to
@@ -728,7 +750,9 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   if (const char* e = getenv("MD_GEMM_GROUP_M")) k.group_m = std::max(1, atoi(e));  // experiments
   k.prio = 0;
   if (const char* e = getenv("MD_GEMM_PRIO")) k.prio = atoi(e);
-  k.nt = 1;  // decode regime: non-temporal weight stream (+2..10 % measured); MD_DECODE_NT=0 for A/B runs
+  k.partial = nullptr;
+  k.partial_ld = k.partial_slice_stride = 0;
+  k.nt = 0;  // decode regime: MD_DECODE_NT=1 streams the weights non-temporally (kernel-level +2..10 %, nothing end to end)
   if (const char* e = getenv("MD_DECODE_NT")) k.nt = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   int tile = pick_tile(k.M, k.n_store);
@@ -765,6 +789,69 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
     case MD_EPI_RESIDUAL: st = launch_epi<MD_EPI_RESIDUAL>(k, tile, s); break;
     default: st = MD_ERR_INVALID_ARG;
   }
+  if (prof) {
+    (void)hipEventRecord(rec.stop, s);
+    g_prof.push_back(rec);
+  }
+  return st;
+}
+
+// Launch-boundary split-K (decode regime, m <= 64): S = md_gemm_partial_slices() workgroups per
+// 64-column tile, each over a contiguous range of K, store fp32 partial products
+// partial[s][row][ld_partial]; no bias, no tickets, no fences -- the kernel boundary publishes
+// them and md_reduce_residual_layernorm sums the slices in index order.
+extern "C" int32_t md_gemm_partial_slices(const md_linear* lin) {
+  if (!lin || lin->n <= 0 || lin->k_pad <= 0) return 0;
+  const int tiles = (lin->n + 63) / 64, nk = lin->k_pad / BK;
+  int s = 256 / std::max(1, tiles);
+  s = std::max(1, std::min(s, std::min(8, nk)));
+  return s;
+}
+
+extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_linear* lin, int32_t m,
+                                         float* partial, int64_t ld_partial, int64_t slice_stride,
+                                         void* stream) {
+  MD_CHECK_ARG(a && lin && lin->w && partial && m > 0 && m <= 64);
+  MD_CHECK_ARG(lin->k_pad % BK == 0 && lin->k_pad >= lin->k && lin->n % 8 == 0 && lin->n_pad % 64 == 0);
+  MD_CHECK_ARG(lda >= lin->k_pad && lda % 8 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)lin->w & 15) == 0);
+  MD_CHECK_ARG(ld_partial >= lin->n && ld_partial % 4 == 0 && ((uintptr_t)partial & 15) == 0);
+  MD_CHECK_ARG(slice_stride >= (int64_t)m * ld_partial && slice_stride % 4 == 0);
+  GemmK k;
+  k.A = (const bf16_t*)a;
+  k.W = (const bf16_t*)lin->w;
+  k.bias = nullptr;
+  k.R = nullptr;
+  k.C = nullptr;
+  k.lda = lda;
+  k.ldw = lin->k_pad;
+  k.ldc = k.ldr = 0;
+  k.M = m;
+  k.n_pad = lin->n_pad;
+  k.n_store = lin->n;
+  k.K = lin->k_pad;
+  k.res_row_mod = 0;
+  k.tiles_m = k.tiles_n = 0;
+  k.group_m = 8;
+  k.gelu_from = 0;
+  k.prio = 0;
+  k.nt = 0;
+  if (const char* e = getenv("MD_DECODE_NT")) k.nt = atoi(e);
+  k.slices = md_gemm_partial_slices(lin);
+  k.slabs = nullptr;
+  k.tickets = nullptr;
+  k.partial = partial;
+  k.partial_ld = ld_partial;
+  k.partial_slice_stride = slice_stride;
+  hipStream_t s = (hipStream_t)stream;
+  ProfRec rec;
+  const bool prof = g_prof_on;
+  if (prof) {
+    if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return MD_ERR_LAUNCH;
+    rec.kind = 1;
+    rec.work = 2.0 * (double)lin->n * (double)lin->k;
+    (void)hipEventRecord(rec.start, s);
+  }
+  const md_status st = launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
   if (prof) {
     (void)hipEventRecord(rec.stop, s);
     g_prof.push_back(rec);

@@ -199,6 +199,65 @@ def test_gemm_decode_regime(lib, m, k, n, epi):
     compare(f"skinny(no scratch) m{m} {k}x{n}", c1, ref, 3e-3, 2e-2)
 
 
+@pytest.mark.parametrize("m,dim,ka,kb", [(64, 2048, 2048, 8192), (5, 1024, 1024, 4096), (1, 144, 144, 576), (33, 256, 256, 704)])
+def test_block_tail_partials_then_reduce_residual_layernorm(lib, m, dim, ka, kb):
+    """Decode-regime block tail: md_gemm_partial_f32 x 2 + md_reduce_residual_layernorm against the
+    composition it replaces (two residual linears with bf16 roundings, then layer norm); the
+    slice sums are exact fp32 restatements, so x is checked against a torch model of the same
+    roundings; rows must not depend on how many rows are in flight."""
+    a1, w1, b1 = randn(m, ka, seed=70), randn(dim, ka, scale=1 / math.sqrt(ka), seed=71), randn(dim, scale=0.1, seed=72)
+    a2, w2, b2 = randn(m, kb, seed=73), randn(dim, kb, scale=1 / math.sqrt(kb), seed=74), randn(dim, scale=0.1, seed=75)
+    x0 = randn(m, dim, seed=76)
+    lw, lb = randn(dim, scale=0.1, seed=77) + 1.0, randn(dim, scale=0.1, seed=78)
+    la, lbn = PackedLinear(w1, b1, "cuda"), PackedLinear(w2, b2, "cuda")
+    ln = PackedLayerNorm(lw, lb, "cuda")
+
+    def run(rows):
+        sa, sb = la.struct(), lbn.struct()
+        na, nb = lib.md_gemm_partial_slices(C.byref(sa)), lib.md_gemm_partial_slices(C.byref(sb))
+        assert 1 <= na <= 8 and 1 <= nb <= 8
+        ldp = dim
+        pa = torch.full((na, rows, ldp), float("nan"), dtype=torch.float32, device="cuda")
+        pb = torch.full((nb, rows, ldp), float("nan"), dtype=torch.float32, device="cuda")
+        A1, A2 = pad_k(a1[:rows], la.k_pad), pad_k(a2[:rows], lbn.k_pad)
+        _lib.check(lib.md_gemm_partial_f32(A1.data_ptr(), A1.stride(0), C.byref(sa), rows, pa.data_ptr(), ldp, rows * ldp, stream()))
+        _lib.check(lib.md_gemm_partial_f32(A2.data_ptr(), A2.stride(0), C.byref(sb), rows, pb.data_ptr(), ldp, rows * ldp, stream()))
+        x = x0[:rows].clone()
+        ld = (dim + 63) // 64 * 64
+        y = torch.zeros(rows, ld, dtype=BF16, device="cuda")
+        st = ln.struct()
+        _lib.check(lib.md_reduce_residual_layernorm(x.data_ptr(), dim, pa.data_ptr(), na, la.b.data_ptr(), pb.data_ptr(), nb,
+                                                    lbn.b.data_ptr(), ldp, rows * ldp, y.data_ptr(), ld, C.byref(st), rows, dim,
+                                                    1e-5, stream()))
+        torch.cuda.synchronize()
+        return x, y, pa, pb
+
+    x, y, pa, pb = run(m)
+    assert torch.isfinite(pa).all() and torch.isfinite(pb).all()
+    # the partials add up to the fp32 products
+    compare("partials a", pa.sum(0).to(BF16), (a1.float() @ w1.float().t()).to(BF16), 3e-3, 2e-2)
+    compare("partials b", pb.sum(0).to(BF16), (a2.float() @ w2.float().t()).to(BF16), 3e-3, 2e-2)
+    # exact model of the roundings, from the kernel's own partials summed in slice order
+    acc_a = torch.zeros_like(pa[0])
+    for s_ in range(pa.shape[0]):
+        acc_a = acc_a + pa[s_]
+    acc_b = torch.zeros_like(pb[0])
+    for s_ in range(pb.shape[0]):
+        acc_b = acc_b + pb[s_]
+    t1 = (acc_a + b1.float()).to(BF16)
+    x1 = (x0[:m].float() + t1.float()).to(BF16)
+    t2 = (acc_b + b2.float()).to(BF16)
+    x2 = (x1.float() + t2.float()).to(BF16)
+    assert torch.equal(x, x2)
+    ref = torch.nn.functional.layer_norm(x2.float(), (dim,), lw.float(), lb.float(), 1e-5).to(BF16)
+    compare("tail layernorm", y[:, :dim], ref, 2e-3, 1e-2)
+    assert torch.count_nonzero(y[:, dim:]) == 0
+    # batch invariance: row 0 alone gives the same bits
+    xs, ys, _, _ = run(1)
+    assert torch.equal(xs[0], x[0]) and torch.equal(ys[0], y[0])
+
+
+
 @pytest.mark.parametrize("rows,dim", [(7, 144), (1458, 1152), (730, 2048), (3, 720), (5, 256)])
 def test_layernorm(lib, rows, dim):
     x = randn(rows, dim, scale=3.0, seed=15) + 0.5

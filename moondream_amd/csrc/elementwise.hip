@@ -97,27 +97,41 @@ __global__ __launch_bounds__(256) void reduce_residual_ln_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
     if (ch < nchunk) {
+      // every slice of both operands is requested before the first add (one exposed memory
+      // latency instead of one per slice); the sums run in slice order
+      constexpr int MAXS = 8;
+      f32x4 la[MAXS][2], lb[MAXS][2];
+      const float* qa = pa + (int64_t)row * ldp + ch * 8;
+      const float* qb = pb + (int64_t)row * ldp + ch * 8;
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) {
+        if (s < sa) {
+          la[s][0] = *(const f32x4*)(qa + (int64_t)s * slice_stride);
+          la[s][1] = *(const f32x4*)(qa + (int64_t)s * slice_stride + 4);
+        }
+        if (s < sb) {
+          lb[s][0] = *(const f32x4*)(qb + (int64_t)s * slice_stride);
+          lb[s][1] = *(const f32x4*)(qb + (int64_t)s * slice_stride + 4);
+        }
+      }
       float acc_a[8], acc_b[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc_a[e] = acc_b[e] = 0.f;
-      const float* qa = pa + (int64_t)row * ldp + ch * 8;
-      for (int s = 0; s < sa; ++s) {
-        const f32x4 lo = *(const f32x4*)(qa + (int64_t)s * slice_stride);
-        const f32x4 hi = *(const f32x4*)(qa + (int64_t)s * slice_stride + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc_a[e] += lo[e];
-          acc_a[4 + e] += hi[e];
+      for (int s = 0; s < MAXS; ++s) {
+        if (s < sa) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc_a[e] += la[s][0][e];
+            acc_a[4 + e] += la[s][1][e];
+          }
         }
-      }
-      const float* qb = pb + (int64_t)row * ldp + ch * 8;
-      for (int s = 0; s < sb; ++s) {
-        const f32x4 lo = *(const f32x4*)(qb + (int64_t)s * slice_stride);
-        const f32x4 hi = *(const f32x4*)(qb + (int64_t)s * slice_stride + 4);
+        if (s < sb) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc_b[e] += lo[e];
-          acc_b[4 + e] += hi[e];
+          for (int e = 0; e < 4; ++e) {
+            acc_b[e] += lb[s][0][e];
+            acc_b[4 + e] += lb[s][1][e];
+          }
         }
       }
       const u32x4 xq = *(const u32x4*)(xr + ch * 8);
@@ -422,7 +436,7 @@ extern "C" md_status md_reduce_residual_layernorm(void* x, int64_t ldx, const fl
                                                   void* y, int64_t ldy, const md_layernorm* ln, int32_t rows,
                                                   int32_t dim, float eps, void* stream) {
   MD_CHECK_ARG(x && partial_a && partial_b && bias_a && bias_b && rows > 0 && dim > 0 && dim % 8 == 0);
-  MD_CHECK_ARG(slices_a >= 1 && slices_b >= 1 && ldx % 8 == 0 && ldx >= dim && ld_partial % 4 == 0 && ld_partial >= dim);
+  MD_CHECK_ARG(slices_a >= 1 && slices_b >= 1 && slices_a <= 8 && slices_b <= 8 && ldx % 8 == 0 && ldx >= dim && ld_partial % 4 == 0 && ld_partial >= dim);
   MD_CHECK_ARG(slice_stride % 4 == 0 && dim <= 8192);
   MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)partial_a | (uintptr_t)partial_b | (uintptr_t)bias_a | (uintptr_t)bias_b) & 15) == 0);
   const bf16_t *lw = nullptr, *lb = nullptr;

@@ -196,18 +196,29 @@ class MoondreamModel:
         )
         return out
 
-    def _text_forward(self, x: torch.Tensor, pos0: torch.Tensor, slot0: int = 0) -> torch.Tensor:
+    def _causal_text_struct(self):
+        """The decoder description with an empty bidirectional prefix: the plain causal
+        mask the reference builds for a text-only query (moondream.py:571-575)."""
+        st = getattr(self, "_text_causal", None)
+        if st is None:
+            st = type(self.w.text).from_buffer_copy(self.w.text)
+            st.prefix_len = 0
+            self._text_causal = st
+        return st
+
+    def _text_forward(self, x: torch.Tensor, pos0: torch.Tensor, slot0: int = 0, causal: bool = False) -> torch.Tensor:
         """x [B,T,D] embeddings -> hidden [B,T,D]; K,V written at pos0[b]..pos0[b]+T-1."""
         b, t, d = x.shape
+        text = self._causal_text_struct() if causal else self.w.text
         self._ensure_batch(slot0 + b)
         x = x.contiguous()
         hidden = torch.empty_like(x)
-        need = self.lib.md_text_workspace_bytes(C.byref(self.w.text), b, t)
+        need = self.lib.md_text_workspace_bytes(C.byref(text), b, t)
         ws = self._workspace(need)
         kv = self._kv_struct(slot0)
         _lib.check(
             self.lib.md_text_forward(
-                C.byref(self.w.text), x.data_ptr(), hidden.data_ptr(), b, t, pos0.data_ptr(), C.byref(kv),
+                C.byref(text), x.data_ptr(), hidden.data_ptr(), b, t, pos0.data_ptr(), C.byref(kv),
                 ws.data_ptr(), ws.numel(), self._stream(),
             ),
             "md_text_forward",
@@ -635,8 +646,10 @@ class MoondreamModel:
 
     # ------------------------------------------------------- sequential API
     def _prefill_prompt(self, prompt_tokens: torch.Tensor, pos: int, temperature: float, top_p: float,
-                        spatial_refs: Optional[SpatialRefs] = None, attn_mask=None, lora=None):
-        """reference: moondream.py:280-321."""
+                        spatial_refs: Optional[SpatialRefs] = None, attn_mask=None, lora=None, causal: bool = False):
+        """reference: moondream.py:280-321.  ``causal`` stands for the reference's
+        ``attn_mask`` argument: the only non-default mask it ever passes is the plain
+        lower-triangular one of a text-only query (moondream.py:571-575)."""
         with torch.inference_mode():
             ids = prompt_tokens.to(torch.int32)
             emb = self._embed(ids)
@@ -646,13 +659,14 @@ class MoondreamModel:
                 if enc["sizes"] is not None:
                     emb[ids.to(self._device) == self.config.tokenizer.size_id] = enc["sizes"]
             pos0 = torch.full((1,), pos, dtype=torch.int32, device=self._device)
-            hidden = self._text_forward(emb, pos0, 0)
+            hidden = self._text_forward(emb, pos0, 0, causal=causal)
             logits = self._lm_head(hidden)
             nxt = self._pick(logits, temperature, top_p)
         return logits, hidden, nxt.reshape(1, 1), pos + ids.shape[1]
 
     def _generate_answer(self, prompt_tokens: torch.Tensor, pos: int, settings: Optional[dict] = None,
-                         spatial_refs: Optional[SpatialRefs] = None, eos_id: Optional[int] = None, attn_mask=None):
+                         spatial_refs: Optional[SpatialRefs] = None, eos_id: Optional[int] = None, attn_mask=None,
+                         causal: bool = False):
         """Generator of text pieces.  reference: moondream.py:434-539."""
         settings = settings or {}
         max_tokens = settings.get("max_tokens", DEFAULT_MAX_TOKENS)
@@ -661,7 +675,8 @@ class MoondreamModel:
         if settings.get("variant") is not None:
             raise NotImplementedError("LoRA variants are not on the native path")
         eos = eos_id if eos_id is not None else self.config.tokenizer.eos_id
-        _, _, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask)
+        # decode steps attend to keys [0, pos] only, which both masks allow: the mask matters for the prompt
+        _, _, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask, causal=causal)
 
         def token_source():
             if temperature == 0:
@@ -755,17 +770,22 @@ class MoondreamModel:
             raise ValueError("spatial_refs can only be used with an image.")
         if reasoning:
             raise NotImplementedError("reasoning mode is not on the native path yet")
-        if image is None:
-            raise NotImplementedError("text-only query (plain causal mask) is not on the native path yet")
-        enc = self.encode_image(image)
-        self.load_encoded_image(enc)
+        if image is not None:
+            enc = self.encode_image(image)
+            self.load_encoded_image(enc)
+            pos, head, causal = enc.pos, list(tpl["prefix"]), False
+        else:
+            # text only: BOS + prefix at position 0 under the plain causal mask (moondream.py:564-575);
+            # stale K/V beyond the positions written here are never read (kv_len bounds every kernel)
+            self._ensure_batch(1)
+            pos, head, causal = 0, [self.config.tokenizer.bos_id] + list(tpl["prefix"]), True
         spatial = []
         if spatial_refs:
             tk = self.config.tokenizer
             for ref in spatial_refs:
                 spatial.extend([tk.coord_id, tk.coord_id] if len(ref) == 2 else [tk.coord_id, tk.coord_id, tk.size_id])
-        prompt = list(tpl["prefix"]) + spatial + list(self.tokenizer.encode(question).ids) + list(tpl["suffix"]) + list(tpl["suffix"])
-        gen = self._generate_answer(torch.tensor([prompt]), enc.pos, settings, spatial_refs)
+        prompt = head + spatial + list(self.tokenizer.encode(question).ids) + list(tpl["suffix"]) + list(tpl["suffix"])
+        gen = self._generate_answer(torch.tensor([prompt]), pos, settings, spatial_refs, causal=causal)
         return {"answer": gen} if stream else {"answer": "".join(list(gen))}
 
     # ------------------------------------------------------------ region head

@@ -303,6 +303,63 @@ def gen_crops():
     print(f"[crops] wrote {path}")
 
 
+def gen_textonly(name="tiny_textonly", cfg_name="tiny", seed=1, n_cases=3, max_tokens=12, min_margin=1.0):
+    """Text-only query through the reference's own public `query(image=None, ...)`
+    (moondream.py:564-575: BOS + query prefix, pos 0, plain causal mask)."""
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    rng = np.random.default_rng(4242 + seed)
+    out = {"seed": np.int64(seed), "cfg": np.array(cfg_name)}
+    kept, tries = 0, 0
+    while kept < n_cases:
+        tries += 1
+        assert tries < 200, "could not find enough wide-margin questions"
+        q = rng.integers(10, min(50000, cfg.text.vocab_size), int(rng.integers(3, 9))).tolist()
+        rec = {"decode_logits": []}
+        orig_decode, orig_lm_head = model._decode_one_tok, ref_md.lm_head
+
+        def decode_tap(x, mask, pos_ids, lora):
+            logits, hidden = orig_decode(x, mask, pos_ids, lora)
+            rec["decode_logits"].append(logits[0].clone())
+            return logits, hidden
+
+        def lm_head_tap(h, w):
+            o = orig_lm_head(h, w)
+            rec.setdefault("prompt_logits", o[0].clone())
+            return o
+
+        model._decode_one_tok, ref_md.lm_head = decode_tap, lm_head_tap
+        try:
+            ans = model.query(None, " ".join(str(t) for t in q), settings={"temperature": 0, "max_tokens": max_tokens})["answer"]
+        finally:
+            model._decode_one_tok, ref_md.lm_head = orig_decode, orig_lm_head
+        tokens = [int(t) for t in ans.split()]
+        steps = [rec["prompt_logits"]]
+        for lg in rec["decode_logits"]:
+            lg = lg.clone()
+            lg[cfg.tokenizer.answer_id] = float("-inf")
+            steps.append(lg)
+        margins = []
+        for lg in steps:
+            top = torch.topk(lg.float(), 2).values
+            margins.append(float(top[0] - top[1]))
+        if min(margins) < min_margin:
+            print(f"[{name}] skip question {q}: min margin {min(margins):.3f}", flush=True)
+            continue
+        pfx = f"q{kept}."
+        out[pfx + "question"] = np.array(q)
+        out[pfx + "tokens"] = np.array(tokens)
+        out[pfx + "margins"] = np.array(margins, dtype=np.float32)
+        out[pfx + "step_logits"] = bf16_bits(torch.stack(steps))
+        print(f"[{name}] q{kept}: question {q} -> {tokens} (min margin {min(margins):.3f})", flush=True)
+        kept += 1
+    out["n_cases"] = np.int64(kept)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -314,6 +371,8 @@ def main():
         gen_model_case("tiny_seed1", "tiny", 1, [(378, 378)], 24, True, n_images=3)
     if "multicrop" in which:
         gen_multicrop()
+    if "textonly" in which:
+        gen_textonly()
     if "0.5b" in which:
         gen_model_case("md05b_seed1", "0.5b", 1, [(378, 378)], 32, False, n_images=2, min_margin=0.5)
     if "2b" in which:

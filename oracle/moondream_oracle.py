@@ -335,11 +335,13 @@ def text_attention(x, sd, prefix, cfg, layer, kv: OracleKV, pos: torch.Tensor, c
     return linear(o, sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"], fast)
 
 
-def text_decoder(x, sd, cfg, kv: OracleKV, pos: torch.Tensor, cos, sin, tap=None, fast=False):
+def text_decoder(x, sd, cfg, kv: OracleKV, pos: torch.Tensor, cos, sin, tap=None, fast=False, prefix=None):
     """Parallel attention + MLP off ONE LayerNorm, then two left-to-right bf16
-    adds.  reference: text.py:128-160.  x [T, D] -> [T, D]; writes kv."""
+    adds.  reference: text.py:128-160.  x [T, D] -> [T, D]; writes kv.
+    ``prefix`` overrides the bidirectional prefix length (0 = the plain causal
+    mask of a text-only query, moondream.py:571-575)."""
     t = cfg.text
-    allowed = prefix_lm_allowed(pos, t.max_context, t.prefix_attn)
+    allowed = prefix_lm_allowed(pos, t.max_context, t.prefix_attn if prefix is None else prefix)
     for i in range(t.n_layers):
         p = f"text.blocks.{i}"
         h = layer_norm(x, sd[p + ".ln.weight"], sd[p + ".ln.bias"])
@@ -390,17 +392,17 @@ class Oracle:
         text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast)
         return x.shape[0], kv
 
-    def prefill_prompt(self, prompt_ids, pos0: int, kv: OracleKV, tap=None, prompt_emb=None):
+    def prefill_prompt(self, prompt_ids, pos0: int, kv: OracleKV, tap=None, prompt_emb=None, prefix=None):
         """reference: moondream.py:280-321 (greedy branch)."""
         x = self.embed(prompt_ids) if prompt_emb is None else prompt_emb
         pos = torch.arange(pos0, pos0 + x.shape[0])
-        h = text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast)
+        h = text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast, prefix)
         logits = lm_head(h[-1], self.sd, self.fast)
         return logits, h, pos0 + x.shape[0]
 
-    def decode_token(self, emb: torch.Tensor, pos: int, kv: OracleKV):
+    def decode_token(self, emb: torch.Tensor, pos: int, kv: OracleKV, prefix=None):
         """reference: moondream.py:183-192.  emb [1, D]."""
-        h = text_decoder(emb, self.sd, self.cfg, kv, torch.tensor([pos]), self.cos, self.sin, None, self.fast)
+        h = text_decoder(emb, self.sd, self.cfg, kv, torch.tensor([pos]), self.cos, self.sin, None, self.fast, prefix)
         return lm_head(h[-1], self.sd, self.fast), h
 
     @staticmethod
@@ -419,6 +421,7 @@ class Oracle:
         eos_id: Optional[int] = None,
         forced: Optional[List[int]] = None,
         keep_logits: bool = True,
+        prefix: Optional[int] = None,
     ) -> OracleRun:
         """Greedy answer generation.  reference: moondream.py:434-539 with
         temperature == 0: prefill the prompt, then per token: stop on eos or
@@ -427,7 +430,7 @@ class Oracle:
         step by a given id while still recording the logits."""
         tk = self.cfg.tokenizer
         eos = tk.eos_id if eos_id is None else eos_id
-        logits, _, pos = self.prefill_prompt(prompt_ids, pos0, kv)
+        logits, _, pos = self.prefill_prompt(prompt_ids, pos0, kv, prefix=prefix)
         out, margins, all_logits = [], [], []
         tok, mg = self._argmax_margin(logits)
         step = 0
@@ -440,7 +443,7 @@ class Oracle:
             if (eos is not None and tok == eos) or step >= max_tokens:
                 break
             out.append(tok)
-            logits, _ = self.decode_token(self.embed([tok]), pos, kv)
+            logits, _ = self.decode_token(self.embed([tok]), pos, kv, prefix)
             logits[tk.answer_id] = float("-inf")
             pos += 1
             step += 1

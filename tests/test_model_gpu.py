@@ -200,6 +200,22 @@ def test_text_api_and_streaming(tiny):
     assert 1 <= len(sampled.split()) <= 6
 
 
+def test_text_only_query_vs_reference(tiny, golden_dir):
+    """query(image=None, question): reference moondream.py:564-575 -- BOS + query prefix at
+    position 0 under the plain causal mask; ids recorded from the reference's public API."""
+    g0, cfg, sd, model = tiny
+    g = load_golden(golden_dir, "tiny_textonly.npz")
+    # dirty the KV slabs first: a text-only query must not see an earlier image's keys
+    model.caption(golden_image(g0, 0), settings={"temperature": 0, "max_tokens": 2})
+    for i in range(int(g["n_cases"])):
+        want = g[f"q{i}.tokens"].tolist()
+        q = " ".join(str(t) for t in g[f"q{i}.question"].tolist())
+        ans = model.query(None, q, settings={"temperature": 0, "max_tokens": len(want)})["answer"]
+        assert [int(t) for t in ans.split()] == want
+    with pytest.raises(ValueError):
+        model.query(None, "1 2 3", spatial_refs=[(0.5, 0.5)])
+
+
 def test_multicrop_images_vs_reference(golden_dir):
     g = load_golden(golden_dir, "tiny_multicrop.npz")
     cfg, sd, model = build("tiny", 3)

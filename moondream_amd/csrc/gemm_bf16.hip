@@ -123,31 +123,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   const int hi = lane >> 5, l31 = lane & 31;
 
   // ---- workgroup -> tile -------------------------------------------------
+  // PP == 3: persistent workgroups (one per CU) walk the tile sequence with stride gridDim.x;
+  // v % 8 == blockIdx.x % 8 (gridDim.x is a multiple of 8 or covers every tile), so the XCD
+  // each tile lands on is the one xcd_remap assumes.
+  constexpr bool PERSIST = (PP == 3);
+  constexpr bool ALT = (PP == 2 || PP == 3);
   const int nwg = p.tiles_m * p.tiles_n;
-  const int L = xcd_remap(blockIdx.x, nwg);
   const int GROUP_M = p.group_m;
   const int per_group = GROUP_M * p.tiles_n;
-  const int first_m = (L / per_group) * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (L % per_group) % gsz;
-  const int tn = (L % per_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // ---- per-thread LDS-DMA source pointers (advance 128 B per K slice) -----
+  int tm, tn, m0, n0;
+  // per-thread LDS-DMA source pointers (advance one slice width per K slice)
   const char* a_src[NA];
   const char* b_src[NB];
+  auto set_tile = [&](int vv) {
+    const int L = xcd_remap(vv, nwg);
+    const int first_m = (L / per_group) * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    tm = first_m + (L % per_group) % gsz;
+    tn = (L % per_group) / gsz;
+    m0 = tm * BM;
+    n0 = tn * BN;
 #pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
-    const int64_t row = min(m0 + r, p.M - 1);
-    a_src[j] = (const char*)(p.A + row * p.lda + c * 8);
-  }
+    for (int j = 0; j < NA; ++j) {
+      const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
+      const int64_t row = min(m0 + r, p.M - 1);
+      a_src[j] = (const char*)(p.A + row * p.lda + c * 8);
+    }
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
-    const int64_t row = min(n0 + r, p.n_pad - 1);
-    b_src[j] = (const char*)(p.W + row * p.ldw + c * 8);
-  }
+    for (int j = 0; j < NB; ++j) {
+      const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
+      const int64_t row = min(n0 + r, p.n_pad - 1);
+      b_src[j] = (const char*)(p.W + row * p.ldw + c * 8);
+    }
+  };
+  int vtile = blockIdx.x;
+  set_tile(vtile);
 
   // one 16-byte-per-lane LDS-DMA piece (1 KiB per wave) of slice `stage`
   auto issue_piece = [&](auto piece_c, int stage) {
@@ -171,12 +181,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   };
 
   f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment read offsets: row = (tile row base, multiple of 32) + l31, so the
   // swizzle term depends on the lane only: (row >> 1) & 7 for 128-byte rows, (row >> 2) & 3 for 64-byte rows
@@ -196,6 +200,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) b_src[j] += (int64_t)t0 * ROW_BYTES;
   }
+  // alternating schedule: the first AHEAD slices of a tile (PERSIST: issued for the NEXT tile
+  // before the current tile's epilogue, so they land under it)
+  auto alt_prologue = [&]() {
+    if constexpr (ALT) {
+      static_for<0, STAGES - 2>([&](auto sc) {
+        constexpr int SL0 = decltype(sc)::value;
+        if (SL0 < nk) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, SL0); });
+      });
+    }
+  };
+  if constexpr (PERSIST) alt_prologue();
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if constexpr (PP == 1) {
     // ---- ping-pong schedule -------------------------------------------------
     // 32-wide slices, one slice = one PHASE (barrier + 2 K-steps).  The second half
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
         static_for<0, PIECES>([&](auto pc) { issue_piece(pc, nstage); });
       }
     }
-  } else if constexpr (PP == 2) {
+  } else if constexpr (ALT) {
     // ---- alternating wave groups (cdna guide 5: "8-phase" discipline) ----------
     // 32-wide slices, two PHASES per slice (the wave's upper / lower 64 rows), eight
     // MFMAs (256 matrix-pipe cycles) per phase on four independent accumulators.
@@ -304,10 +326,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
     constexpr int AHEAD = STAGES - 2;  // slices in flight ahead of the one being computed
     static_assert((AHEAD - 1) * PIECES < 64, "vmcnt is a 6-bit counter");
     const int lag = (wave >= (WM * WN) / 2) ? 1 : 0;  // SGPR: uniform per wave
-    static_for<0, AHEAD>([&](auto sc) {
-      constexpr int SL0 = decltype(sc)::value;
-      if (SL0 < nk) static_for<0, PIECES>([&](auto pc) { issue_piece(pc, SL0); });
-    });
+    if constexpr (!PERSIST) alt_prologue();
     if (nk >= AHEAD) wait_vm<(AHEAD - 1) * PIECES>(); else wait_vm<0>();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();  // slice 0 visible to everybody
@@ -508,8 +527,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
   // ---- epilogue -----------------------------------------------------------
   // acc[i][j][r]: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)
   __syncthreads();  // all waves are done reading the operand ring
-  char* tile = smem + wave * 4096;  // wave-private 32 x 64 bf16 transposition tile
-  const int wn0 = n0 + wn * TN;
+  const int m0c = m0, n0c = n0;  // the tile whose accumulators are being stored
+  char* tile = smem + (PERSIST ? STAGES * STAGE : 0) + wave * 4096;  // wave-private 32 x 64 bf16 transposition tile
+  const int wn0 = n0c + wn * TN;
 
   float bias_v[NI][4][4];
 #pragma unroll
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
-        const int m = m0 + wm * TM + 32 * i + row;
+        const int m = m0c + wm * TM + 32 * i + row;
         const int n = wn0 + ch * 8;
         rres[i][q] = u32x4{0, 0, 0, 0};
         if (m < p.M && n < p.n_store) {
@@ -544,6 +564,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
           rres[i][q] = *(const u32x4*)(p.R + rrow * p.ldr + n);
         }
       }
+  }
+
+  bool more = false;
+  if constexpr (PERSIST) {
+    // next tile's first slices are requested now (AFTER this tile's bias / residual loads, which
+    // would otherwise queue behind them) and land under this epilogue; the transposition
+    // scratch lives behind the ring so the two do not meet
+    vtile += gridDim.x;
+    more = vtile < nwg;
+    if (more) {
+      set_tile(vtile);
+      alt_prologue();
+    }
   }
 
 #pragma unroll
@@ -562,7 +595,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
     for (int q = 0; q < 4; ++q) {
       const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
       u32x4 v = *(const u32x4*)(tile + row * 128 + ((ch ^ (row & 7)) * 16));
-      const int m = m0 + wm * TM + 32 * i + row;
+      const int m = m0c + wm * TM + 32 * i + row;
       const int n = wn0 + ch * 8;
       if (m < p.M && n < p.n_store) {
         if constexpr (EPI == MD_EPI_GELU) {
@@ -590,6 +623,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
       }
     }
   }
+  if (!more) break;
+  // the epilogue's stores share vmcnt with the DMA ring: drain both before the next tile's counted waits
+  wait_vm<0>();
+  }  // tile loop
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
@@ -597,7 +634,8 @@ md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int ring = STAGES * (BM + BN) * BKT * 2;
   constexpr int epi = WM * WN * 4096;
-  constexpr int lds = ring > epi ? ring : epi;
+  constexpr int lds = (PP == 3) ? ring + epi : (ring > epi ? ring : epi);
+  static_assert(lds <= 163840, "LDS budget");
   auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -610,7 +648,9 @@ md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   GemmK kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.n_store + BN - 1) / BN;
-  hipLaunchKernelGGL(fn, dim3(kk.tiles_m * kk.tiles_n, SPLITK ? kk.slices : 1), dim3(NT), lds, stream, kk);
+  const int nwg = kk.tiles_m * kk.tiles_n;
+  const int gx = (PP == 3) ? std::min(nwg, 256) : nwg;  // persistent: one workgroup per CU
+  hipLaunchKernelGGL(fn, dim3(gx, SPLITK ? kk.slices : 1), dim3(NT), lds, stream, kk);
   return md_launch_status();
 }
 
@@ -646,6 +686,7 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     case 9: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 1>(k, stream);  // same, 5-deep ring
     case 11: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 2>(k, stream);  // alternating wave groups, 2 slices ahead
     case 12: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 2>(k, stream);  // same, 3 slices ahead (160 KiB LDS)
+    case 15: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 3>(k, stream);  // alternating + persistent tile loop
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }

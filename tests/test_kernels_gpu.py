@@ -62,7 +62,7 @@ def pad_k(a, k_pad):
     return out
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12", "15"])
 def test_gemm_identity_detects_transposes(lib, tile, monkeypatch):
     """A = I with an ASYMMETRIC W: C must equal W^T bit for bit."""
     monkeypatch.setenv("MD_GEMM_TILE", tile)
@@ -74,7 +74,7 @@ def test_gemm_identity_detects_transposes(lib, tile, monkeypatch):
     assert torch.equal(c, w.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12", "15"])
 @pytest.mark.parametrize("m,k,n", [(300, 588, 1152), (777, 1152, 3456), (1000, 2048, 6144), (64, 2048, 1024), (1, 256, 64)])
 def test_gemm_bias(lib, tile, m, k, n, monkeypatch):
     monkeypatch.setenv("MD_GEMM_TILE", tile)
@@ -93,7 +93,7 @@ def test_gemm_tile_configs_agree_bitwise(lib, monkeypatch):
     lin = PackedLinear(w, b, "cuda")
     monkeypatch.setenv("MD_GEMM_TILE", "2")
     want = gemm(lib, a, lin)
-    for tile in ("0", "1", "4", "5", "8", "11", "12"):
+    for tile in ("0", "1", "4", "5", "8", "11", "12", "15"):
         monkeypatch.setenv("MD_GEMM_TILE", tile)
         for rep in range(6):
             got = gemm(lib, a, lin)

@@ -20,17 +20,12 @@ def run(m,k,n,epi,env):
     dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())))
     for kk in env: os.environ.pop(kk)
     return 2.0*m*n*k/dt/1e12
-shapes=[(23328,1152,4304,1),(23328,1152,3456,0),(23328,4304,1152,2),(46720,2048,14336,1),(46720,2048,2048,2),(46720,8192,2048,2),(4096,4096,4096,0),(8192,8192,8192,0)]
-def line(m,k,n,epi):
-    r={t:run(m,k,n,epi,{'MD_GEMM_TILE':t,'MD_GEMM_PRIO':pr}) for t,pr in (('0','0'),('0','1'),('11','0'),('12','0'))}
-    return f"m={m} k={k} n={n}: 256x256 bk64x2 {r['0']:6.0f} | ALTERNATING bk32x4 {r['11']:6.0f} | ALTERNATING bk32x5 {r['12']:6.0f}"
+shapes=[(23328,1152,4304,1),(23328,1152,3456,0),(23328,1152,1152,2),(23328,4304,1152,2),(46720,2048,14336,1),(46720,2048,2048,2),(46720,8192,2048,2),(4096,4096,4096,0),(8192,8192,8192,0)]
 def run2(m,k,n,epi):
     r={}
-    for key,t,pr in (('base','0','0'),('prio','0','1'),('alt4','11','0'),('alt5','12','0')):
-        r[key]=run(m,k,n,epi,{'MD_GEMM_TILE':t,'MD_GEMM_PRIO':pr})
-    return f"m={m} k={k} n={n}: 256x256 bk64x2 {r['base']:6.0f} (setprio {r['prio']:6.0f}) | ALTERNATING bk32x4 {r['alt4']:6.0f} | bk32x5 {r['alt5']:6.0f}"
+    for rep in range(2):
+        for key,t in (('alt','11'),('persist','15')):
+            r.setdefault(key,[]).append(run(m,k,n,epi,{'MD_GEMM_TILE':t}))
+    return f"m={m} k={k} n={n} epi={epi}: alternating {r['alt'][0]:6.0f} {r['alt'][1]:6.0f} | + persistent tile loop {r['persist'][0]:6.0f} {r['persist'][1]:6.0f}"
 for sh in shapes:
     print(run2(*sh), flush=True)
-ZERO = True
-for sh in [(4096,4096,4096,0),(8192,8192,8192,0)]:
-    print("ZERO-FILLED "+run2(*sh)+"  (guide 8-phase template: 1563@4k / 1728@8k zero-filled, ~1330 / ~1470 random)", flush=True)

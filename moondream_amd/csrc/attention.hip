@@ -390,9 +390,20 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     vsrc[j] = vbase + (int64_t)vrow[j] * p.v_ts + vcol[j];
   }
   const int64_t k_step = 64 * p.k_ts, v_step = 64 * p.v_ts;
+  // LDS-DMA issued through inline asm: with the builtin, hipcc orders every later LDS read it can
+  // see (the transpose reads of the P V stage) behind the in-flight DMA of the NEXT tile with an
+  // s_waitcnt vmcnt(0) in the middle of the iteration.  The buffers are disjoint by construction
+  // (double buffering + the barrier below), so the wait belongs in front of that barrier only.
   auto dma16 = [&](const bf16_t* src, char* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(src), "s"(lds)
+                 : "memory", "m0");
+  };
+  auto tile_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own LDS-DMA pieces (the compiler does not count them)
+    __syncthreads();
   };
   auto issue_k = [&](int kv0, int buf) {
     char* kb = smem + buf * C::BUF + 64 * wave * 16;
@@ -443,12 +454,17 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   };
 
   f32x16 sacc[2];
+  // Pin the Q fragments before the loop: otherwise hipcc keeps its wait for those loads inside the
+  // loop (s_waitcnt vmcnt(0) in front of the first MFMAs), where it also waits for the LDS-DMA
+  // pieces it does not know about, every iteration.
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) asm volatile("" ::"v"(qf[s]));
   if (kv_end > 0) {
     issue_k(0, 0);
     issue_v(0, 0);
     if (PIPE) {
       if (64 < kv_end) issue_k(64, 1);
-      __syncthreads();
+      tile_barrier();
       compute_s(sacc, smem);
     }
   }
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   for (int kv0 = 0; kv0 < kv_end; kv0 += 64, buf ^= 1) {
     // own DMA of the previous iteration landed (vmcnt 0), everybody's is visible, and the
     // buffers refilled below are no longer read by any wave
-    __syncthreads();
+    tile_barrier();
     if (PIPE) {
       if (kv0 + 128 < kv_end) issue_k(kv0 + 128, buf);      // K(t+2) over K(t), consumed one iteration ago
       if (kv0 + 64 < kv_end) issue_v(kv0 + 64, buf ^ 1);    // V(t+1) over V(t-1)

@@ -117,6 +117,11 @@ size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pa
 int32_t md_gemm_partial_slices(const md_linear* lin);
 md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_linear* lin, int32_t m, float* partial,
                               int64_t ld_partial, int64_t slice_stride, void* stream);
+/* The same for two independent layers over the same rows in ONE launch (a decode block's proj and
+ * fc2): partial0 / partial1 get md_gemm_partial_slices(lin0) / (lin1) slices. */
+md_status md_gemm_partial_f32_pair(const void* a0, int64_t lda0, const md_linear* lin0, float* partial0,
+                                   const void* a1, int64_t lda1, const md_linear* lin1, float* partial1,
+                                   int32_t m, int64_t ld_partial, int64_t slice_stride, void* stream);
 
 /* Block tail of a decode step, one launch (text.py:53,157-158 and the next block's text.py:145):
  *   x = bf16(bf16(x + bf16(sum_s A[s] + bias_a)) + bf16(sum_s B[s] + bias_b));  y = layer_norm(x)

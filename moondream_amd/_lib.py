@@ -95,6 +95,8 @@ SIGNATURES = {
     "md_gemm_workspace_bytes": (c_size_t, [P(MdLinear), c_int32, c_int32]),
     "md_gemm_partial_slices": (c_int32, [P(MdLinear)]),
     "md_gemm_partial_f32": (C.c_int, [c_void_p, c_int64, P(MdLinear), c_int32, c_void_p, c_int64, c_int64, c_void_p]),
+    "md_gemm_partial_f32_pair": (C.c_int, [c_void_p, c_int64, P(MdLinear), c_void_p, c_void_p, c_int64, P(MdLinear), c_void_p,
+                                           c_int32, c_int64, c_int64, c_void_p]),
     "md_reduce_residual_layernorm": (C.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                                c_int64, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_float, c_void_p]),
     "md_profile_gemm": (None, [c_int32]),

@@ -376,8 +376,8 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     if (tail_fused) {
       // decode regime: both linears leave fp32 K-slice partials; ONE tail kernel sums them, applies
       // bias / residual with the same roundings and writes the next block's ln(x)
-      MD_TRY(md_gemm_partial_f32(w.att, Dp, &b.proj, M, w.part_a, w.part_ld, w.part_stride, s));
-      MD_TRY(md_gemm_partial_f32(w.ff, ffld, &b.fc2, M, w.part_b, w.part_ld, w.part_stride, s));
+      MD_TRY(md_gemm_partial_f32_pair(w.att, Dp, &b.proj, w.part_a, w.ff, ffld, &b.fc2, w.part_b, M, w.part_ld,
+                                      w.part_stride, s));
       const bool last = (l + 1 == m->n_layers);
       MD_TRY(md_reduce_residual_layernorm(x, D, w.part_a, md_gemm_partial_slices(&b.proj), b.proj.b, w.part_b,
                                           md_gemm_partial_slices(&b.fc2), b.fc2.b, w.part_ld, w.part_stride,

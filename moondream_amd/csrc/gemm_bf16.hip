@@ -98,8 +98,8 @@ __device__ __forceinline__ void wait_vm() {
 // whose per-slice compute is far shorter than the DMA latency.
 // BKT = K elements per slice (64: 128-byte rows, 8 chunks; 32: 64-byte rows, 4 chunks,
 // which lets the 256x256 tile keep three 32 KiB slices in flight in a 4-deep ring).
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK, int STAGES, int BKT, int PP>
+__device__ __forceinline__ void gemm_body(const GemmK& p) {
   constexpr int ROW_BYTES = BKT * 2;
   constexpr int CH = BKT / 8;                 // 16-byte chunks per row
   constexpr int CH_SHIFT = (CH == 8) ? 3 : 2;
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
     }
   };
   int vtile = blockIdx.x;
+  if (vtile >= nwg) return;                                    // paired launches: grid covers the larger problem
+  if constexpr (SPLITK) if ((int)blockIdx.y >= p.slices) return;
   set_tile(vtile);
 
   // one 16-byte-per-lane LDS-DMA piece (1 KiB per wave) of slice `stage`
@@ -630,6 +632,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
+  gemm_body<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP>(p);
+}
+
+// two independent problems in ONE launch (blockIdx.z picks the problem): the decode block's
+// proj and fc2 partial-product GEMMs
+struct GemmPair {
+  GemmK g[2];
+};
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_pair_kernel(const GemmPair pair) {
+  gemm_body<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP>(pair.g[blockIdx.z]);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
 md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int ring = STAGES * (BM + BN) * BKT * 2;
@@ -849,15 +866,14 @@ extern "C" int32_t md_gemm_partial_slices(const md_linear* lin) {
   return s;
 }
 
-extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_linear* lin, int32_t m,
-                                         float* partial, int64_t ld_partial, int64_t slice_stride,
-                                         void* stream) {
+namespace {
+md_status fill_partial(GemmK& k, const void* a, int64_t lda, const md_linear* lin, int32_t m, float* partial,
+                       int64_t ld_partial, int64_t slice_stride) {
   MD_CHECK_ARG(a && lin && lin->w && partial && m > 0 && m <= 64);
   MD_CHECK_ARG(lin->k_pad % BK == 0 && lin->k_pad >= lin->k && lin->n % 8 == 0 && lin->n_pad % 64 == 0);
   MD_CHECK_ARG(lda >= lin->k_pad && lda % 8 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)lin->w & 15) == 0);
   MD_CHECK_ARG(ld_partial >= lin->n && ld_partial % 4 == 0 && ((uintptr_t)partial & 15) == 0);
   MD_CHECK_ARG(slice_stride >= (int64_t)m * ld_partial && slice_stride % 4 == 0);
-  GemmK k;
   k.A = (const bf16_t*)a;
   k.W = (const bf16_t*)lin->w;
   k.bias = nullptr;
@@ -871,7 +887,8 @@ extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_li
   k.n_store = lin->n;
   k.K = lin->k_pad;
   k.res_row_mod = 0;
-  k.tiles_m = k.tiles_n = 0;
+  k.tiles_m = (m + 63) / 64;
+  k.tiles_n = (lin->n + 63) / 64;
   k.group_m = 8;
   k.gelu_from = 0;
   k.prio = 0;
@@ -883,21 +900,73 @@ extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_li
   k.partial = partial;
   k.partial_ld = ld_partial;
   k.partial_slice_stride = slice_stride;
-  hipStream_t s = (hipStream_t)stream;
+  return MD_OK;
+}
+
+struct ProfScope {  // HIP-event bracket of one launch for md_profile_gemm (kind 1: weight bytes streamed)
   ProfRec rec;
-  const bool prof = g_prof_on;
-  if (prof) {
+  bool on;
+  hipStream_t s;
+  md_status begin(double work, hipStream_t stream) {
+    on = g_prof_on;
+    s = stream;
+    if (!on) return MD_OK;
     if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return MD_ERR_LAUNCH;
     rec.kind = 1;
-    rec.work = 2.0 * (double)lin->n * (double)lin->k;
+    rec.work = work;
     (void)hipEventRecord(rec.start, s);
+    return MD_OK;
   }
-  const md_status st = launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
-  if (prof) {
+  void end() {
+    if (!on) return;
     (void)hipEventRecord(rec.stop, s);
     g_prof.push_back(rec);
   }
+};
+}  // namespace
+
+extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_linear* lin, int32_t m,
+                                         float* partial, int64_t ld_partial, int64_t slice_stride,
+                                         void* stream) {
+  GemmK k;
+  const md_status chk = fill_partial(k, a, lda, lin, m, partial, ld_partial, slice_stride);
+  if (chk != MD_OK) return chk;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof;
+  if (prof.begin(2.0 * (double)lin->n * (double)lin->k, s) != MD_OK) return MD_ERR_LAUNCH;
+  const md_status st = launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
+  prof.end();
   return st;
+}
+
+// Both partial-product GEMMs of a decode block (proj over the attention output, fc2 over
+// gelu(fc1)) in ONE launch: they are independent, and a launch costs as much as the stream.
+extern "C" md_status md_gemm_partial_f32_pair(const void* a0, int64_t lda0, const md_linear* lin0, float* partial0,
+                                              const void* a1, int64_t lda1, const md_linear* lin1, float* partial1,
+                                              int32_t m, int64_t ld_partial, int64_t slice_stride, void* stream) {
+  GemmPair pair;
+  md_status chk = fill_partial(pair.g[0], a0, lda0, lin0, m, partial0, ld_partial, slice_stride);
+  if (chk != MD_OK) return chk;
+  chk = fill_partial(pair.g[1], a1, lda1, lin1, m, partial1, ld_partial, slice_stride);
+  if (chk != MD_OK) return chk;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int NT = 2 * 1 * 64, lds = 4 * (64 + 64) * 64 * 2;
+  auto fn = gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return MD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  ProfScope prof;
+  if (prof.begin(2.0 * ((double)lin0->n * lin0->k + (double)lin1->n * lin1->k), s) != MD_OK) return MD_ERR_LAUNCH;
+  const int gx = std::max(pair.g[0].tiles_m * pair.g[0].tiles_n, pair.g[1].tiles_m * pair.g[1].tiles_n);
+  const int gy = std::max(pair.g[0].slices, pair.g[1].slices);
+  hipLaunchKernelGGL(fn, dim3(gx, gy, 2), dim3(NT), lds, s, pair);
+  prof.end();
+  return md_launch_status();
 }
 
 extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols) {

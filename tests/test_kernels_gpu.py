@@ -234,6 +234,14 @@ def test_block_tail_partials_then_reduce_residual_layernorm(lib, m, dim, ka, kb)
 
     x, y, pa, pb = run(m)
     assert torch.isfinite(pa).all() and torch.isfinite(pb).all()
+    # both layers in one launch: the same partials, bit for bit
+    sa, sb = la.struct(), lbn.struct()
+    pa2, pb2 = torch.full_like(pa, float("nan")), torch.full_like(pb, float("nan"))
+    A1, A2 = pad_k(a1, la.k_pad), pad_k(a2, lbn.k_pad)
+    _lib.check(lib.md_gemm_partial_f32_pair(A1.data_ptr(), A1.stride(0), C.byref(sa), pa2.data_ptr(), A2.data_ptr(), A2.stride(0),
+                                            C.byref(sb), pb2.data_ptr(), m, dim, m * dim, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(pa2, pa) and torch.equal(pb2, pb)
     # the partials add up to the fp32 products
     compare("partials a", pa.sum(0).to(BF16), (a1.float() @ w1.float().t()).to(BF16), 3e-3, 2e-2)
     compare("partials b", pb.sum(0).to(BF16), (a2.float() @ w2.float().t()).to(BF16), 3e-3, 2e-2)

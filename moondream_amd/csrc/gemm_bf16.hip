@@ -98,14 +98,20 @@ __device__ __forceinline__ void wait_vm() {
 // whose per-slice compute is far shorter than the DMA latency.
 // BKT = K elements per slice (64: 128-byte rows, 8 chunks; 32: 64-byte rows, 4 chunks,
 // which lets the 256x256 tile keep three 32 KiB slices in flight in a 4-deep ring).
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK, int STAGES, int BKT, int PP>
+// XW = extra DMA-only waves: they issue their share of every slice's LDS-DMA pieces and take
+// part in the barriers, nothing else.  An LDS-DMA instruction costs its wave ~100+ cycles, so in
+// the decode regime (tiny MFMA work per slice) a workgroup's stream is bound by how many waves
+// issue it (probe: 67 / 108 / 120 GB/s per CU with 2 / 4 / 8 issuing waves).
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK, int STAGES, int BKT, int PP, int XW>
 __device__ __forceinline__ void gemm_body(const GemmK& p) {
   constexpr int ROW_BYTES = BKT * 2;
   constexpr int CH = BKT / 8;                 // 16-byte chunks per row
   constexpr int CH_SHIFT = (CH == 8) ? 3 : 2;
   constexpr int KSTEPS = BKT / 16;            // MFMA K-steps per slice
   static_assert(BKT == 64 || BKT == 32, "slice width");
-  constexpr int NT = WM * WN * 64;
+  constexpr int CT = WM * WN * 64;       // threads that compute
+  constexpr int NT = CT + XW * 64;       // threads that move data
+  static_assert(XW == 0 || PP == 0, "helper waves: lockstep schedule only");
   constexpr int TM = BM / WM, TN = BN / WN;
   static_assert(TN == 64, "epilogue transposes 32 x 64 wave tiles");
   constexpr int MI = TM / 32, NI = TN / 32;
@@ -119,6 +125,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_compute = (XW == 0) || wave < WM * WN;  // wave-uniform
   const int wm = wave / WN, wn = wave % WN;
   const int hi = lane >> 5, l31 = lane & 31;
 
@@ -408,6 +415,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
       asm volatile("" ::: "memory");
       const bool has_next = t + STAGES - 1 < nk;
       const int nstage = (t + STAGES - 1) % STAGES;
+      if constexpr (XW > 0) {
+        if (!is_compute) {  // DMA-only wave: its pieces of slice t+STAGES-1, then the next barrier
+          if (has_next) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, nstage); });
+          continue;
+        }
+      }
       // LDS -> register fragments, software pipelined by hand: the six ds_read_b128 of
       // K-step s+1 are issued BEFORE the eight MFMAs of step s and waited for with a
       // counted lgkmcnt (LDS returns in order), so the matrix pipe never waits on LDS
@@ -464,6 +477,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
     if (p.partial != nullptr) {
       // acc[i][j][r]: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)
       float* dst = p.partial + (int64_t)blockIdx.y * p.partial_slice_stride;
+      if (is_compute)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * TM + 32 * i + l31;
@@ -485,15 +499,17 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
     // arrive (agent-scope release -> ticket -> acquire, cdna guide 6 G16) sums the
     // slabs in slice order and runs the epilogue.  The summation tree depends on
     // the layer shape only, never on how many rows are live.
-    constexpr int SLAB = NT * MI * NI * 16;  // floats per workgroup
+    constexpr int SLAB = CT * MI * NI * 16;  // floats per workgroup
     const int tile_id = tm * p.tiles_n + tn;
     float* slab = p.slabs + ((int64_t)tile_id * p.slices + blockIdx.y) * SLAB;
+    if (is_compute) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[((i * NI + j) * 16 + r) * NT + tid] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r) slab[((i * NI + j) * 16 + r) * CT + tid] = acc[i][j][r];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* flag = (unsigned*)smem;  // operand ring is dead after the barrier
@@ -517,18 +533,23 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int sl = 0; sl < p.slices; ++sl)
+    if (is_compute) {
+      for (int sl = 0; sl < p.slices; ++sl)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+          for (int j = 0; j < NI; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += base[(int64_t)sl * SLAB + ((i * NI + j) * 16 + r) * NT + tid];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += base[(int64_t)sl * SLAB + ((i * NI + j) * 16 + r) * CT + tid];
+    }
   }
 
   // ---- epilogue -----------------------------------------------------------
   // acc[i][j][r]: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)
   __syncthreads();  // all waves are done reading the operand ring
+  if constexpr (XW > 0) {
+    if (!is_compute) return;
+  }
   const int m0c = m0, n0c = n0;  // the tile whose accumulators are being stored
   char* tile = smem + (PERSIST ? STAGES * STAGE : 0) + wave * 4096;  // wave-private 32 x 64 bf16 transposition tile
   const int wn0 = n0c + wn * TN;
@@ -631,9 +652,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
   }  // tile loop
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
-  gemm_body<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP>(p);
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0, int XW = 0>
+__global__ __launch_bounds__((WM * WN + XW) * 64) void gemm_bf16_kernel(const GemmK p) {
+  gemm_body<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP, XW>(p);
 }
 
 // two independent problems in ONE launch (blockIdx.z picks the problem): the decode block's
@@ -641,19 +662,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmK p) {
 struct GemmPair {
   GemmK g[2];
 };
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_pair_kernel(const GemmPair pair) {
-  gemm_body<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP>(pair.g[blockIdx.z]);
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0, int XW = 0>
+__global__ __launch_bounds__((WM * WN + XW) * 64) void gemm_pair_kernel(const GemmPair pair) {
+  gemm_body<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP, XW>(pair.g[blockIdx.z]);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK = false, int STAGES = 2, int BKT = 64, int PP = 0, int XW = 0>
 md_status launch_cfg(const GemmK& k, hipStream_t stream) {
-  constexpr int NT = WM * WN * 64;
+  constexpr int NT = (WM * WN + XW) * 64;
   constexpr int ring = STAGES * (BM + BN) * BKT * 2;
   constexpr int epi = WM * WN * 4096;
   constexpr int lds = (PP == 3) ? ring + epi : (ring > epi ? ring : epi);
   static_assert(lds <= 163840, "LDS budget");
-  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP>;
+  auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP, XW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -704,6 +725,9 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     case 11: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 2>(k, stream);  // alternating wave groups, 2 slices ahead
     case 12: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 2>(k, stream);  // same, 3 slices ahead (160 KiB LDS)
     case 15: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 3>(k, stream);  // alternating + persistent tile loop
+    // decode regime, 64x64 tiles + two DMA-only helper waves (4 waves issue the stream)
+    case 16: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4, 64, 0, 2>(k, stream)
+                                 : launch_cfg<64, 64, 2, 1, EPI, false, 4, 64, 0, 2>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }
@@ -721,9 +745,10 @@ int decode_cfg() {
   if (dc && dc[0] == 'c') return 7;
   if (dc && dc[0] == 'e') return 13;
   if (dc && dc[0] == 'f') return 14;
-  return 10;
+  if (dc && dc[0] == '6') return 10;  // "64": two waves, no helpers
+  return 16;
 }
-bool decode_is64(int cfg) { return cfg == 10 || cfg == 13 || cfg == 14; }
+bool decode_is64(int cfg) { return cfg == 10 || cfg == 13 || cfg == 14 || cfg == 16; }
 int decode_bn() { return decode_is64(decode_cfg()) ? 64 : 128; }
 int decode_slab_floats() { return decode_is64(decode_cfg()) ? 128 * 1 * 2 * 16 : 128 * 2 * 2 * 16; }  // NT * MI * NI * 16
 
@@ -934,7 +959,8 @@ extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_li
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof;
   if (prof.begin(2.0 * (double)lin->n * (double)lin->k, s) != MD_OK) return MD_ERR_LAUNCH;
-  const md_status st = launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
+  const md_status st = decode_cfg() == 16 ? launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
+                                          : launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
   prof.end();
   return st;
 }
@@ -950,15 +976,18 @@ extern "C" md_status md_gemm_partial_f32_pair(const void* a0, int64_t lda0, cons
   chk = fill_partial(pair.g[1], a1, lda1, lin1, m, partial1, ld_partial, slice_stride);
   if (chk != MD_OK) return chk;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int NT = 2 * 1 * 64, lds = 4 * (64 + 64) * 64 * 2;
-  auto fn = gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  constexpr int lds = 4 * (64 + 64) * 64 * 2;
+  const bool helpers = decode_cfg() == 16;
+  const int NT = helpers ? 256 : 128;
+  auto fn = helpers ? gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
+                    : gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[helpers]) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       return MD_ERR_LAUNCH;
     }
-    attr_set = true;
+    attr_set[helpers] = true;
   }
   ProfScope prof;
   if (prof.begin(2.0 * ((double)lin0->n * lin0->k + (double)lin1->n * lin1->k), s) != MD_OK) return MD_ERR_LAUNCH;

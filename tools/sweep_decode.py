@@ -18,7 +18,7 @@ for (m, k, n, epi) in [(64, 2048, 14336, 1), (64, 2048, 6144, 0), (64, 2048, 204
     ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, ws.data_ptr(), ws.numel())
     out = []
-    for cfg, nt in (("64", "0"), ("64", "1"), ("e", "0"), ("e", "1"), ("f", "1")):
+    for cfg, nt in (("64", "0"), ("helpers", "0")):
         os.environ["MD_DECODE_CFG"] = cfg; os.environ["MD_DECODE_NT"] = nt
         best = None
         for sl in (1, 2, 4, 8):

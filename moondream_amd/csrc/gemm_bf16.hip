@@ -83,6 +83,16 @@ __device__ __forceinline__ void ds_read_b128(bf16x8& dst, uint32_t addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
+// LDS store / load of the epilogue transposition the compiler does not see (persistent tile
+// loop: with visible LDS accesses hipcc parks an s_waitcnt vmcnt(0) in front of them while the
+// next tile's LDS-DMA prefetch is in flight)
+__device__ __forceinline__ void ds_write_b64_asm(uint32_t addr, u32x2 v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ds_read_b128_u32(u32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
@@ -552,6 +562,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
   }
   const int m0c = m0, n0c = n0;  // the tile whose accumulators are being stored
   char* tile = smem + (PERSIST ? STAGES * STAGE : 0) + wave * 4096;  // wave-private 32 x 64 bf16 transposition tile
+  const uint32_t tile_lds = lds_base + (PERSIST ? STAGES * STAGE : 0) + wave * 4096;
   const int wn0 = n0c + wn * TN;
 
   float bias_v[NI][4][4];
@@ -612,12 +623,30 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
         w[0] = pack_bf16x2(acc[i][j][4 * g + 0] + bias_v[j][g][0], acc[i][j][4 * g + 1] + bias_v[j][g][1]);
         w[1] = pack_bf16x2(acc[i][j][4 * g + 2] + bias_v[j][g][2], acc[i][j][4 * g + 3] + bias_v[j][g][3]);
         const int ch = 4 * j + g;
-        *(u32x2*)(tile + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8) = w;
+        if constexpr (PERSIST)
+          ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, w);
+        else
+          *(u32x2*)(tile + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8) = w;
       }
+    u32x4 tv[4];
+    if constexpr (PERSIST) {
+      // same-wave LDS operations execute in order: the reads see the writes above
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+        ds_read_b128_u32(tv[q], tile_lds + row * 128 + ((ch ^ (row & 7)) * 16));
+      }
+      wait_lgkm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
-      u32x4 v = *(const u32x4*)(tile + row * 128 + ((ch ^ (row & 7)) * 16));
+      u32x4 v;
+      if constexpr (PERSIST)
+        v = tv[q];
+      else
+        v = *(const u32x4*)(tile + row * 128 + ((ch ^ (row & 7)) * 16));
       const int m = m0c + wm * TM + 32 * i + row;
       const int n = wn0 + ch * 8;
       if (m < p.M && n < p.n_store) {
@@ -843,6 +872,14 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.slabs = nullptr;
   k.tickets = nullptr;
   const char* forced = getenv("MD_GEMM_TILE");
+  if (tile == 11 && a->epilogue != MD_EPI_RESIDUAL && !(forced && *forced)) {
+    // bias / GELU layers with more tiles than CUs: persistent tile loop, the next tile's first
+    // slices land under the current epilogue (+3..5 % at K = 1152; residual layers lose, see
+    // profiles/r01_gemm_persistent_tile_loop_sweep*.txt)
+    static const bool persist = [] { const char* e = getenv("MD_GEMM_PERSIST"); return !(e && e[0] == '0'); }();
+    const long tiles = (long)((k.M + 255) / 256) * ((k.n_store + 255) / 256);
+    if (persist && tiles > 256) tile = 15;
+  }
   if (a->m <= 64 && !(forced && *forced)) {
     tile = decode_cfg();
     const int sl = decode_slices(k.n_store, k.K);

@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--tokens", type=int, default=32, help="decode tokens per image")
     ap.add_argument("--model", default="2b")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--vit-chunk", type=int, default=32)
+    ap.add_argument("--vit-chunk", type=int, default=128, help="crops per ViT launch group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--no-graphs", action="store_true", help="launch decode steps eagerly instead of hipGraph replay")

@@ -86,7 +86,7 @@ class MoondreamModel:
         setup_caches: bool = True,
         tokenizer: Any = None,
         max_batch: int = 1,
-        vit_chunk_crops: int = 32,
+        vit_chunk_crops: int = 128,
     ):
         if dtype != BF16:
             raise ValueError("the Moondream hot path is bf16-only (reference: vision.py:36)")

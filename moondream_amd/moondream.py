@@ -148,6 +148,15 @@ class MoondreamModel:
             self._graphs.clear()
         return ws
 
+    @classmethod
+    def from_pretrained(cls, weights_file: str, config: Optional[MoondreamConfig] = None, **kwargs):
+        """Build the model from a checkpoint file (``.safetensors`` / ``.pt``; both key layouts the
+        reference accepts, weights.py:112-171).  ``config`` defaults to the 2B configuration."""
+        from .config import get_config
+        from .weights import load_state_dict_file
+
+        return cls(config or get_config("2b"), load_state_dict_file(weights_file), **kwargs)
+
     def compile(self):
         """The reference rebinds the seam to torch.compile'd functions here
         (moondream.py:194-204).  The seam is already native; ``compile`` turns on

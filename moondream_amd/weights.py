@@ -152,6 +152,29 @@ def remap_legacy_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
+def load_state_dict_file(weights_file: str) -> Dict[str, torch.Tensor]:
+    """Read a checkpoint the way the reference's ``load_weights_into_model`` does
+    (weights.py:112-171): ``.safetensors`` or a torch ``.pt`` state dict, in the
+    module-tree key layout (optionally prefixed ``model.``) or the older
+    ``vision_encoder.* / text_model.* / region_model.*`` layout (optionally with
+    torch.compile's ``._orig_mod`` infix).  Returns module-tree keys; tensors
+    stay on the CPU (``PackedModel`` moves and packs them)."""
+    if weights_file.endswith(".safetensors"):
+        import safetensors
+
+        with safetensors.safe_open(weights_file, framework="pt") as st:
+            raw = {k: st.get_tensor(k) for k in st.keys()}
+    else:
+        raw = torch.load(weights_file, map_location="cpu", weights_only=True)
+    norm = {}
+    for k, v in raw.items():
+        k = k.replace("._orig_mod", "")
+        if k.startswith("model."):
+            k = k[len("model."):]
+        norm[k] = v
+    return remap_legacy_keys(norm)
+
+
 class PackedModel:
     """All weights resident on one device + the md_vit_model / md_text_model
     structs (kept alive here; the library only borrows the pointers)."""

@@ -1,0 +1,79 @@
+"""Checkpoint files: the key layouts and containers the reference's loader accepts
+(reference weights.py:30-171) come back as the module-tree state dict."""
+import os
+
+import torch
+
+from moondream_amd import synth
+from moondream_amd.config import get_config
+from moondream_amd.weights import load_state_dict_file
+
+
+def _to_legacy(sd):
+    """Inverse of the reference's weight_map (weights.py:36-109)."""
+    pre = {
+        "vision.patch_emb": "vision_encoder.encoder.model.visual.patch_embed.linear",
+        "vision.post_ln": "vision_encoder.encoder.model.visual.norm",
+        "vision.proj_mlp.fc1": "vision_encoder.projection.mlp.fc1",
+        "vision.proj_mlp.fc2": "vision_encoder.projection.mlp.fc2",
+        "text.post_ln": "text_model.lm_head.ln",
+        "text.lm_head": "text_model.lm_head.linear",
+        "region.coord_encoder": "region_model.coordinate_encoder",
+        "region.coord_decoder.fc1": "region_model.coordinate_decoder.fc1",
+        "region.coord_decoder.fc2": "region_model.coordinate_decoder.fc2",
+        "region.size_encoder": "region_model.size_encoder",
+        "region.size_decoder.fc1": "region_model.size_decoder.fc1",
+        "region.size_decoder.fc2": "region_model.size_decoder.fc2",
+    }
+    out = {}
+    for k, v in sd.items():
+        if k == "vision.pos_emb":
+            out["vision_encoder.encoder.model.visual.pos_embed"] = v
+        elif k == "text.wte":
+            out["text_model.transformer.embd.wte.weight"] = v
+        elif k == "region.coord_features":
+            out["region_model.coordinate_features.weight"] = v.T.contiguous()
+        elif k == "region.size_features":
+            out["region_model.size_features.weight"] = v.T.contiguous()
+        elif k.startswith("vision.blocks."):
+            i, rest = k[len("vision.blocks."):].split(".", 1)
+            rest = rest.replace("ln1", "norm1").replace("ln2", "norm2")
+            out[f"vision_encoder.encoder.model.visual.blocks.{i}.{rest}"] = v
+        elif k.startswith("text.blocks."):
+            i, rest = k[len("text.blocks."):].split(".", 1)
+            rest = rest.replace("attn.qkv", "mixer.Wqkv").replace("attn.proj", "mixer.out_proj")
+            out[f"text_model.transformer.h.{i}.{rest}"] = v
+        else:
+            for new, old in pre.items():
+                if k.startswith(new + "."):
+                    out[old + k[len(new):]] = v
+                    break
+            else:
+                raise AssertionError(f"unmapped key {k}")
+    return out
+
+
+def _same(a, b):
+    assert set(a) == set(b), (sorted(set(a) ^ set(b))[:8])
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k].cpu(), b[k].cpu()), k
+
+
+def test_checkpoint_layouts_and_containers(tmp_path):
+    from safetensors.torch import save_file
+
+    cfg = get_config("tiny")
+    sd = {k: v.contiguous() for k, v in synth.synthetic_state_dict(cfg, seed=3).items()}
+    # module-tree layout, "model." prefix, safetensors
+    p1 = os.path.join(tmp_path, "a.safetensors")
+    save_file({"model." + k: v for k, v in sd.items()}, p1)
+    _same(load_state_dict_file(p1), sd)
+    # legacy layout with torch.compile's infix, safetensors
+    legacy = _to_legacy(sd)
+    p2 = os.path.join(tmp_path, "b.safetensors")
+    save_file({k.replace("visual.blocks", "visual._orig_mod.blocks"): v for k, v in legacy.items()}, p2)
+    _same(load_state_dict_file(p2), sd)
+    # legacy layout, torch container
+    p3 = os.path.join(tmp_path, "c.pt")
+    torch.save(legacy, p3)
+    _same(load_state_dict_file(p3), sd)

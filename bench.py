@@ -209,6 +209,18 @@ def main():
 
     if rank != 0:
         return
+    # HBM-side bytes per tile-GEMM launch from the committed PMC passes over this command's eager step
+    # (tools/gpu_pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950
+    # note in MI355X_MICROARCH.md; WRITE_SIZE uncalibrated).  bench.py cannot collect counters on itself.
+    traffic, traffic_note = None, "no profiles/r01_pmc_traffic.json"
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+            tg = json.load(f)["tile_gemm"]
+        traffic = (2.0 * tg["FETCH_SIZE_kb_sum"] + tg["WRITE_SIZE_kb_sum"]) * 1024.0 / tg["launches"]
+        traffic_note = ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) / launches from profiles/r01_pmc_traffic.json "
+                        "(rocprofv3 --pmc passes over one eager bench step, B=64)")
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
     result = {
         "metric": "images_per_sec",
         "value": n_total * args.steps / elapsed,
@@ -236,7 +248,8 @@ def main():
             "peak": 2500.0,
             "unit": "TFLOP/s",
             "frac": gemm_tflops / 2500.0,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": traffic_note,
             "launches": int(n.value),
             "share_of_step": (ms.value * 1e-3) / step_gpu_s if step_gpu_s > 0 else None,
             "measured_on": "one non-overlapped, eagerly launched step after the timed region",

@@ -243,7 +243,7 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)",
+            "kernel": "gemm_bf16_kernel<256,256,...> tile GEMM, alternating wave groups (v_mfma_f32_32x32x16_bf16)",
             "achieved": gemm_tflops,
             "peak": 2500.0,
             "unit": "TFLOP/s",
@@ -255,7 +255,7 @@ def main():
             "measured_on": "one non-overlapped, eagerly launched step after the timed region",
         },
         "decode_gemm": {
-            "bound": "hbm", "kernel": "gemm_bf16_kernel<64,64> decode-regime config (m <= 64 weight stream, split-K where N is small)",
+            "bound": "hbm", "kernel": "gemm_bf16_kernel / gemm_pair_kernel <64,64> decode-regime configs (m <= 64 weight stream; proj+fc2 as K-slice partials)",
             "achieved": stream_gbs if n1.value else None, "peak": 8000.0, "unit": "GB/s",
             "frac": stream_gbs / 8000.0 if n1.value else None, "launches": int(n1.value),
             "share_of_step": (ms1.value * 1e-3) / step_gpu_s if step_gpu_s > 0 and n1.value else None,

@@ -120,8 +120,11 @@ class MoondreamModel:
         """Zeroed KV slabs [L][B][H_kv][ctx][hd] (reference: moondream.py:62-72,152-162)."""
         t = self.config.text
         b = max(1, int(max_batch or self._max_batch or 1))
-        self._kv_k = torch.zeros(t.n_layers, b, t.n_kv_heads, t.max_context, t.head_dim, dtype=BF16, device=self._device)
-        self._kv_v = torch.zeros_like(self._kv_k)
+        # ordinary (non-inference) tensors even when a generate call grows the slabs from inside
+        # torch.inference_mode(): load_encoded_image updates them in place from user code
+        with torch.inference_mode(False):
+            self._kv_k = torch.zeros(t.n_layers, b, t.n_kv_heads, t.max_context, t.head_dim, dtype=BF16, device=self._device)
+            self._kv_v = torch.zeros_like(self._kv_k)
         self._max_batch = b
         self._graphs.clear()
 
@@ -374,9 +377,10 @@ class MoondreamModel:
     def load_encoded_image(self, encoded_image: EncodedImage, slot: int = 0):
         """reference: moondream.py:620-623."""
         self._ensure_batch(slot + 1)
-        for l, (k, v) in enumerate(encoded_image.caches):
-            self._kv_k[l, slot : slot + 1, :, : k.size(2), :] = k
-            self._kv_v[l, slot : slot + 1, :, : v.size(2), :] = v
+        with torch.inference_mode():
+            for l, (k, v) in enumerate(encoded_image.caches):
+                self._kv_k[l, slot : slot + 1, :, : k.size(2), :] = k
+                self._kv_v[l, slot : slot + 1, :, : v.size(2), :] = v
 
     # --------------------------------------------------------------- sampling
     def _apply_top_p(self, probs: torch.Tensor, top_p: float) -> torch.Tensor:
@@ -457,7 +461,10 @@ class MoondreamModel:
         chunk = max(1, min(check_every or 16, max_tokens))
         while steps < max_tokens:
             n = min(chunk, max_tokens - steps)
-            key = ("decode", b, slot0, n, suppress_id, ws.data_ptr(), self._kv_k.data_ptr())
+            # a graph is replayed only on the stream (context) it was captured for: the pipelined engine's
+            # decode stream and the default stream each keep their own captures
+            key = ("decode", b, slot0, n, suppress_id, ws.data_ptr(), self._kv_k.data_ptr(), logits.data_ptr(),
+                   torch.cuda.current_stream(self._device).cuda_stream)
             entry = self._graphs.get(key)
             if entry is None:
                 buf = torch.zeros(n + 1, b, dtype=torch.int32, device=self._device)

@@ -107,6 +107,19 @@ def test_batched_equals_sequential_and_reference(tiny):
         assert batched[i] == model.batch_generate_ids([images[i]], [prompts[i]], max_tokens=n)[0]
 
 
+def test_decode_steps_over_more_than_64_sequences(tiny):
+    """> 64 sequences per decode step run as blocks of 64 through the decode-regime kernels
+    (md_text_forward); every sequence must still produce the reference's ids."""
+    g, cfg, sd, model = tiny
+    n_seq = 70
+    images = [golden_image(g, i % 3) for i in range(n_seq)]
+    prompts = [g[f"img{i % 3}.cap.prompt"].tolist() for i in range(n_seq)]
+    n = len(g["img0.cap.tokens"])
+    out = model.batch_generate_ids(images, prompts, max_tokens=n)
+    for i in range(n_seq):
+        assert out[i] == g[f"img{i % 3}.cap.tokens"].tolist(), i
+
+
 def test_hipgraph_decode_equals_eager(tiny):
     """compile() replays the device-resident decode steps from a captured hipGraph:
     same ids as the eager path, on first use (capture) and on replay."""

@@ -45,7 +45,36 @@ def parse():
     ap.add_argument("--prompt", choices=["caption", "vqa32"], default="caption",
                     help="caption: the 5-id caption template; vqa32: 32-id seeded question prompts (SURVEY 8d)")
     ap.add_argument("--no-vqa-leg", action="store_true", help="skip the auxiliary 32-token-prompt measurement")
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="only exercise the launch + collective plumbing (gloo on a CPU-only box) and print a JSON line")
     return ap.parse_args()
+
+
+def selftest_dist(args):
+    """The N>1 plumbing without a model: rendezvous, flat broadcast, id gather, barrier, max-over-ranks.
+    Runs over gloo where there is no GPU (tests/test_dist_cpu.py drives `bench.py --gpus 2 --selftest-dist`)."""
+    from moondream_amd import dist as mdist
+
+    rank, world, local = mdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    full = {"w": torch.arange(24, dtype=torch.float32).reshape(4, 6).to(torch.bfloat16)} if rank == 0 else None
+    obj = [mdist.state_dict_template(full) if rank == 0 else None]
+    if world > 1:
+        torch.distributed.broadcast_object_list(obj, src=0)
+    sd = mdist.broadcast_state_dict(full, obj[0], dev)
+    assert sd["w"].float().sum().item() == 276.0
+    mine = mdist.shard_range(3 * world + 1, rank, world)
+    ids = torch.tensor([[i, i + 1] for i in mine], dtype=torch.int32, device=dev).reshape(len(mine), 2)
+    blocks = mdist.gather_token_ids(ids)
+    mdist.barrier()
+    t = mdist.max_over_ranks(float(rank), dev)
+    if rank == 0:
+        got = torch.cat([b.cpu() for b in blocks], 0)[:, 0].tolist()
+        assert got == list(range(3 * world + 1)), got
+        print(json.dumps({"selftest": "dist", "n_gpus": world, "max_rank": t, "items": len(got)}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def cpu_baseline(cfg, sd, seed, T, budget_s=20.0):
@@ -120,7 +149,15 @@ def cpu_baseline(cfg, sd, seed, T, budget_s=20.0):
 
 def main():
     args = parse()
-    from moondream_amd import _lib, synth, dist as mdist
+    from moondream_amd import dist as mdist
+
+    # `python bench.py --gpus N` with no launcher: become N ranks under torch.distributed.run
+    rc = mdist.relaunch_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
+    if args.selftest_dist:
+        return selftest_dist(args)
+    from moondream_amd import _lib, synth
     from moondream_amd.config import get_config
     from moondream_amd.moondream import MoondreamModel, IdTokenizer
 

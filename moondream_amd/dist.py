@@ -40,6 +40,32 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(n_procs: int, script: str, argv: Sequence[str]) -> Optional[int]:
+    """``python bench.py --gpus N`` without a launcher: when N > 1 and no torchrun
+    environment is present, re-run ``script`` as N ranks of ONE node under
+    ``python -m torch.distributed.run`` (rendezvous on 127.0.0.1, a free port) and return
+    the child's exit code; returns None when no relaunch is needed (N == 1, or this
+    process already is a rank: WORLD_SIZE is set).  One process per GPU either way."""
+    if n_procs <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
+    return subprocess.call(cmd, env=env)
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous block of items for ``rank`` (sizes differ by at most one)."""
     base, rem = divmod(n_items, world)

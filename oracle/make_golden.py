@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [0.5b] [2b]
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [0.5b] [2b] [bench64]
 """
 from __future__ import annotations
 
@@ -360,6 +360,57 @@ def gen_textonly(name="tiny_textonly", cfg_name="tiny", seed=1, n_cases=3, max_t
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
 
 
+def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tokens=32):
+    """The TIMED configuration (BASELINE.json configs[2]): the reference itself on the exact 64
+    seed-1 378x378 images and caption prompt that bench.py times, Moondream-2B, greedy, 32 tokens.
+    No survivorship filter: every image is kept, with the reference's top-1/top-2 margin of every
+    decision, so bench.py / the GPU tests can compare the batched HIP ids margin-aware
+    (reference: moondream.py:434-539 behind caption(), moondream.py:625-651).  Also records the
+    reference's own CPU wall-clock per image (sample.py:159-207 style) -> profiles/."""
+    import json
+
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    caption_ids = cfg.tokenizer.templates["caption"]["normal"]
+    toks, margins, top_v, top_i, t_enc, t_gen = [], [], [], [], [], []
+    for i in range(n_images):
+        image = synth.synthetic_image_array(i, seed, (378, 378))
+        r = run_reference_caption(model, ref_md, image, caption_ids, max_tokens)
+        assert len(r["tokens"]) == max_tokens, (i, len(r["tokens"]))  # no EOS inside the window
+        toks.append(r["tokens"])
+        margins.append(r["margins"])
+        top = torch.topk(torch.stack(r["steps"]).float(), 8, dim=-1)
+        top_v.append(top.values.numpy())
+        top_i.append(top.indices.numpy().astype(np.int32))
+        t_enc.append(r["t_enc"])
+        t_gen.append(r["t_gen"])
+        print(f"[{name}] image {i}: min margin {min(r['margins']):.4f} encode {r['t_enc']:.2f}s gen {r['t_gen']:.2f}s", flush=True)
+    out = {
+        "seed": np.int64(seed), "cfg": np.array(cfg_name), "prompt": np.array(caption_ids),
+        "tokens": np.array(toks, dtype=np.int32), "margins": np.array(margins, dtype=np.float32),
+        "top8_val": np.array(top_v, dtype=np.float32), "top8_idx": np.array(top_i, dtype=np.int32),
+    }
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
+    timing = {
+        "what": "unmodified /root/reference moondream/torch (tokenizer stub + seeded synthetic weights), Moondream-2B bf16, "
+                "B=1 sequential, 378x378 synthetic images, caption prompt, greedy, 32 tokens; wall clock (time.perf_counter) "
+                "around encode_image and around the _generate_answer generator",
+        "host": {"cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "torch": torch.__version__},
+        "images": n_images,
+        "encode_s_p50": float(np.median(t_enc[1:])), "generate_s_p50": float(np.median(t_gen[1:])),
+        "images_per_sec": float(1.0 / (np.median(t_enc[1:]) + np.median(t_gen[1:]))),
+        "encode_s": [round(x, 3) for x in t_enc], "generate_s": [round(x, 3) for x in t_gen],
+        "note": "image 0 is the warm-up and is excluded from the medians",
+    }
+    prof = os.path.join(REPO, "profiles", "r02_reference_cpu_timing_build_container.json")
+    with open(prof, "w") as f:
+        json.dump(timing, f, indent=1)
+    print(f"[{name}] wrote {prof}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -375,6 +426,8 @@ def main():
         gen_textonly()
     if "0.5b" in which:
         gen_model_case("md05b_seed1", "0.5b", 1, [(378, 378)], 32, False, n_images=2, min_margin=0.5)
+    if "bench64" in which:
+        gen_bench64()
     if "2b" in which:
         gen_model_case("md2b_seed1", "2b", 1, [(378, 378)], 32, False, n_images=3, min_margin=0.5)
 

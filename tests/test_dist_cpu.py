@@ -60,3 +60,28 @@ def test_world_size_2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def test_bench_self_launches_n2_without_torchrun():
+    """`python bench.py --gpus 2` with no launcher in front of it (what the driver runs) must
+    re-exec itself as 2 ranks under torch.distributed.run and print ONE JSON line with n_gpus 2;
+    --selftest-dist limits the run to the launch + collective plumbing (gloo on this CPU-only box)."""
+    import json
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest-dist"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["items"] == 7 and d["max_rank"] == 1.0
+
+
+def test_relaunch_is_a_noop_inside_a_rank_and_for_one_gpu(monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert mdist.relaunch_under_torchrun(1, "bench.py", []) is None
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert mdist.relaunch_under_torchrun(2, "bench.py", []) is None

@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ 
         best = sv[w];
         bi = si[w];
       }
-    next[b] = bi;
+    // an all-NaN row selects nothing: fall back to id 0 rather than an out-of-range id that the
+    // next md_embed_tokens would use as a table index
+    next[b] = (bi >= vocab) ? 0 : bi;
     if (pos_inc) pos_inc[b] += 1;
   }
 }

@@ -57,18 +57,33 @@ class IdTokenizer:
             self.ids = ids
 
     def encode(self, s: str):
-        return self._Enc([int(t) for t in s.split()])
+        try:
+            return self._Enc([int(t) for t in s.split()])
+        except ValueError:
+            raise ValueError(
+                "IdTokenizer only understands space-separated token ids; load the real vocabulary "
+                "(tokenizers.Tokenizer 'moondream/starmie-v1') and pass it as tokenizer= for text prompts"
+            ) from None
 
     def decode(self, ids: Iterable[int]) -> str:
         return "".join(f"{int(i)} " for i in ids)
 
 
 def _load_tokenizer():
+    """The reference loads ``moondream/starmie-v1`` from the Hub (moondream.py:89).  Offline that
+    fails; the id-echo stand-in is then used, LOUDLY: with it, prompts and outputs are token ids."""
     try:
         from tokenizers import Tokenizer
 
         return Tokenizer.from_pretrained("moondream/starmie-v1")
-    except Exception:
+    except Exception as e:  # no network / no cache
+        import warnings
+
+        warnings.warn(
+            f"could not load the 'moondream/starmie-v1' vocabulary ({type(e).__name__}); falling back to IdTokenizer: "
+            "text prompts must be space-separated token ids and answers come back as ids.  Pass tokenizer= to avoid this.",
+            RuntimeWarning, stacklevel=3,
+        )
         return IdTokenizer()
 
 
@@ -120,11 +135,20 @@ class MoondreamModel:
         """Zeroed KV slabs [L][B][H_kv][ctx][hd] (reference: moondream.py:62-72,152-162)."""
         t = self.config.text
         b = max(1, int(max_batch or self._max_batch or 1))
+        old_k, old_v = self._kv_k, self._kv_v
+        if old_k is not None:
+            # growing: work queued on the pipelined engine's streams may still use the old slabs,
+            # arenas and captured graphs
+            torch.cuda.synchronize(self._device)
         # ordinary (non-inference) tensors even when a generate call grows the slabs from inside
         # torch.inference_mode(): load_encoded_image updates them in place from user code
         with torch.inference_mode(False):
             self._kv_k = torch.zeros(t.n_layers, b, t.n_kv_heads, t.max_context, t.head_dim, dtype=BF16, device=self._device)
             self._kv_v = torch.zeros_like(self._kv_k)
+            if old_k is not None:  # slots loaded earlier (load_encoded_image) survive the growth
+                keep = min(b, old_k.shape[1])
+                self._kv_k[:, :keep] = old_k[:, :keep]
+                self._kv_v[:, :keep] = old_v[:, :keep]
         self._max_batch = b
         self._graphs.clear()
 
@@ -218,9 +242,24 @@ class MoondreamModel:
             self._text_causal = st
         return st
 
-    def _text_forward(self, x: torch.Tensor, pos0: torch.Tensor, slot0: int = 0, causal: bool = False) -> torch.Tensor:
-        """x [B,T,D] embeddings -> hidden [B,T,D]; K,V written at pos0[b]..pos0[b]+T-1."""
+    def _text_forward(self, x: torch.Tensor, pos0: Union[int, Sequence[int]], slot0: int = 0, causal: bool = False) -> torch.Tensor:
+        """x [B,T,D] embeddings -> hidden [B,T,D]; K,V written at pos0[b]..pos0[b]+T-1.
+        ``pos0`` is host data (one int for the whole batch or one per sequence): the slab has
+        max_context slots per head and the kernels do not bounds-check, so the check is here
+        (the reference fails at this point too: its index_put / mask indexing raises)."""
         b, t, d = x.shape
+        hi = pos0 if isinstance(pos0, int) else max(int(p) for p in pos0)
+        lo = pos0 if isinstance(pos0, int) else min(int(p) for p in pos0)
+        if lo < 0 or hi + t > self.config.text.max_context:
+            raise ValueError(
+                f"positions [{lo}, {hi + t}) do not fit the {self.config.text.max_context}-slot context "
+                "(image prefix + prompt + generated tokens)"
+            )
+        if isinstance(pos0, int):
+            pos0 = torch.full((b,), pos0, dtype=torch.int32, device=self._device)
+        else:
+            assert len(pos0) == b
+            pos0 = torch.tensor([int(p) for p in pos0], dtype=torch.int32, device=self._device)
         text = self._causal_text_struct() if causal else self.w.text
         self._ensure_batch(slot0 + b)
         x = x.contiguous()
@@ -256,8 +295,7 @@ class MoondreamModel:
         """reference: moondream.py:174-181.  x [1,T,D]; pos_ids int64 [T] consecutive."""
         if lora is not None:
             raise NotImplementedError("LoRA variants are not on the native path")
-        pos0 = torch.tensor([int(pos_ids[0])], dtype=torch.int32, device=self._device)
-        return self._text_forward(x.to(self._device), pos0, 0)
+        return self._text_forward(x.to(self._device), int(pos_ids[0]), 0)
 
     def _decode_one_tok(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, lora=None):
         """reference: moondream.py:183-192.  x [1,1,D] -> (logits [1,V], hidden [1,1,D])."""
@@ -267,6 +305,10 @@ class MoondreamModel:
     # ------------------------------------------------------------ vision path
     def _embed(self, ids: torch.Tensor) -> torch.Tensor:
         """token ids [..] -> embeddings [.., D]  (reference: text.py:12-13)."""
+        if ids.device.type == "cpu" and ids.numel():  # user-supplied prompt ids: the gather kernel does not range-check
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.config.text.vocab_size:
+                raise ValueError(f"token id out of range [0, {self.config.text.vocab_size}): {lo if lo < 0 else hi}")
         flat = ids.reshape(-1).to(device=self._device, dtype=torch.int32).contiguous()
         d = self.config.text.dim
         out = torch.empty(flat.numel(), d, dtype=BF16, device=self._device)
@@ -353,8 +395,7 @@ class MoondreamModel:
         b = img_emb.shape[0]
         bos = self._embed(torch.full((b, 1), self.config.tokenizer.bos_id, dtype=torch.int32))
         x = torch.cat([bos, img_emb], dim=1)
-        pos0 = torch.zeros(b, dtype=torch.int32, device=self._device)
-        self._text_forward(x, pos0, slot0)
+        self._text_forward(x, 0, slot0)
         return x.shape[1]
 
     def encode_image(self, image: Union[Image.Image, EncodedImage], settings: Optional[dict] = None) -> EncodedImage:
@@ -413,19 +454,22 @@ class MoondreamModel:
         b = len(prompts)
         ids = torch.tensor(prompts, dtype=torch.int32)
         x = self._embed(ids) if prompt_embs is None else prompt_embs
-        pos0 = torch.full((b,), pos, dtype=torch.int32, device=self._device)
-        hidden = self._text_forward(x, pos0, slot0)
+        hidden = self._text_forward(x, pos, slot0)
         return self._lm_head(hidden), hidden, pos + ids.shape[1]
 
-    def _decode_greedy(self, first: torch.Tensor, pos: int, max_tokens: int, suppress_id: int, slot0: int = 0,
-                       eos_id: Optional[int] = None, check_every: int = 16) -> torch.Tensor:
+    def _decode_greedy(self, first: torch.Tensor, pos: Union[int, Sequence[int]], max_tokens: int, suppress_id: int,
+                       slot0: int = 0, eos_id: Optional[int] = None, check_every: int = 16) -> torch.Tensor:
         """Device-resident greedy loop: returns int32 [steps+1, B] (row 0 = ``first``).
         reference: the generator of moondream.py:471-530 without its per-token host sync.
+        ``pos`` is the position of the next token, one int or one per sequence (sequences whose
+        prompts differ in length decode in the same lockstep batch).
         With ``compile()`` the steps are replayed from a captured hipGraph in chunks."""
         b = first.shape[0]
         t = self.config.text
         self._ensure_batch(slot0 + b)
-        max_tokens = max(0, min(max_tokens, t.max_context - 1 - pos))
+        pos_list = [int(pos)] * b if isinstance(pos, int) else [int(p) for p in pos]
+        assert len(pos_list) == b
+        max_tokens = max(0, min(max_tokens, t.max_context - 1 - max(pos_list)))
         hist = torch.zeros(max_tokens + 1, b, dtype=torch.int32, device=self._device)
         hist[0] = first
         if max_tokens == 0:
@@ -434,6 +478,7 @@ class MoondreamModel:
         need = self.lib.md_decode_workspace_bytes(C.byref(self.w.text), b)
         ws = self._workspace(need, 2)
         kv = self._kv_struct(slot0)
+        pos_base = torch.tensor(pos_list, dtype=torch.int32, device=self._device)
 
         def one_step(tok_in, tok_out, pos_buf):
             _lib.check(
@@ -449,7 +494,7 @@ class MoondreamModel:
 
         steps = 0
         if not self.use_graphs:
-            pos_t = torch.full((b,), pos, dtype=torch.int32, device=self._device)
+            pos_t = pos_base.clone()
             while steps < max_tokens:
                 one_step(hist[steps], hist[steps + 1], pos_t)
                 steps += 1
@@ -472,7 +517,7 @@ class MoondreamModel:
                 # eager warm-up on scratch state is not possible (KV side effects), so the
                 # first chunk of a new shape runs eagerly and the graph is captured afterwards
                 buf[0] = hist[steps]
-                pos_buf.fill_(pos + steps)
+                pos_buf.copy_(pos_base + steps)
                 for i in range(n):
                     one_step(buf[i], buf[i + 1], pos_buf)
                 hist[steps + 1 : steps + n + 1] = buf[1:]
@@ -486,7 +531,7 @@ class MoondreamModel:
             else:
                 g, buf, pos_buf = entry
                 buf[0] = hist[steps]
-                pos_buf.fill_(pos + steps)
+                pos_buf.copy_(pos_base + steps)
                 g.replay()
                 hist[steps + 1 : steps + n + 1] = buf[1:]
             steps += n
@@ -539,39 +584,57 @@ class MoondreamModel:
                 e.record(torch.cuda.current_stream(self._device))
                 marks.append((name, e))
 
+        # Sequences are placed in KV slots in order of prompt length (stable), so that every group of
+        # equal-length prompts occupies a contiguous slot range: one prompt prefill per distinct
+        # length, then ONE lockstep decode over all B sequences with per-sequence positions.
+        order = sorted(range(b), key=lambda i: len(prompts[i]))
+        images = [images[i] for i in order]
+        prompts = [list(prompts[i]) for i in order]
+        if any(len(p) == 0 for p in prompts):
+            raise ValueError("empty prompt")
         with torch.inference_mode():
             self._ensure_batch(b)
-            raw = [im for im in images if not isinstance(im, EncodedImage)]
+            raw_idx = [i for i, im in enumerate(images) if not isinstance(im, EncodedImage)]
             mark("start")
-            if len(raw) == b:
-                img_emb = self._run_vision_encoder_batch(raw)
+            pos = None
+            if raw_idx:
+                img_emb = self._run_vision_encoder_batch([images[i] for i in raw_idx])
                 mark("vision")
-                pos = self._prefill_images(img_emb, 0)
+                # every run of consecutive raw images is prefilled straight into its own slots
+                j = 0
+                while j < len(raw_idx):
+                    k = j
+                    while k + 1 < len(raw_idx) and raw_idx[k + 1] == raw_idx[k] + 1:
+                        k += 1
+                    pos = self._prefill_images(img_emb[j : k + 1], raw_idx[j])
+                    j = k + 1
                 mark("image_prefill")
-            else:
-                pos = None
-                for i, im in enumerate(images):
-                    enc = self.encode_image(im)
-                    self.load_encoded_image(enc, i)
-                    pos = enc.pos
-            lens = {len(p) for p in prompts}
+            for i, im in enumerate(images):
+                if isinstance(im, EncodedImage):
+                    if pos is not None and im.pos != pos:
+                        raise ValueError("EncodedImage with a different prefix length than the rest of the batch")
+                    self.load_encoded_image(im, i)
+                    pos = im.pos
+            first = torch.empty(b, dtype=torch.int32, device=self._device)
+            next_pos = [0] * b
+            g0 = 0
+            while g0 < b:  # one prefill per distinct prompt length
+                g1 = g0
+                while g1 < b and len(prompts[g1]) == len(prompts[g0]):
+                    g1 += 1
+                logits, _, p1 = self._prefill_prompts(prompts[g0:g1], pos, g0)
+                first[g0:g1] = self._pick(logits, 0.0, 0.0)
+                next_pos[g0:g1] = [p1] * (g1 - g0)
+                g0 = g1
+            mark("prompt_prefill")
+            stop = None if ignore_eos else eos
+            hist = self._decode_greedy(first, next_pos if len(set(next_pos)) > 1 else next_pos[0], max_tokens,
+                                       tk.answer_id, 0, stop)
+            mark("decode")
+            cols = hist.t().tolist()
             results: List[Optional[List[int]]] = [None] * b
-            if len(lens) == 1:
-                logits, _, p1 = self._prefill_prompts(prompts, pos, 0)
-                first = self._pick(logits, 0.0, 0.0)
-                mark("prompt_prefill")
-                hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, 0, None if ignore_eos else eos)
-                mark("decode")
-                cols = hist.t().tolist()
-                for i in range(b):
-                    results[i] = self._truncate(cols[i], None if ignore_eos else eos, max_tokens)
-            else:
-                # ragged prompts: one lockstep group per distinct length over contiguous slots
-                for i in range(b):
-                    logits, _, p1 = self._prefill_prompts([prompts[i]], pos, i)
-                    first = self._pick(logits, 0.0, 0.0)
-                    hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, i, None if ignore_eos else eos)
-                    results[i] = self._truncate(hist[:, 0].tolist(), None if ignore_eos else eos, max_tokens)
+            for slot, src in enumerate(order):
+                results[src] = self._truncate(cols[slot], stop, max_tokens)
         if self.collect_timing and len(marks) > 1:
             torch.cuda.synchronize(self._device)
             self.last_phase_ms = {marks[i][0]: marks[i - 1][1].elapsed_time(marks[i][1]) for i in range(1, len(marks))}
@@ -674,8 +737,7 @@ class MoondreamModel:
                 emb[ids.to(self._device) == self.config.tokenizer.coord_id] = enc["coords"]
                 if enc["sizes"] is not None:
                     emb[ids.to(self._device) == self.config.tokenizer.size_id] = enc["sizes"]
-            pos0 = torch.full((1,), pos, dtype=torch.int32, device=self._device)
-            hidden = self._text_forward(emb, pos0, 0, causal=causal)
+            hidden = self._text_forward(emb, pos, 0, causal=causal)
             logits = self._lm_head(hidden)
             nxt = self._pick(logits, temperature, top_p)
         return logits, hidden, nxt.reshape(1, 1), pos + ids.shape[1]
@@ -716,10 +778,11 @@ class MoondreamModel:
                 cur_pos = pos
                 while True:
                     yield int(tok[0])
+                    if cur_pos >= self.config.text.max_context:  # context full: same bound as the greedy loop
+                        return
                     with torch.inference_mode():
                         emb = self._embed(tok.reshape(1, 1))
-                        p0 = torch.full((1,), cur_pos, dtype=torch.int32, device=self._device)
-                        hidden = self._text_forward(emb, p0, 0)
+                        hidden = self._text_forward(emb, cur_pos, 0)
                         logits = self._lm_head(hidden)
                         logits[:, self.config.tokenizer.answer_id] = float("-inf")
                         cur_pos += 1
@@ -865,8 +928,7 @@ class MoondreamModel:
 
         def step(emb):
             nonlocal pos
-            p0 = torch.full((1,), pos, dtype=torch.int32, device=self._device)
-            h = self._text_forward(emb.reshape(1, 1, -1), p0, 0)
+            h = self._text_forward(emb.reshape(1, 1, -1), pos, 0)
             pos += 1
             return h
 

@@ -411,6 +411,147 @@ def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tok
     print(f"[{name}] wrote {prof}", flush=True)
 
 
+def gen_detect(name="tiny_detect", cfg_name="tiny", seed=1, n_cases=2, max_objects=3, min_margin=4.0):
+    """Region head + points loop through the reference's own public ``detect`` / ``point``
+    (moondream.py:735-829 -> _generate_points moondream.py:653-733 -> region.py:12-93), with taps on
+    the four region functions: every call's input, output and (for the decoders) the top-1/top-2
+    margin of each argmax IN BF16 ULPS of the top logit.  With i.i.d. synthetic weights the 1024-bin
+    heads separate their best two bins by a few ulps only, so: a case is kept when every decision of
+    its FIRST object (x, y, w, h bins and the next token) has margin >= min_margin ulps, all margins
+    are recorded, and consumers compare objects up to the first narrow decision.  Also one ``query`` with spatial_refs (region.py:96-136 +
+    moondream.py:293-301: coordinate / size embeddings injected into the prompt)."""
+    import moondream.torch.moondream as ref_md_mod
+    from PIL import Image
+
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    out = {"seed": np.int64(seed), "cfg": np.array(cfg_name), "max_objects": np.int64(max_objects), "object_ids": np.array([7, 8])}
+    names = ("decode_coordinate", "encode_coordinate", "decode_size", "encode_size")
+    orig = {n: getattr(ref_md, n) for n in names}
+    orig_decode_tok = model._decode_one_tok
+
+    def run(kind, image):
+        rec = {n: [] for n in names}
+        rec["next_logits"] = []
+
+        def tap(n):
+            def f(x, w):
+                y = orig[n](x, w)
+                rec[n].append((x.detach().clone(), y.detach().clone()))
+                return y
+            return f
+
+        def decode_tok_tap(x, mask, pos_ids, lora):
+            logits, hidden = orig_decode_tok(x, mask, pos_ids, lora)
+            rec["next_logits"].append(logits[0].detach().clone())
+            return logits, hidden
+
+        for n in names:
+            setattr(ref_md, n, tap(n))
+        model._decode_one_tok = decode_tok_tap
+        try:
+            fn = model.detect if kind == "detect" else model.point
+            # "variant": None -- the reference's encode_image indexes settings["variant"] (moondream.py:241-243)
+            res = fn(Image.fromarray(image, "RGB"), "7 8", settings={"max_objects": max_objects, "variant": None})
+        finally:
+            for n in names:
+                setattr(ref_md, n, orig[n])
+            model._decode_one_tok = orig_decode_tok
+        return res, rec
+
+    def margin(lg):
+        """top-1/top-2 gap in units of the bf16 spacing at the top logit (8 significand bits)."""
+        top = torch.topk(lg.float().reshape(-1), 2).values
+        ulp = 2.0 ** (np.floor(np.log2(max(abs(float(top[0])), 2.0 ** -120))) - 7)
+        return float(top[0] - top[1]) / ulp
+
+    for kind in ("detect", "point"):
+        kept, src = 0, -1
+        while kept < n_cases:
+            src += 1
+            assert src < 400, "could not find enough wide-margin detect cases"
+            image = synth.synthetic_image_array(src, seed, (378, 378))
+            res, rec = run(kind, image)
+            objs = res["objects" if kind == "detect" else "points"]
+            # decisions in loop order: per object x, y, (w, h,) next-token
+            per_obj = 3 if kind == "detect" else 2  # _decode_one_tok calls per object; the last decides the next token
+            nxt = rec["next_logits"][per_obj - 1 :: per_obj]
+            margins = []
+            for k in range(len(objs)):
+                margins += [margin(rec["decode_coordinate"][2 * k][1]), margin(rec["decode_coordinate"][2 * k + 1][1])]
+                if kind == "detect":
+                    sz = rec["decode_size"][k][1]
+                    margins += [margin(sz[0]), margin(sz[1])]
+                margins.append(margin(nxt[k]))
+            per_dec = len(margins) // max(1, len(objs))
+            # with i.i.d. synthetic weights the 1024-bin heads have top-1/top-2 gaps of a few bf16 ulps on
+            # most decisions; keep images whose FIRST object (all its decisions) is wide-margin and record
+            # every margin, so consumers compare objects up to the first narrow decision
+            if len(objs) == 0 or min(margins[:per_dec]) < min_margin:
+                print(f"[{name}] {kind}: skip image {src}: {len(objs)} objects, first-object min margin {min(margins[:per_dec]) if margins else 0:.3f}", flush=True)
+                continue
+            pfx = f"{kind}{kept}."
+            out[pfx + "image_index"] = np.int64(src)
+            keys = ("x_min", "y_min", "x_max", "y_max") if kind == "detect" else ("x", "y")
+            out[pfx + "objects"] = np.array([[o[k] for k in keys] for o in objs], dtype=np.float64)
+            out[pfx + "margins"] = np.array(margins, dtype=np.float32).reshape(len(objs), per_dec)
+            out[pfx + "next_tokens"] = np.array([int(torch.argmax(l.float())) for l in nxt])
+            for n in names:
+                if rec[n]:
+                    out[pfx + n + ".in"] = bf16_bits(torch.stack([x.reshape(-1) for x, _ in rec[n]]))
+                    out[pfx + n + ".out"] = bf16_bits(torch.stack([y.reshape(-1) for _, y in rec[n]]))
+            print(f"[{name}] {kind}{kept}: image {src} -> {len(objs)} objects, min margin {min(margins):.3f}: {objs[0]}", flush=True)
+            kept += 1
+
+    # query with spatial refs: a point and a box
+    refs = [(0.25, 0.5), (0.125, 0.25, 0.625, 0.75)]
+    kept, src = 0, -1
+    while kept < 1:
+        src += 1
+        assert src < 200
+        image = synth.synthetic_image_array(src, seed, (378, 378))
+        rec = {"decode_logits": []}
+        orig_lm_head = ref_md.lm_head
+
+        def decode_tap(x, mask, pos_ids, lora):
+            logits, hidden = orig_decode_tok(x, mask, pos_ids, lora)
+            rec["decode_logits"].append(logits[0].clone())
+            return logits, hidden
+
+        def lm_head_tap(h, w):
+            o = orig_lm_head(h, w)
+            rec.setdefault("prompt_logits", o[0].clone())
+            return o
+
+        model._decode_one_tok, ref_md.lm_head = decode_tap, lm_head_tap
+        try:
+            ans = model.query(Image.fromarray(image, "RGB"), "11 12 13", spatial_refs=refs,
+                              settings={"temperature": 0, "max_tokens": 10, "variant": None})["answer"]
+        finally:
+            model._decode_one_tok, ref_md.lm_head = orig_decode_tok, orig_lm_head
+        steps = [rec["prompt_logits"]]
+        for lg in rec["decode_logits"]:
+            lg = lg.clone()
+            lg[cfg.tokenizer.answer_id] = float("-inf")
+            steps.append(lg)
+        margins = [margin(l) for l in steps]
+        if min(margins) < min_margin:
+            print(f"[{name}] spatial query: skip image {src}: min margin {min(margins):.3f}", flush=True)
+            continue
+        out["spatial.image_index"] = np.int64(src)
+        out["spatial.refs_point"] = np.array(refs[0])
+        out["spatial.refs_box"] = np.array(refs[1])
+        out["spatial.question"] = np.array([11, 12, 13])
+        out["spatial.tokens"] = np.array([int(t) for t in ans.split()])
+        out["spatial.margins"] = np.array(margins, dtype=np.float32)
+        print(f"[{name}] spatial query: image {src} -> {ans} (min margin {min(margins):.3f})", flush=True)
+        kept += 1
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -426,6 +567,8 @@ def main():
         gen_textonly()
     if "0.5b" in which:
         gen_model_case("md05b_seed1", "0.5b", 1, [(378, 378)], 32, False, n_images=2, min_margin=0.5)
+    if "detect" in which:
+        gen_detect()
     if "bench64" in which:
         gen_bench64()
     if "2b" in which:

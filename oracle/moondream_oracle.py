@@ -482,3 +482,88 @@ class Oracle:
     def decode_size(self, h: torch.Tensor):
         """reference: region.py:74-93."""
         return mlp(h, self.sd, "region.size_decoder", self.fast).reshape(2, -1)
+
+    def encode_spatial_refs(self, spatial_refs):
+        """reference: region.py:96-136: points -> (x, y); boxes -> (centre x, centre y) + (w, h)."""
+        coords, sizes = [], []
+        for ref in spatial_refs:
+            if len(ref) == 2:
+                coords += [ref[0], ref[1]]
+            else:
+                coords += [(ref[0] + ref[2]) / 2, (ref[1] + ref[3]) / 2]
+                sizes.append([ref[2] - ref[0], ref[3] - ref[1]])
+        c = self.encode_coordinate(torch.tensor(coords, dtype=BF16).view(-1, 1))
+        s = self.encode_size(torch.tensor(sizes, dtype=BF16)) if sizes else None
+        return c, s
+
+    def spatial_prompt(self, head_ids, spatial_refs, tail_ids):
+        """Prompt ids + embeddings with coordinate / size placeholders replaced by the encoded
+        refs (reference: moondream.py:577-604 builds the ids, moondream.py:293-301 injects)."""
+        tk = self.cfg.tokenizer
+        ids = list(head_ids)
+        for ref in spatial_refs:
+            ids += [tk.coord_id, tk.coord_id] if len(ref) == 2 else [tk.coord_id, tk.coord_id, tk.size_id]
+        ids += list(tail_ids)
+        emb = self.embed(ids).clone()
+        c, s = self.encode_spatial_refs(spatial_refs)
+        idt = torch.tensor(ids)
+        emb[idt == tk.coord_id] = c
+        if s is not None:
+            emb[idt == tk.size_id] = s
+        return ids, emb
+
+    def generate_points(self, hidden: torch.Tensor, next_token: int, pos: int, kv: OracleKV, include_size: bool,
+                        max_objects: int, trace: Optional[list] = None):
+        """reference: moondream.py:653-733.  hidden [1, D] = last prompt position.  Per object: x bin
+        from the coordinate head -> embed -> decoder step -> y bin -> (embed -> step -> w, h bins)
+        -> embed -> step -> lm_head argmax (eos ends the loop).  ``trace`` receives every decision
+        as (kind, logits) in loop order."""
+        out = []
+        eos = self.cfg.tokenizer.eos_id
+
+        def step(emb):
+            nonlocal pos
+            logits, h = self.decode_token(emb.reshape(1, -1), pos, kv)
+            pos += 1
+            return logits, h[-1:].clone()
+
+        def note(kind, lg):
+            if trace is not None:
+                trace.append((kind, lg.clone()))
+
+        while next_token != eos and len(out) < max_objects:
+            x_logits = self.decode_coordinate(hidden)
+            note("x", x_logits)
+            x_center = torch.argmax(x_logits.float(), dim=-1) / x_logits.size(-1)  # int64 / int -> fp32
+            _, hidden = step(self.encode_coordinate(x_center.to(BF16)))
+            y_logits = self.decode_coordinate(hidden)
+            note("y", y_logits)
+            y_center = torch.argmax(y_logits.float(), dim=-1) / y_logits.size(-1)
+            emb = self.encode_coordinate(y_center.to(BF16))
+            if include_size:
+                _, hidden = step(emb)
+                size_logits = self.decode_size(hidden)
+                note("w", size_logits[0])
+                note("h", size_logits[1])
+                w_bin = torch.argmax(size_logits[0].float(), dim=-1)
+                h_bin = torch.argmax(size_logits[1].float(), dim=-1)
+                w = torch.pow(2.0, (w_bin.float() / 1023.0) * 10.0 - 10.0)
+                h = torch.pow(2.0, (h_bin.float() / 1023.0) * 10.0 - 10.0)
+                emb = self.encode_size(torch.tensor([w, h], dtype=BF16))
+                xc, yc, wf, hf = x_center.item(), y_center.item(), w.item(), h.item()
+                out.append({"x_min": xc - wf / 2, "y_min": yc - hf / 2, "x_max": xc + wf / 2, "y_max": yc + hf / 2})
+            else:
+                out.append({"x": x_center.item(), "y": y_center.item()})
+            logits, hidden = step(emb)
+            note("next", logits)
+            next_token = int(torch.argmax(logits.float()))
+        return out
+
+    def detect_like(self, kind: str, crops_u8, tiling, object_ids, max_objects: int, trace: Optional[list] = None):
+        """reference: detect moondream.py:735-781 / point moondream.py:783-829."""
+        tpl = self.cfg.tokenizer.templates[kind]
+        pos, kv = self.encode_image(crops_u8, tiling)
+        prompt = list(tpl["prefix"]) + list(object_ids) + list(tpl["suffix"])
+        logits, h, pos = self.prefill_prompt(prompt, pos, kv)
+        nxt = int(torch.argmax(logits.float()))
+        return self.generate_points(h[-1:].clone(), nxt, pos, kv, kind == "detect", max_objects, trace)

@@ -242,6 +242,32 @@ md_status md_embed_tokens(const int32_t* ids, const void* table, int64_t ld_tabl
 md_status md_argmax_bf16(const void* logits, int64_t ld, int32_t batch, int32_t vocab,
                          int32_t suppress_id, int32_t* next, void* stream);
 
+/* Temperature / top-p sampling of one token per sequence, device resident (reference:
+ * moondream.py:521-528 with _apply_top_p, moondream.py:270-278):
+ *   p = bf16(softmax(bf16(logits / temperature)));  in descending-p order keep the tokens whose
+ *   preceding mass is <= top_p;  q = bf16(p / bf16(sum kept));  next[b] ~ q by inverse CDF over
+ *   token ids with the caller's uniforms[b] in [0, 1)  (torch.multinomial draws from the same q;
+ *   the random stream differs, the distribution does not).
+ * logits[b, suppress_id] is treated as -inf when suppress_id >= 0 (moondream.py:517).
+ * probs_out (optional, bf16 [batch][ld_probs]) receives q -- what _apply_top_p returns. */
+md_status md_sample_top_p(const void* logits, int64_t ld, int32_t batch, int32_t vocab, int32_t suppress_id,
+                          float temperature, float top_p, const float* uniforms, int32_t* next,
+                          void* probs_out, int64_t ld_probs, void* stream);
+
+/* Region head, device resident (reference: region.py:12-71 inside the loop of moondream.py:653-733).
+ * md_fourier_features: out[r] = [cos(f) | sin(f)], f = bf16(bf16(2 pi x[r, :in_dim]) . w[in_dim][half])
+ *   (region.py:12-29; in_dim 1 for coordinates, 2 for sizes) -- the input of coord_encoder /
+ *   size_encoder.
+ * md_region_pick_encode: one step of the points loop for `batch` sequences with no host round trip:
+ *   bins[b][g] = argmax of logits[b][g*n_bins .. (g+1)*n_bins) (ties -> lowest index), value =
+ *   value_table[bin] (bf16 [n_bins]: bin/1024 for coordinates, 2^(bin/1023*10-10) for sizes --
+ *   moondream.py:673-674,696-701), then the Fourier features of the value(s) as above. */
+md_status md_fourier_features(const void* x, int64_t ldx, int32_t rows, int32_t in_dim, const void* w,
+                              int32_t half, void* out, int64_t ld_out, void* stream);
+md_status md_region_pick_encode(const void* logits, int64_t ld, int32_t batch, int32_t n_groups,
+                                int32_t n_bins, const void* value_table, const void* feat_w, int32_t half,
+                                int32_t* bins, int64_t ld_bins, void* feats, int64_t ld_feats, void* stream);
+
 /* Overlap-crop stitch + adaptive average pool + concat with the global crop's
  * features (reference: moondream.py:213-226, image_crops.py:170-231 with
  * patch_size=1, vision.py:83-88).  feats: bf16 [1 + th*tw][g*g][dim] for ONE

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "elementwise.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
@@ -113,6 +113,11 @@ SIGNATURES = {
                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "md_embed_tokens": (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "md_argmax_bf16": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "md_sample_top_p": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_int64, c_void_p]),
+    "md_fourier_features": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+    "md_region_pick_encode": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                        c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "md_stitch_pool_concat": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "md_vit_workspace_bytes": (c_size_t, [P(MdVitModel), c_int32]),
     "md_vit_encode": (C.c_int, [P(MdVitModel), c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -120,6 +120,7 @@ class MoondreamModel:
         self.use_graphs = False
         self.collect_timing = False
         self.last_phase_ms: Dict[str, float] = {}
+        self._region_tables = None
         if setup_caches:
             self._setup_caches(max_batch)
 
@@ -242,7 +243,8 @@ class MoondreamModel:
             self._text_causal = st
         return st
 
-    def _text_forward(self, x: torch.Tensor, pos0: Union[int, Sequence[int]], slot0: int = 0, causal: bool = False) -> torch.Tensor:
+    def _text_forward(self, x: torch.Tensor, pos0: Union[int, Sequence[int]], slot0: int = 0, causal: bool = False,
+                      pos_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [B,T,D] embeddings -> hidden [B,T,D]; K,V written at pos0[b]..pos0[b]+T-1.
         ``pos0`` is host data (one int for the whole batch or one per sequence): the slab has
         max_context slots per head and the kernels do not bounds-check, so the check is here
@@ -255,7 +257,10 @@ class MoondreamModel:
                 f"positions [{lo}, {hi + t}) do not fit the {self.config.text.max_context}-slot context "
                 "(image prefix + prompt + generated tokens)"
             )
-        if isinstance(pos0, int):
+        if pos_dev is not None:  # the same positions, already on the device (loops that advance them there)
+            assert pos_dev.dtype == torch.int32 and pos_dev.numel() == b
+            pos0 = pos_dev
+        elif isinstance(pos0, int):
             pos0 = torch.full((b,), pos0, dtype=torch.int32, device=self._device)
         else:
             assert len(pos0) == b
@@ -434,18 +439,30 @@ class MoondreamModel:
         out.scatter_(dim=-1, index=probs_idx, src=probs_sort)
         return out
 
-    def _pick(self, logits: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
-        """[B,V] -> int32 [B]   (reference: moondream.py:313-318,521-528)."""
+    def _pick(self, logits: torch.Tensor, temperature: float, top_p: float, suppress_id: int = -1,
+              generator: Optional[torch.Generator] = None, probs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[B,V] -> int32 [B]   (reference: moondream.py:313-318,521-528).  Greedy: argmax, ties to the
+        lowest id.  Otherwise temperature + top-p on the device (md_sample_top_p): the reference's
+        softmax / _apply_top_p / multinomial semantics with one uniform per sequence from torch's
+        generator (same distribution as torch.multinomial, different random stream)."""
+        b, v = logits.shape
+        nxt = torch.empty(b, dtype=torch.int32, device=self._device)
         if temperature == 0:
-            b, v = logits.shape
-            nxt = torch.empty(b, dtype=torch.int32, device=self._device)
             _lib.check(
-                self.lib.md_argmax_bf16(logits.data_ptr(), v, b, v, -1, nxt.data_ptr(), self._stream()), "md_argmax_bf16"
+                self.lib.md_argmax_bf16(logits.data_ptr(), logits.stride(0), b, v, suppress_id, nxt.data_ptr(), self._stream()),
+                "md_argmax_bf16",
             )
             return nxt
-        probs = torch.softmax(logits / temperature, dim=-1)
-        probs = self._apply_top_p(probs, top_p)
-        return torch.multinomial(probs.float(), num_samples=1)[:, 0].to(torch.int32)
+        u = torch.rand(b, device=self._device, dtype=torch.float32, generator=generator)
+        _lib.check(
+            self.lib.md_sample_top_p(
+                logits.data_ptr(), logits.stride(0), b, v, suppress_id, float(temperature), float(top_p), u.data_ptr(),
+                nxt.data_ptr(), probs_out.data_ptr() if probs_out is not None else None,
+                probs_out.stride(0) if probs_out is not None else 0, self._stream(),
+            ),
+            "md_sample_top_p",
+        )
+        return nxt
 
     # ---------------------------------------------------------- batched engine
     def _prefill_prompts(self, prompts: Sequence[Sequence[int]], pos: int, slot0: int = 0, prompt_embs=None):
@@ -556,6 +573,61 @@ class MoondreamModel:
             out.append(tok)
         return out
 
+    def _prepare_sequences(self, images, prompts: Sequence[Sequence[int]], mark=None):
+        """Everything before the first generated token, for B (image, prompt-ids) pairs: sequences are
+        placed in KV slots in order of prompt length (stable), so that every group of equal-length
+        prompts occupies a contiguous slot range; raw images are encoded together and prefilled
+        straight into their slots, EncodedImages are copied into theirs; one prompt prefill per
+        distinct length.  Returns (order, first int32 [B], hidden_last [B, D], next_pos list) in slot
+        order; ``order[slot]`` is the caller's index.  Must run under torch.inference_mode()."""
+        mark = mark or (lambda name: None)
+        b = len(images)
+        order = sorted(range(b), key=lambda i: len(prompts[i]))
+        images = [images[i] for i in order]
+        prompts = [list(prompts[i]) for i in order]
+        if any(len(p) == 0 for p in prompts):
+            raise ValueError("empty prompt")
+        self._ensure_batch(b)
+        raw_idx = [i for i, im in enumerate(images) if not isinstance(im, EncodedImage)]
+        for i in raw_idx:
+            if not isinstance(images[i], Image.Image):
+                raise ValueError("image must be a PIL Image or EncodedImage")
+        mark("start")
+        pos = None
+        if raw_idx:
+            img_emb = self._run_vision_encoder_batch([images[i] for i in raw_idx])
+            mark("vision")
+            # every run of consecutive raw images is prefilled straight into its own slots
+            j = 0
+            while j < len(raw_idx):
+                k = j
+                while k + 1 < len(raw_idx) and raw_idx[k + 1] == raw_idx[k] + 1:
+                    k += 1
+                pos = self._prefill_images(img_emb[j : k + 1], raw_idx[j])
+                j = k + 1
+            mark("image_prefill")
+        for i, im in enumerate(images):
+            if isinstance(im, EncodedImage):
+                if pos is not None and im.pos != pos:
+                    raise ValueError("EncodedImage with a different prefix length than the rest of the batch")
+                self.load_encoded_image(im, i)
+                pos = im.pos
+        first = torch.empty(b, dtype=torch.int32, device=self._device)
+        hidden_last = torch.empty(b, self.config.text.dim, dtype=BF16, device=self._device)
+        next_pos = [0] * b
+        g0 = 0
+        while g0 < b:  # one prefill per distinct prompt length
+            g1 = g0
+            while g1 < b and len(prompts[g1]) == len(prompts[g0]):
+                g1 += 1
+            logits, hidden, p1 = self._prefill_prompts(prompts[g0:g1], pos, g0)
+            first[g0:g1] = self._pick(logits, 0.0, 0.0)
+            hidden_last[g0:g1] = hidden[:, -1, :]
+            next_pos[g0:g1] = [p1] * (g1 - g0)
+            g0 = g1
+        mark("prompt_prefill")
+        return order, first, hidden_last, next_pos
+
     def batch_generate_ids(
         self,
         images: Sequence[Union[Image.Image, EncodedImage]],
@@ -584,49 +656,9 @@ class MoondreamModel:
                 e.record(torch.cuda.current_stream(self._device))
                 marks.append((name, e))
 
-        # Sequences are placed in KV slots in order of prompt length (stable), so that every group of
-        # equal-length prompts occupies a contiguous slot range: one prompt prefill per distinct
-        # length, then ONE lockstep decode over all B sequences with per-sequence positions.
-        order = sorted(range(b), key=lambda i: len(prompts[i]))
-        images = [images[i] for i in order]
-        prompts = [list(prompts[i]) for i in order]
-        if any(len(p) == 0 for p in prompts):
-            raise ValueError("empty prompt")
         with torch.inference_mode():
-            self._ensure_batch(b)
-            raw_idx = [i for i, im in enumerate(images) if not isinstance(im, EncodedImage)]
-            mark("start")
-            pos = None
-            if raw_idx:
-                img_emb = self._run_vision_encoder_batch([images[i] for i in raw_idx])
-                mark("vision")
-                # every run of consecutive raw images is prefilled straight into its own slots
-                j = 0
-                while j < len(raw_idx):
-                    k = j
-                    while k + 1 < len(raw_idx) and raw_idx[k + 1] == raw_idx[k] + 1:
-                        k += 1
-                    pos = self._prefill_images(img_emb[j : k + 1], raw_idx[j])
-                    j = k + 1
-                mark("image_prefill")
-            for i, im in enumerate(images):
-                if isinstance(im, EncodedImage):
-                    if pos is not None and im.pos != pos:
-                        raise ValueError("EncodedImage with a different prefix length than the rest of the batch")
-                    self.load_encoded_image(im, i)
-                    pos = im.pos
-            first = torch.empty(b, dtype=torch.int32, device=self._device)
-            next_pos = [0] * b
-            g0 = 0
-            while g0 < b:  # one prefill per distinct prompt length
-                g1 = g0
-                while g1 < b and len(prompts[g1]) == len(prompts[g0]):
-                    g1 += 1
-                logits, _, p1 = self._prefill_prompts(prompts[g0:g1], pos, g0)
-                first[g0:g1] = self._pick(logits, 0.0, 0.0)
-                next_pos[g0:g1] = [p1] * (g1 - g0)
-                g0 = g1
-            mark("prompt_prefill")
+            order, first, _, next_pos = self._prepare_sequences(list(images), prompts, mark)
+            b = len(order)
             stop = None if ignore_eos else eos
             hist = self._decode_greedy(first, next_pos if len(set(next_pos)) > 1 else next_pos[0], max_tokens,
                                        tk.answer_id, 0, stop)
@@ -784,9 +816,8 @@ class MoondreamModel:
                         emb = self._embed(tok.reshape(1, 1))
                         hidden = self._text_forward(emb, cur_pos, 0)
                         logits = self._lm_head(hidden)
-                        logits[:, self.config.tokenizer.answer_id] = float("-inf")
                         cur_pos += 1
-                        tok = self._pick(logits, temperature, top_p)
+                        tok = self._pick(logits, temperature, top_p, self.config.tokenizer.answer_id)  # moondream.py:517
 
         def generator():
             # streaming detokeniser: flush on newline, CJK, or up to the last space
@@ -868,44 +899,85 @@ class MoondreamModel:
         return {"answer": gen} if stream else {"answer": "".join(list(gen))}
 
     # ------------------------------------------------------------ region head
-    def _gemm(self, a: torch.Tensor, lin, epi: int = _lib.MD_EPI_BIAS) -> torch.Tensor:
-        """rows [m, k] -> [m, n] through md_gemm_bf16 (pads the operand to k_pad)."""
+    # Device-resident and batched: the heads are decode-regime GEMMs over B rows, "argmax the bin,
+    # turn it into a value, Fourier-encode it" is one kernel (md_region_pick_encode), the decoder step
+    # is md_text_forward -- no host round trip per coordinate (the reference syncs 3-4 times per
+    # object: moondream.py:669,718-721).  One D2H per object decides whether every sequence is done.
+    def _region(self):
+        if self.w.region is None:
+            raise NotImplementedError("checkpoint has no region head")
+        if self._region_tables is None:
+            r, rc = self.w.region, self.config.region
+            nb_c, nb_s = rc.coord_out_dim, rc.size_out_dim // 2
+            # bin -> value exactly as the reference computes it (moondream.py:673-674: argmax / size(-1),
+            # fp32; :699-701: 2^(bin/1023*10-10), fp32), then the dtype of the logits (bf16)
+            coord = (torch.arange(nb_c) / nb_c).to(BF16)
+            size = torch.pow(2.0, (torch.arange(nb_s).float() / 1023.0) * 10.0 - 10.0).to(BF16)
+            need = 0
+            for lin in (r["coord_dec_fc1"], r["coord_dec_fc2"], r["size_dec_fc1"], r["size_dec_fc2"], r["coord_encoder"], r["size_encoder"]):
+                st = lin.struct()
+                need = max(need, self.lib.md_gemm_workspace_bytes(C.byref(st), 64, 1))
+            self._region_tables = {
+                "coord": coord.to(self._device), "size": size.to(self._device),
+                # decode-regime split-K scratch: tickets start zeroed, every launch leaves them zeroed
+                "splitk": torch.zeros(max(need, 16), dtype=torch.uint8, device=self._device),
+            }
+        return self.w.region, self._region_tables
+
+    def _lin(self, a: torch.Tensor, lin, epi: int = _lib.MD_EPI_BIAS) -> torch.Tensor:
+        """rows [m, k] (bf16, contiguous) -> [m, n] through md_gemm_bf16."""
         m = a.shape[0]
-        ap = torch.zeros(m, lin.k_pad, dtype=BF16, device=self._device)
-        ap[:, : lin.k] = a
+        if a.shape[1] != lin.k_pad or not a.is_contiguous():
+            ap = torch.zeros(m, lin.k_pad, dtype=BF16, device=self._device)
+            ap[:, : lin.k] = a
+            a = ap
+        _, tabs = self._region()
+        ws = tabs["splitk"]
         out = torch.empty(m, lin.n_pad, dtype=BF16, device=self._device)
-        args = _lib.MdGemmArgs(ap.data_ptr(), lin.k_pad, lin.struct(), out.data_ptr(), lin.n_pad, None, 0, 0, m, epi, 1)
+        args = _lib.MdGemmArgs(a.data_ptr(), lin.k_pad, lin.struct(), out.data_ptr(), lin.n_pad, None, 0, 0, m, epi, 1, 0,
+                               ws.data_ptr(), ws.numel())
         _lib.check(self.lib.md_gemm_bf16(C.byref(args), self._stream()), "md_gemm_bf16")
         return out[:, : lin.n]
 
+    def _gemm(self, a, lin, epi: int = _lib.MD_EPI_BIAS):
+        return self._lin(a.to(self._device, BF16), lin, epi)
+
     def _mlp(self, x: torch.Tensor, fc1, fc2) -> torch.Tensor:
-        h = self._gemm(x, fc1, _lib.MD_EPI_GELU)
-        return self._gemm(h, fc2)
+        return self._lin(self._lin(x, fc1, _lib.MD_EPI_GELU), fc2)
 
     def _fourier(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-        """reference: region.py:12-29 (tiny: evaluated with torch elementwise ops on device)."""
-        f = (2 * math.pi * x) @ w
-        return torch.cat([f.cos(), f.sin()], dim=-1)
+        """reference: region.py:12-29.  x bf16 [n, in_dim], w bf16 [in_dim, half] -> [n, 2*half]."""
+        x = x.to(self._device, BF16).contiguous()
+        n, in_dim = x.shape
+        half = w.shape[1]
+        out = torch.empty(n, 2 * half, dtype=BF16, device=self._device)
+        _lib.check(
+            self.lib.md_fourier_features(x.data_ptr(), x.stride(0), n, in_dim, w.data_ptr(), half, out.data_ptr(), out.stride(0), self._stream()),
+            "md_fourier_features",
+        )
+        return out
 
     def encode_coordinate(self, coord: torch.Tensor) -> torch.Tensor:
         """reference: region.py:32-43."""
-        r = self.w.region
-        return self._gemm(self._fourier(coord.reshape(-1, 1).to(self._device, BF16), r["coord_features"]), r["coord_encoder"])
+        r, _ = self._region()
+        return self._lin(self._fourier(coord.reshape(-1, 1), r["coord_features"]), r["coord_encoder"])
 
     def decode_coordinate(self, hidden: torch.Tensor) -> torch.Tensor:
         """reference: region.py:46-57."""
-        r = self.w.region
-        return self._mlp(hidden.reshape(-1, hidden.shape[-1]), r["coord_dec_fc1"], r["coord_dec_fc2"])
+        r, _ = self._region()
+        return self._mlp(hidden.reshape(-1, hidden.shape[-1]).to(self._device, BF16), r["coord_dec_fc1"], r["coord_dec_fc2"])
 
     def encode_size(self, size: torch.Tensor) -> torch.Tensor:
         """reference: region.py:60-71."""
-        r = self.w.region
-        return self._gemm(self._fourier(size.reshape(-1, 2).to(self._device, BF16), r["size_features"]), r["size_encoder"])
+        r, _ = self._region()
+        return self._lin(self._fourier(size.reshape(-1, 2), r["size_features"]), r["size_encoder"])
 
     def decode_size(self, hidden: torch.Tensor) -> torch.Tensor:
-        """reference: region.py:74-93."""
-        r = self.w.region
-        return self._mlp(hidden.reshape(-1, hidden.shape[-1]), r["size_dec_fc1"], r["size_dec_fc2"]).reshape(2, -1)
+        """reference: region.py:74-93.  [1, D] -> [2, bins]; [B, D] -> [B, 2, bins]."""
+        r, _ = self._region()
+        h = hidden.reshape(-1, hidden.shape[-1]).to(self._device, BF16)
+        out = self._mlp(h, r["size_dec_fc1"], r["size_dec_fc2"])
+        return out.reshape(2, -1) if h.shape[0] == 1 else out.reshape(h.shape[0], 2, -1)
 
     def encode_spatial_refs(self, spatial_refs: SpatialRefs):
         """reference: region.py:96-136."""
@@ -920,60 +992,126 @@ class MoondreamModel:
         s = self.encode_size(torch.tensor(sizes, dtype=BF16)) if sizes else None
         return {"coords": c, "sizes": s}
 
-    def _generate_points(self, hidden: torch.Tensor, next_token: torch.Tensor, pos: int, include_size: bool = True,
-                         max_objects: int = DEFAULT_MAX_OBJECTS):
-        """reference: moondream.py:653-733."""
-        out = []
+    def _region_pick_encode(self, hidden: torch.Tensor, which: str, bins_out: torch.Tensor) -> torch.Tensor:
+        """hidden [B, D] -> next embedding [B, D]: head MLP -> per-sequence argmax bin(s) (written to
+        ``bins_out`` [B, 1|2], int32) -> value -> Fourier features -> encoder.  All on the device.
+        reference: moondream.py:672-677 (x), :682-687 (y), :693-713 (size)."""
+        r, tabs = self._region()
+        b = hidden.shape[0]
+        if which == "coord":
+            logits = self._mlp(hidden, r["coord_dec_fc1"], r["coord_dec_fc2"])
+            groups, table, fw, enc = 1, tabs["coord"], r["coord_features"], r["coord_encoder"]
+        else:
+            logits = self._mlp(hidden, r["size_dec_fc1"], r["size_dec_fc2"])
+            groups, table, fw, enc = 2, tabs["size"], r["size_features"], r["size_encoder"]
+        n_bins = logits.shape[1] // groups
+        half = fw.shape[1]
+        feats = torch.empty(b, 2 * half, dtype=BF16, device=self._device)
+        assert bins_out.dtype == torch.int32 and bins_out.stride(-1) == 1
+        _lib.check(
+            self.lib.md_region_pick_encode(
+                logits.data_ptr(), logits.stride(0), b, groups, n_bins, table.data_ptr(), fw.data_ptr(), half,
+                bins_out.data_ptr(), bins_out.stride(0), feats.data_ptr(), feats.stride(0), self._stream(),
+            ),
+            "md_region_pick_encode",
+        )
+        return self._lin(feats, enc)
+
+    def _points_loop(self, hidden: torch.Tensor, first: torch.Tensor, pos: Sequence[int], slot0: int, include_size: bool,
+                     max_objects: int) -> List[List[dict]]:
+        """The loop of moondream.py:653-733 for B sequences in lockstep.  hidden [B, D] = last prompt
+        position, first int32 [B] = the token after the prompt, pos[b] = next position."""
+        b = hidden.shape[0]
         eos = self.config.tokenizer.eos_id
+        n_bins = self.config.region.coord_out_dim
+        steps_per_obj = 3 if include_size else 2
+        if max(pos) + steps_per_obj * max_objects > self.config.text.max_context:
+            max_objects = max(0, (self.config.text.max_context - max(pos)) // steps_per_obj)
+        bins = torch.zeros(max(1, max_objects), b, 4, dtype=torch.int32, device=self._device)
+        toks = torch.full((max_objects + 1, b), eos, dtype=torch.int32, device=self._device)
+        toks[0] = first
+        pos_host = [int(p) for p in pos]
+        pos_dev = torch.tensor(pos_host, dtype=torch.int32, device=self._device)
+        hidden = hidden.reshape(b, -1).contiguous()
 
         def step(emb):
-            nonlocal pos
-            h = self._text_forward(emb.reshape(1, 1, -1), pos, 0)
-            pos += 1
-            return h
+            nonlocal pos_host, hidden
+            h = self._text_forward(emb.reshape(b, 1, -1), pos_host, slot0, pos_dev=pos_dev)
+            pos_host = [p + 1 for p in pos_host]
+            pos_dev.add_(1)
+            hidden = h.reshape(b, -1)
 
-        with torch.inference_mode():
-            while int(next_token.reshape(-1)[0]) != eos and len(out) < max_objects:
-                x_logits = self.decode_coordinate(hidden)
-                x_center = torch.argmax(x_logits, dim=-1) / x_logits.size(-1)
-                hidden = step(self.encode_coordinate(x_center.to(dtype=x_logits.dtype)))
-                y_logits = self.decode_coordinate(hidden)
-                y_center = torch.argmax(y_logits, dim=-1) / y_logits.size(-1)
-                emb = self.encode_coordinate(y_center.to(dtype=y_logits.dtype))
+        n_done = 0
+        for k in range(max_objects):
+            # one host decision per object: is any sequence still emitting objects?
+            alive = (toks[: k + 1] != eos).all(dim=0)
+            if not bool(alive.any()):
+                break
+            step(self._region_pick_encode(hidden, "coord", bins[k, :, 0:1]))       # x -> y's hidden state
+            emb = self._region_pick_encode(hidden, "coord", bins[k, :, 1:2])      # y
+            if include_size:
+                step(emb)
+                emb = self._region_pick_encode(hidden, "size", bins[k, :, 2:4])    # w, h
+            step(emb)
+            toks[k + 1] = self._pick(self._lm_head(hidden.reshape(b, 1, -1)), 0.0, 0.0)  # next token: x again, or eos
+            n_done = k + 1
+        bins_h = bins[:n_done].cpu() if n_done else torch.zeros(0, b, 4, dtype=torch.int32)
+        toks_h = toks[: n_done + 1].cpu()
+        # host floats exactly as the reference forms them (moondream.py:673,683,699-721)
+        xc = (bins_h[..., 0].to(torch.int64) / n_bins)
+        yc = (bins_h[..., 1].to(torch.int64) / n_bins)
+        wv = torch.pow(2.0, (bins_h[..., 2].float() / 1023.0) * 10.0 - 10.0)
+        hv = torch.pow(2.0, (bins_h[..., 3].float() / 1023.0) * 10.0 - 10.0)
+        out: List[List[dict]] = []
+        for i in range(b):
+            objs = []
+            for k in range(n_done):
+                if int(toks_h[k, i]) == eos:
+                    break
+                x, y = xc[k, i].item(), yc[k, i].item()
                 if include_size:
-                    hidden = step(emb)
-                    size_logits = self.decode_size(hidden)
-                    w_bin = torch.argmax(size_logits[0], dim=-1)
-                    h_bin = torch.argmax(size_logits[1], dim=-1)
-                    w = torch.pow(2.0, (w_bin.float() / 1023.0) * 10.0 - 10.0)
-                    h = torch.pow(2.0, (h_bin.float() / 1023.0) * 10.0 - 10.0)
-                    emb = self.encode_size(torch.tensor([w, h], device=self._device, dtype=size_logits.dtype))
-                    xc, yc, wf, hf = x_center.item(), y_center.item(), w.item(), h.item()
-                    out.append({"x_min": xc - wf / 2, "y_min": yc - hf / 2, "x_max": xc + wf / 2, "y_max": yc + hf / 2})
+                    w, h = wv[k, i].item(), hv[k, i].item()
+                    objs.append({"x_min": x - w / 2, "y_min": y - h / 2, "x_max": x + w / 2, "y_max": y + h / 2})
                 else:
-                    out.append({"x": x_center.item(), "y": y_center.item()})
-                hidden = step(emb)
-                next_token = self._pick(self._lm_head(hidden), 0.0, 0.0)
+                    objs.append({"x": x, "y": y})
+            out.append(objs)
         return out
 
-    def _detect_like(self, image, obj: str, kind: str, include_size: bool, settings: Optional[dict]):
+    def _generate_points(self, hidden: torch.Tensor, next_token: torch.Tensor, pos: int, include_size: bool = True,
+                         max_objects: int = DEFAULT_MAX_OBJECTS):
+        """reference: moondream.py:653-733 (B = 1 form of the lockstep loop; KV slot 0)."""
+        with torch.inference_mode():
+            first = next_token.reshape(1).to(device=self._device, dtype=torch.int32)
+            return self._points_loop(hidden.reshape(1, -1), first, [pos], 0, include_size, max_objects)[0]
+
+    def _batch_detect_like(self, images, objects: Sequence[str], kind: str, include_size: bool, settings: Optional[dict]):
         tpl = self.config.tokenizer.templates[kind]
         if tpl is None:
             raise NotImplementedError(f"Model does not support {kind}.")
-        if self.w.region is None:
-            raise NotImplementedError("checkpoint has no region head")
-        enc = self.encode_image(image)
-        self.load_encoded_image(enc)
-        prompt = torch.tensor([list(tpl["prefix"]) + list(self.tokenizer.encode(" " + obj).ids) + list(tpl["suffix"])])
-        _, hidden, nxt, pos = self._prefill_prompt(prompt, enc.pos, temperature=0, top_p=0)
-        hidden = hidden[:, -1:, :]
+        self._region()
+        if settings is not None and settings.get("variant") is not None:
+            raise NotImplementedError("LoRA variants are not on the native path")
         max_objects = (settings or {}).get("max_objects", DEFAULT_MAX_OBJECTS)
-        return self._generate_points(hidden, nxt, pos, include_size=include_size, max_objects=max_objects)
+        prompts = [list(tpl["prefix"]) + list(self.tokenizer.encode(" " + o).ids) + list(tpl["suffix"]) for o in objects]
+        with torch.inference_mode():
+            order, first, hidden, next_pos = self._prepare_sequences(list(images), prompts)
+            res = self._points_loop(hidden, first, next_pos, 0, include_size, max_objects)
+        out = [None] * len(order)
+        for slot, src in enumerate(order):
+            out[src] = res[slot]
+        return out
+
+    def batch_detect(self, images, objects: Sequence[str], settings: Optional[dict] = None) -> List[dict]:
+        """B (image, object) pairs in lockstep; element i == detect(images[i], objects[i])."""
+        return [{"objects": o} for o in self._batch_detect_like(images, objects, "detect", True, settings)]
+
+    def batch_point(self, images, objects: Sequence[str], settings: Optional[dict] = None) -> List[dict]:
+        return [{"points": o} for o in self._batch_detect_like(images, objects, "point", False, settings)]
 
     def detect(self, image, object: str, settings: Optional[dict] = None):
         """reference: moondream.py:735-781."""
-        return {"objects": self._detect_like(image, object, "detect", True, settings)}
+        return self.batch_detect([image], [object], settings)[0]
 
     def point(self, image, object: str, settings: Optional[dict] = None):
         """reference: moondream.py:783-829."""
-        return {"points": self._detect_like(image, object, "point", False, settings)}
+        return self.batch_point([image], [object], settings)[0]

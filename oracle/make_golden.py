@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [0.5b] [2b] [bench64]
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [0.5b] [2b] [bench64]
 """
 from __future__ import annotations
 
@@ -552,6 +552,34 @@ def gen_detect(name="tiny_detect", cfg_name="tiny", seed=1, n_cases=2, max_objec
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
 
 
+def gen_sampling(name="sampling_top_p", seed=7):
+    """The reference's sampling filter on fixed logits: softmax(logits / T) -> MoondreamModel._apply_top_p
+    (moondream.py:270-278, called at :316-317 and :526-527), bf16 like the decode path's logits.
+    Rows: peaked, flat-ish and tied distributions; vocab 8192 and the real 51200."""
+    cfg = get_config("tiny")
+    sd = synth.synthetic_state_dict(cfg, seed=1)
+    model, _ = load_reference(cfg, sd)
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    cases = [(0.5, 0.3, 8192, 3.0), (1.0, 0.9, 8192, 2.0), (0.7, 0.5, 8192, 0.25), (0.5, 0.3, 51200, 2.5), (1.5, 0.95, 8192, 4.0)]
+    for i, (temp, top_p, vocab, scale) in enumerate(cases):
+        logits = (torch.randn(2, vocab, generator=g) * scale).to(torch.bfloat16)
+        logits[1, :64] = logits[1, 0]  # a block of exact ties at a random level
+        logits[1, 100] = logits[1].float().max() + 1.0
+        probs = torch.softmax(logits / temp, dim=-1)
+        kept = model._apply_top_p(probs.clone(), top_p)
+        out[f"case{i}.temperature"] = np.float32(temp)
+        out[f"case{i}.top_p"] = np.float32(top_p)
+        out[f"case{i}.logits"] = bf16_bits(logits)
+        out[f"case{i}.probs"] = bf16_bits(probs)
+        out[f"case{i}.kept"] = bf16_bits(kept)
+        print(f"[{name}] case{i}: T={temp} top_p={top_p} V={vocab}: kept {(kept > 0).sum(dim=-1).tolist()} tokens", flush=True)
+    out["n_cases"] = np.int64(len(cases))
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -567,6 +595,8 @@ def main():
         gen_textonly()
     if "0.5b" in which:
         gen_model_case("md05b_seed1", "0.5b", 1, [(378, 378)], 32, False, n_images=2, min_margin=0.5)
+    if "sampling" in which:
+        gen_sampling()
     if "detect" in which:
         gen_detect()
     if "bench64" in which:

@@ -360,6 +360,35 @@ def lm_head(hidden_last: torch.Tensor, sd, fast=False):
 
 
 # --------------------------------------------------------------------------
+# sampling
+# --------------------------------------------------------------------------
+def sampling_probs(logits: torch.Tensor, temperature: float) -> torch.Tensor:
+    """reference: moondream.py:316,526 -- softmax(logits / T) on bf16 tensors: the quotient is a
+    bf16 tensor, the softmax runs in fp32 and is rounded once."""
+    z = _r(logits.float() / temperature)
+    return _r(torch.softmax(z.float(), dim=-1))
+
+
+def apply_top_p(probs: torch.Tensor, top_p: float) -> torch.Tensor:
+    """Nucleus filter of one row, restated with its rounding points (reference:
+    moondream.py:270-278).  In descending-probability order: the running sum is accumulated in fp32
+    and rounded to bf16 per element (torch.cumsum on a bf16 tensor), ``csum - p`` is a bf16
+    subtraction and the comparison casts the python scalar top_p to bf16; survivors are divided by
+    their bf16 sum (fp32 accumulate) in bf16 and put back at their ids."""
+    assert probs.dim() == 1 and probs.dtype == BF16
+    order = torch.argsort(probs.float(), descending=True, stable=True)
+    ps = probs[order]
+    run = _r(torch.cumsum(ps.float(), dim=0))
+    before = _r(run.float() - ps.float())
+    keep = before.float() <= float(_r(torch.tensor(top_p)))
+    kept = torch.where(keep, ps.float(), torch.zeros(()))
+    denom = float(_r(kept.sum()))
+    out = torch.zeros_like(probs)
+    out[order] = _r(kept / denom)
+    return out
+
+
+# --------------------------------------------------------------------------
 # end-to-end drivers
 # --------------------------------------------------------------------------
 @dataclass

@@ -476,3 +476,102 @@ def test_stitch_pool_concat(lib, th, tw):
     pooled = O.adaptive_avg_pool_hw(stitched, g).reshape(g * g, dim)
     assert torch.equal(out[:, :dim].cpu(), f[0])
     compare(f"stitch_pool {th}x{tw}", out[:, dim : 2 * dim], pooled, 2e-3, 1e-2)
+
+
+# ---------------------------------------------------------------------------
+# sampling and the region head's device-resident step
+def _sample(lib, logits, temperature, top_p, u, suppress=-1, want_probs=True):
+    b, v = logits.shape
+    nxt = torch.full((b,), -1, dtype=torch.int32, device="cuda")
+    probs = torch.full((b, v), float("nan"), dtype=BF16, device="cuda") if want_probs else None
+    _lib.check(lib.md_sample_top_p(logits.data_ptr(), logits.stride(0), b, v, suppress, temperature, top_p, u.data_ptr(),
+                                   nxt.data_ptr(), probs.data_ptr() if want_probs else None, v if want_probs else 0, stream()))
+    torch.cuda.synchronize()
+    return nxt, probs
+
+
+def test_sample_top_p_filter_matches_reference(lib):
+    """md_sample_top_p's filtered distribution against the REFERENCE's softmax + _apply_top_p
+    (moondream.py:270-278,526-527) on fixed logits (tests/golden/sampling_top_p.npz): same support
+    and the same bf16 values; the only licence is the order of exactly tied probabilities at the
+    nucleus boundary (torch.sort is not stable) and a last-bit difference of exp()."""
+    from util import bits_to_bf16
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling_top_p.npz"))
+    for i in range(int(g["n_cases"])):
+        logits = bits_to_bf16(g[f"case{i}.logits"]).cuda()
+        want = bits_to_bf16(g[f"case{i}.kept"]).float()
+        temp, top_p = float(g[f"case{i}.temperature"]), float(g[f"case{i}.top_p"])
+        u = torch.full((logits.shape[0],), 0.5, device="cuda")
+        nxt, probs = _sample(lib, logits, temp, top_p, u)
+        got = probs.float().cpu()
+        for r in range(logits.shape[0]):
+            ks, kw = got[r] > 0, want[r] > 0
+            # support: identical, or differing only inside one tied probability value / by <= 2 boundary tokens
+            if not torch.equal(ks, kw):
+                diff = (ks != kw).nonzero().flatten()
+                pv = bits_to_bf16(g[f"case{i}.probs"]).float()[r][diff]
+                assert int(ks.sum()) == int(kw.sum()) and pv.unique().numel() == 1 or diff.numel() <= 2, (i, r, diff.numel())
+            both = ks & kw
+            rel = ((got[r][both] - want[r][both]).abs() / want[r][both]).max()
+            assert float(rel) <= 2.0 ** -7, (i, r, float(rel))  # one bf16 ulp
+            assert bool(ks[int(nxt[r])]), "the drawn token must be inside the nucleus"
+
+
+def test_sample_top_p_distribution_and_suppression(lib):
+    """Draws follow the filtered distribution: 20000 sequences share one logits row whose nucleus has
+    a handful of tokens; empirical frequencies within 5 sigma of q.  The suppressed id is never drawn."""
+    v = 2048
+    g = torch.Generator().manual_seed(3)
+    row = (torch.randn(v, generator=g) * 1.0).to(BF16)
+    hot = torch.tensor([5, 77, 300, 301, 1024, 2000])
+    row[hot] = torch.tensor([6.0, 5.5, 5.0, 5.0, 4.5, 7.0]).to(BF16)  # id 2000 is the best and will be suppressed
+    n = 20000
+    logits = row.cuda().repeat(n, 1).contiguous()
+    u = torch.rand(n, generator=torch.Generator().manual_seed(4)).cuda()
+    nxt, probs = _sample(lib, logits, 1.0, 0.8, u, suppress=2000)
+    q = probs[0].float().cpu()
+    assert q[2000] == 0 and abs(float(q.sum()) - 1.0) < 2e-2
+    support = (q > 0).nonzero().flatten()
+    assert 3 <= support.numel() <= 64
+    counts = torch.bincount(nxt.cpu().long(), minlength=v).float()
+    assert counts[q == 0].sum() == 0
+    qn = q / q.sum()
+    sigma = (n * qn * (1 - qn)).sqrt()
+    assert ((counts - n * qn).abs() <= 5 * sigma + 1)[support].all(), (counts[support], n * qn[support])
+    # u -> 0 picks the lowest surviving id, u -> 1 the highest (inverse CDF over ids)
+    lo, _ = _sample(lib, logits[:1], 1.0, 0.8, torch.zeros(1, device="cuda"), suppress=2000, want_probs=False)
+    hi, _ = _sample(lib, logits[:1], 1.0, 0.8, torch.full((1,), 0.999999, device="cuda"), suppress=2000, want_probs=False)
+    assert int(lo[0]) == int(support.min()) and int(hi[0]) == int(support.max())
+
+
+def test_region_pick_encode_and_fourier(lib):
+    """argmax bin (ties -> lowest) -> table value -> [cos | sin] Fourier features, against torch ops
+    written like region.py:12-29 / moondream.py:672-713."""
+    b, n_bins, half = 5, 1024, 128
+    g = torch.Generator().manual_seed(9)
+    for groups in (1, 2):
+        logits = torch.randn(b, groups * n_bins, generator=g).to(BF16)
+        logits[0, 17] = logits[0, 900] = 9.0                      # tie: lowest index wins
+        table = (torch.arange(n_bins) / n_bins).to(BF16) if groups == 1 else \
+            torch.pow(2.0, (torch.arange(n_bins).float() / 1023.0) * 10.0 - 10.0).to(BF16)
+        w = (torch.randn(groups, half, generator=g) * 2.0).to(BF16)
+        bins = torch.full((b, groups), -1, dtype=torch.int32, device="cuda")
+        feats = torch.empty(b, 2 * half, dtype=BF16, device="cuda")
+        lg, tb, wd = logits.cuda(), table.cuda(), w.cuda()
+        _lib.check(lib.md_region_pick_encode(lg.data_ptr(), lg.stride(0), b, groups, n_bins, tb.data_ptr(), wd.data_ptr(), half,
+                                             bins.data_ptr(), groups, feats.data_ptr(), 2 * half, stream()))
+        torch.cuda.synchronize()
+        want_bins = torch.stack([logits[:, k * n_bins:(k + 1) * n_bins].float().argmax(-1) for k in range(groups)], 1)
+        assert bins.cpu().tolist() == want_bins.tolist()
+        assert bins[0, 0] == 17
+        x = table[want_bins]                                       # bf16 [b, groups]
+        f = 2 * math.pi * x @ w                                    # region.py:28, bf16 ops on the CPU
+        want = torch.cat([f.cos(), f.sin()], dim=-1)
+        err = (feats.float().cpu() - want.float()).abs().max()
+        assert float(err) <= 2.0 ** -7, float(err)                 # cos/sin values, one bf16 ulp at 1.0
+        out2 = torch.empty(b, 2 * half, dtype=BF16, device="cuda")
+        xd = x.cuda().contiguous()
+        _lib.check(lib.md_fourier_features(xd.data_ptr(), xd.stride(0), b, groups, wd.data_ptr(), half, out2.data_ptr(), 2 * half, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out2, feats)

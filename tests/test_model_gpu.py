@@ -10,7 +10,7 @@ from PIL import Image
 
 from moondream_amd import synth
 from moondream_amd.config import get_config
-from util import bits_to_bf16, compare
+from util import bits_to_bf16, compare, leading_wide_objects, margin_aware_mismatches, vit_fp64
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
@@ -24,6 +24,7 @@ def load_golden(golden_dir, name):
 
 
 def build(cfg_name, seed, max_batch=4):
+    max_batch = 128 if cfg_name == "2b" else max_batch  # the 2B test also runs the timed B=64 (x2 slot groups) config
     from moondream_amd.moondream import MoondreamModel, IdTokenizer
 
     cfg = get_config(cfg_name)
@@ -59,9 +60,10 @@ def test_vis_enc_seam_matches_reference(tiny):
     arr = np.array(golden_image(g, 0))
     x = O.normalize_crops(np.stack([arr, arr])).cuda()  # what prepare_crops hands to _vis_enc
     out = model._vis_enc(x)
-    compare("vit.out vs reference", out, bits_to_bf16(g["img0.vit.out"]), 3e-2)
+    # two correct bf16 evaluations of the 27-layer stack sit ~1.0e-2 apart (oracle vs reference: 1.02e-2)
+    compare("vit.out vs reference", out, bits_to_bf16(g["img0.vit.out"]), 1.5e-2)
     orc = O.vision_encoder(x.cpu(), {k: v.cpu() for k, v in sd.items()}, cfg)
-    compare("vit.out vs oracle", out, orc, 3e-2)
+    compare("vit.out vs oracle", out, orc, 1.5e-2)
     # identical crops must give identical features (no cross-row leakage in any kernel)
     assert torch.equal(out[0], out[1])
 
@@ -83,8 +85,8 @@ def test_encode_image_kv_matches_reference(tiny):
     assert len(enc.caches) == L and enc.caches[0][0].shape == (1, cfg.text.n_kv_heads, 730, 64)
     for li in (0, L - 1):
         k, v = enc.caches[li]
-        compare(f"k{li}", k[0, :, ::rs], bits_to_bf16(g[f"img0.cap.k{li}"]), 3e-2)
-        compare(f"v{li}", v[0, :, ::rs], bits_to_bf16(g[f"img0.cap.v{li}"]), 3e-2)
+        compare(f"k{li}", k[0, :, ::rs], bits_to_bf16(g[f"img0.cap.k{li}"]), 1.5e-2)
+        compare(f"v{li}", v[0, :, ::rs], bits_to_bf16(g[f"img0.cap.v{li}"]), 1.5e-2)
 
 
 @pytest.mark.parametrize("idx", [0, 1, 2])
@@ -167,7 +169,7 @@ def test_teacher_forced_logits_vs_reference(tiny):
     ref_tokens = g["img0.cap.tokens"].tolist()
     ref_logits = bits_to_bf16(g["img0.cap.step_logits"]).float()
     logits, hidden, pos = model._prefill_prompts([g["img0.cap.prompt"].tolist()], enc.pos, 0)
-    compare("prompt hidden", hidden[0], bits_to_bf16(g["img0.cap.prompt_hidden"]), 3e-2)
+    compare("prompt hidden", hidden[0], bits_to_bf16(g["img0.cap.prompt_hidden"]), 2e-2)
     for i, tok in enumerate(ref_tokens):
         lg = logits[0].float().cpu()
         if i > 0:
@@ -236,31 +238,194 @@ def test_multicrop_images_vs_reference(golden_dir):
         size = tuple(g[f"case{i}.size"])
         img = Image.fromarray(synth.synthetic_image_array(i, 3, size), "RGB")
         out = model._run_vision_encoder(img)
-        compare(f"multicrop case{i} vis.proj", out, bits_to_bf16(g[f"case{i}.vis.proj"]), 3e-2)
+        compare(f"multicrop case{i} vis.proj", out, bits_to_bf16(g[f"case{i}.vis.proj"]), 2e-2)
     # two different tilings in one batch
     imgs = [Image.fromarray(synth.synthetic_image_array(i, 3, tuple(g[f"case{i}.size"])), "RGB") for i in range(2)]
     both = model._run_vision_encoder_batch(imgs)
     for i in range(2):
-        compare(f"batched multicrop {i}", both[i], bits_to_bf16(g[f"case{i}.vis.proj"]), 3e-2)
+        compare(f"batched multicrop {i}", both[i], bits_to_bf16(g[f"case{i}.vis.proj"]), 2e-2)
 
 
-def test_detect_and_point_run(tiny):
-    """Region head: shape/range checks + oracle parity of the heads."""
+def test_vit_error_against_fp64_truth_no_worse_than_reference(tiny):
+    """The reference's bf16 ViT output is 9.6e-3 (rel-rms) away from an fp64 evaluation of the same
+    network; the HIP path must not be further than 1.2x that (i.e. it is as accurate as the
+    reference, not merely 'close to it')."""
     g, cfg, sd, model = tiny
     from oracle import moondream_oracle as O
 
-    orc = O.Oracle(cfg, {k: v.cpu() for k, v in sd.items()})
-    h = torch.randn(1, cfg.text.dim, generator=torch.Generator().manual_seed(0)).to(BF16)
-    compare("decode_coordinate", model.decode_coordinate(h.cuda()), orc.decode_coordinate(h), 1e-2)
-    compare("decode_size", model.decode_size(h.cuda()), orc.decode_size(h), 1e-2)
-    c = torch.tensor([[0.25]], dtype=BF16)
-    compare("encode_coordinate", model.encode_coordinate(c), orc.encode_coordinate(c), 1e-2)
-    s = torch.tensor([[0.5, 0.125]], dtype=BF16)
-    compare("encode_size", model.encode_size(s), orc.encode_size(s), 1e-2)
-    objs = model.detect(golden_image(g, 0), "7 8", settings={"max_objects": 2})["objects"]
-    assert len(objs) <= 2 and all(set(o) == {"x_min", "y_min", "x_max", "y_max"} for o in objs)
-    pts = model.point(golden_image(g, 0), "7 8", settings={"max_objects": 2})["points"]
-    assert len(pts) <= 2 and all(0.0 <= p["x"] < 1.0 and 0.0 <= p["y"] < 1.0 for p in pts)
+    arr = np.array(golden_image(g, 0))
+    x = O.normalize_crops(np.stack([arr, arr]))
+    truth = vit_fp64(x, sd, cfg)
+    rel = lambda a: float(((a.double().cpu() - truth) ** 2).mean().sqrt() / (truth ** 2).mean().sqrt())
+    e_ref = rel(bits_to_bf16(g["img0.vit.out"]))
+    e_hip = rel(model._vis_enc(x.cuda()))
+    print(f"rel-rms vs fp64 truth: reference {e_ref:.3e}, hip {e_hip:.3e}")
+    assert e_hip <= 1.2 * e_ref
+
+
+# ------------------------------------------------------------------ region head, pinned to the reference
+@pytest.fixture(scope="module")
+def detect_gold(golden_dir, tiny):
+    return load_golden(golden_dir, "tiny_detect.npz")
+
+
+@pytest.mark.parametrize("fn", ["decode_coordinate", "encode_coordinate", "decode_size", "encode_size"])
+def test_region_functions_match_reference_io_pairs(tiny, detect_gold, fn):
+    """Every call the reference made to region.py:32-93 during detect / point, replayed on the HIP heads."""
+    g0, cfg, sd, model = tiny
+    g = detect_gold
+    n = 0
+    for case in ("detect0", "detect1", "point0", "point1"):
+        key = f"{case}.{fn}.in"
+        if key not in g.files:
+            continue
+        xin, want = bits_to_bf16(g[key]).cuda(), bits_to_bf16(g[f"{case}.{fn}.out"])
+        if fn == "encode_coordinate":
+            got = model.encode_coordinate(xin.reshape(-1, 1))
+        elif fn == "encode_size":
+            got = model.encode_size(xin.reshape(-1, 2))
+        elif fn == "decode_size":
+            got = model.decode_size(xin).reshape(xin.shape[0], -1)
+        else:
+            got = model.decode_coordinate(xin)
+        compare(f"{case}.{fn}", got, want, 1e-2)
+        n += xin.shape[0]
+    assert n >= 4
+
+
+@pytest.mark.parametrize("case", ["detect0", "detect1", "point0", "point1"])
+def test_detect_point_vs_reference(tiny, detect_gold, case):
+    """detect / point through the public API: objects equal the reference's (exact floats) up to the
+    first decision whose reference margin is below 4 bf16 ulps."""
+    g0, cfg, sd, model = tiny
+    g = detect_gold
+    kind = "detect" if case.startswith("detect") else "point"
+    img = Image.fromarray(synth.synthetic_image_array(int(g[f"{case}.image_index"]), int(g["seed"]), (378, 378)), "RGB")
+    obj = " ".join(str(t) for t in g["object_ids"].tolist())
+    res = (model.detect if kind == "detect" else model.point)(img, obj, settings={"max_objects": int(g["max_objects"])})
+    objs = res["objects" if kind == "detect" else "points"]
+    ref = g[f"{case}.objects"]
+    n_ok = leading_wide_objects(g[f"{case}.margins"], 4.0)
+    assert n_ok >= 1 and len(objs) >= n_ok
+    keys = ("x_min", "y_min", "x_max", "y_max") if kind == "detect" else ("x", "y")
+    for k in range(n_ok):
+        assert [objs[k][f] for f in keys] == ref[k].tolist(), (case, k, objs[k], ref[k])
+
+
+def test_batch_detect_equals_sequential(tiny, detect_gold):
+    """B images in lockstep (ragged object prompts, mixed EncodedImage / PIL inputs) == one at a time."""
+    g0, cfg, sd, model = tiny
+    g = detect_gold
+    imgs = [Image.fromarray(synth.synthetic_image_array(int(g[f"{c}.image_index"]), int(g["seed"]), (378, 378)), "RGB")
+            for c in ("detect0", "detect1", "point0")]
+    objects = ["7 8", "7 8 9 10", "5"]
+    st = {"max_objects": 2}
+    seq = [model.detect(im, o, settings=st) for im, o in zip(imgs, objects)]
+    enc1 = model.encode_image(imgs[1])
+    got = model.batch_detect([imgs[0], enc1, imgs[2]], objects, settings=st)
+    assert got == seq
+    pts = model.batch_point(imgs, objects, settings=st)
+    assert pts == [model.point(im, o, settings=st) for im, o in zip(imgs, objects)]
+
+
+def test_spatial_ref_query_vs_reference(tiny, detect_gold):
+    """query(image, question, spatial_refs=[point, box]): moondream.py:577-604 + 293-301."""
+    g0, cfg, sd, model = tiny
+    g = detect_gold
+    img = Image.fromarray(synth.synthetic_image_array(int(g["spatial.image_index"]), int(g["seed"]), (378, 378)), "RGB")
+    refs = [tuple(g["spatial.refs_point"].tolist()), tuple(g["spatial.refs_box"].tolist())]
+    want = g["spatial.tokens"].tolist()
+    q = " ".join(str(t) for t in g["spatial.question"].tolist())
+    ans = model.query(img, q, spatial_refs=refs, settings={"temperature": 0, "max_tokens": len(want)})["answer"]
+    assert [int(t) for t in ans.split()] == want
+
+
+# ------------------------------------------------------------------ batched string API + HF wrapper
+def test_batch_generate_strings_ragged_equals_sequential(tiny):
+    """batch_generate / batch_query / batch_caption (the names BASELINE.json uses) with questions of
+    different token counts: ONE lockstep decode, answers equal query(...) one at a time."""
+    g, cfg, sd, model = tiny
+    images = [golden_image(g, i) for i in range(3)] + [golden_image(g, 0)]
+    questions = ["11 12 13", "21 22 23 24 25 26 27", "31", "11 12 13"]
+    st = {"temperature": 0, "max_tokens": 10}
+    seq = [model.query(im, q, settings=st)["answer"] for im, q in zip(images, questions)]
+    calls = []
+    orig = model._text_forward
+    model._text_forward = lambda x, *a, **k: (calls.append(tuple(x.shape)), orig(x, *a, **k))[1]
+    try:
+        got = model.batch_generate(images, questions, {"max_tokens": 10})
+    finally:
+        model._text_forward = orig
+    assert got == seq
+    assert got == model.batch_query(images, questions, {"max_tokens": 10})
+    prompt_prefills = [c for c in calls if c[1] not in (1, 730)]
+    assert len(prompt_prefills) == 3, calls  # one per distinct question length, not one per image
+    caps = model.batch_generate(images[:3], None, {"max_tokens": 8})
+    assert caps == [model.caption(im, settings={"temperature": 0, "max_tokens": 8})["caption"] for im in images[:3]]
+    assert caps == model.batch_caption(images[:3], "normal", {"max_tokens": 8})
+
+
+def test_mixed_encoded_and_raw_images_in_one_batch(tiny):
+    """an EncodedImage next to raw PIL images must keep its own KV slot."""
+    g, cfg, sd, model = tiny
+    images = [golden_image(g, i) for i in range(3)]
+    prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(3)]
+    n = len(g["img0.cap.tokens"])
+    ref = [g[f"img{i}.cap.tokens"].tolist() for i in range(3)]
+    enc0, enc2 = model.encode_image(images[0]), model.encode_image(images[2])
+    assert model.batch_generate_ids([enc0, images[1], images[2]], prompts, max_tokens=n) == ref
+    assert model.batch_generate_ids([images[0], images[1], enc2], prompts, max_tokens=n) == ref
+    assert model.batch_generate_ids([enc0, images[1], enc2], prompts, max_tokens=n) == ref
+
+
+def test_kv_slab_growth_keeps_loaded_slots_and_context_is_bounded(tiny):
+    g, cfg, sd, _ = tiny
+    from moondream_amd.moondream import MoondreamModel, IdTokenizer
+
+    model = MoondreamModel(cfg, sd, device="cuda", tokenizer=IdTokenizer(), max_batch=1)
+    enc = model.encode_image(golden_image(g, 0))
+    model.load_encoded_image(enc, 0)
+    model.load_encoded_image(model.encode_image(golden_image(g, 1)), 2)  # grows the slabs to 3 slots
+    assert model._max_batch >= 3
+    assert torch.equal(model._kv_k[0, 0:1, :, :730], enc.caches[0][0])   # slot 0 survived the growth
+    with pytest.raises(ValueError):                                       # ADVICE r1: no silent slab overrun
+        model._text_forward(torch.zeros(1, 8, cfg.text.dim, dtype=BF16, device="cuda"), cfg.text.max_context - 4, 0)
+    with pytest.raises(ValueError):
+        model._embed(torch.tensor([[cfg.text.vocab_size]]))
+
+
+def test_hf_wrapper_answer_question_and_batch_answer(tiny):
+    """HfMoondream (hf_moondream.py:37-183): lazy cache set-up, answer_question == query(...).strip(),
+    batch_answer == per-pair greedy query, generate() with the legacy prompt form, embedding accessors."""
+    g, cfg, sd, model = tiny
+    from moondream_amd.hf_moondream import HfMoondream, extract_question
+    from moondream_amd.moondream import IdTokenizer
+    import queue
+
+    hf = HfMoondream(cfg, sd, device="cuda", tokenizer=IdTokenizer(), max_batch=2)
+    assert hf.model._kv_k is None and not hf._is_kv_cache_setup
+    images = [golden_image(g, 0), golden_image(g, 1)]
+    questions = ["11 12 13", "21 22 23 24 25"]
+    st = {"temperature": 0, "max_tokens": 9}
+    want = [model.query(im, q, settings=st)["answer"].strip() for im, q in zip(images, questions)]
+    rq = queue.Queue()
+    assert hf.answer_question(images[0], questions[0], result_queue=rq, settings=st) == want[0]
+    assert hf._is_kv_cache_setup and rq.get_nowait() == want[0]
+    assert hf.batch_answer(images, questions, max_new_tokens=9) == want
+    enc = hf.encode_image(images[1])
+    assert hf.answer_question(enc, questions[1], settings=st) == want[1]
+    sampled = hf.answer_question(images[0], questions[0])          # default sampling settings, like the reference
+    assert isinstance(sampled, str)
+    legacy = "<image>\n\nQuestion: 11 12 13\n\nAnswer:"
+    assert extract_question(legacy) == "11 12 13"
+    assert isinstance(hf.generate(images[0], legacy)[0], str)
+    cont = hf.generate(images[0], "5 6 7", max_new_tokens=4, settings={"temperature": 0})[0]
+    assert 1 <= len(cont.split()) <= 4
+    ids = torch.tensor([[1, 2, 3]])
+    assert torch.equal(hf.input_embeds(ids).cpu(), hf.get_input_embeddings()(ids.cuda()).cpu())
+    assert hf.caption(images[0], settings={"temperature": 0, "max_tokens": 5})["caption"] == model.caption(images[0], settings={"temperature": 0, "max_tokens": 5})["caption"]
+    with pytest.raises(NotImplementedError):
+        hf._unsupported_exception()
 
 
 @pytest.mark.parametrize("name,cfg_name", [("md05b_seed1.npz", "0.5b"), ("md2b_seed1.npz", "2b")])
@@ -283,11 +448,11 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     arr = np.array(images[0])
     feats = model._vis_enc(O.normalize_crops(np.stack([arr, arr])).cuda())
     ts, fs = int(g["vit_token_stride"]), int(g["vit_feat_stride"])
-    compare(f"{cfg_name} vit.out", feats[:, ::ts, ::fs], bits_to_bf16(g["img0.vit.out"]), 4e-2)
+    compare(f"{cfg_name} vit.out", feats[:, ::ts, ::fs], bits_to_bf16(g["img0.vit.out"]), 1.5e-2)
     enc = model.encode_image(images[0])
     rs = int(g["kv_row_stride"])
     for li in (0, cfg.text.n_layers - 1):
-        compare(f"{cfg_name} k{li}", enc.caches[li][0][0, :, ::rs], bits_to_bf16(g[f"img0.cap.k{li}"]), 4e-2)
+        compare(f"{cfg_name} k{li}", enc.caches[li][0][0, :, ::rs], bits_to_bf16(g[f"img0.cap.k{li}"]), 1.5e-2)
     # top-8 logits of the prompt prefill
     model.load_encoded_image(enc)
     logits, _, _ = model._prefill_prompts([prompts[0]], enc.pos, 0)
@@ -302,3 +467,25 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
         if a != b:
             assert g["img0.vqa.margins"][i] <= 0.5, (i, a, b, g["img0.vqa.margins"][i])
             break
+    if cfg_name != "2b":
+        return
+    # THE TIMED CONFIGURATION (bench.py / BASELINE configs[2]): the 64 seed-1 images, B=64, 32 tokens,
+    # against the reference's ids for exactly these images (unfiltered, margin-aware)
+    gb = load_golden(golden_dir, "md2b_bench64.npz")
+    imgs64 = [synth.synthetic_image(i, int(gb["seed"])) for i in range(gb["tokens"].shape[0])]
+    pr = gb["prompt"].tolist()
+    for pipelined in (False, True):
+        if pipelined:
+            model.compile()
+            outs = list(model.batch_generate_ids_pipelined([(imgs64, [pr] * 64)] * 2, max_tokens=32, ignore_eos=True))
+            model.use_graphs = False
+            assert outs[0] == outs[1]
+            got64 = outs[1]
+        else:
+            got64 = model.batch_generate_ids(imgs64, [pr] * 64, max_tokens=32, ignore_eos=True)
+        exact, bad = margin_aware_mismatches(got64, gb["tokens"].tolist(), gb["margins"])
+        print(f"bench64 parity ({'pipelined+graphs' if pipelined else 'eager'}): {exact}/64 sequences identical to the reference, {len(bad)} violations")
+        assert not bad, bad[:5]
+        for i in g["image_index"].tolist():  # the wide-margin images of md2b_seed1 are among the 64: exact
+            assert got64[i] == gb["tokens"][i].tolist(), i
+        assert exact >= 4  # most of the 64 have at least one decision inside bf16 noise (margins recorded in the fixture)

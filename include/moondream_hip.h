@@ -133,6 +133,14 @@ md_status md_reduce_residual_layernorm(void* x, int64_t ldx, const float* partia
                                        void* y, int64_t ldy, const md_layernorm* ln, int32_t rows,
                                        int32_t dim, float eps, void* stream);
 
+/* Measurement / test hook, not needed by the product path: overrides one of the GEMM dispatch
+ * knobs at run time (the same knobs are read once from MD_GEMM_* / MD_DECODE_* environment
+ * variables at first use).  Keys: "tile" (-1 = automatic; 20 = four-wave 256x256, 11 / 15 = the
+ * eight-wave 256x256 baselines, 1 = 256x128, 2 = 128x128, 16 / 10 / 3 = decode-regime configs),
+ * "w4", "persist", "group_m", "decode_nt", "decode_cfg", "decode_slices".  Every config accumulates K
+ * in the same order, so outputs do not depend on these.  Unknown key: MD_ERR_INVALID_ARG. */
+md_status md_gemm_set_tuning(const char* key, int32_t value);
+
 /* Live timing of the GEMM launches for the roofline report: while enabled,
  * md_gemm_bf16 brackets every launch with HIP events on the caller's stream.
  * md_profile_gemm(0|1) also resets the log.  md_profile_gemm_read waits for the

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
@@ -99,6 +99,7 @@ SIGNATURES = {
                                            c_int32, c_int64, c_int64, c_void_p]),
     "md_reduce_residual_layernorm": (C.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                                c_int64, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_float, c_void_p]),
+    "md_gemm_set_tuning": (C.c_int, [C.c_char_p, c_int32]),
     "md_profile_gemm": (None, [c_int32]),
     "md_profile_gemm_read": (C.c_int, [c_int32, P(C.c_double), P(C.c_double), P(c_int64)]),
     "md_layernorm_bf16": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_float, c_void_p]),
@@ -151,30 +152,37 @@ def hipcc_path() -> str:
 def build_library(force: bool = False, verbose: bool = True) -> str:
     """Compile csrc/*.hip for gfx950 into moondream_amd/libmoondream_hip.so."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "md_common.hpp"), os.path.join(REPO, "include", "moondream_hip.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("md_common.hpp", "gemm_internal.hpp")] + [os.path.join(REPO, "include", "moondream_hip.h")]
     if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps + [os.path.abspath(__file__)]):
             return LIB_PATH
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs.  Every kernel here fits
-    # in <= 256 registers per wave, and the softmax / epilogue code works on the accumulators with
+    base = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs.  Every kernel built with it
+    # fits in <= 256 registers per wave, and the softmax / epilogue code works on the accumulators with
     # VALU instructions, so the default AGPR placement only adds v_accvgpr_read/write traffic
     # (prefill attention: ~190 moves per 64-key tile, and 216 -> 158 registers).
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+    # gemm_w4.hip is the exception: its 256 accumulator registers per wave live in a[0:255], named
+    # literally by inline asm (512-register waves, one per SIMD); it is compiled with -save-temps and its
+    # ISA is audited below.
+    vgpr_form = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
     procs = []
     objs = []
     for s in srcs:
-        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        name = os.path.basename(s)
+        o = os.path.join(objdir, name + ".o")
         objs.append(o)
+        flags = base + (["-save-temps=obj"] if name == "gemm_w4.hip" else vgpr_form)
         cmd = [hipcc_path(), *flags, "-c", s, "-o", o]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=objdir)))
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise MoondreamHipError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+    audit_asm_owned_accumulators(os.path.join(objdir, "gemm_w4-hip-amdgcn-amd-amdhsa-gfx950.s"))
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
@@ -182,6 +190,31 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if r.returncode != 0:
         raise MoondreamHipError("link failed:\n" + r.stdout.decode())
     return LIB_PATH
+
+
+def audit_asm_owned_accumulators(asm_path: str) -> None:
+    """gemm_w4.hip keeps its accumulators in a[0:255] through inline asm.  That is only sound while
+    the compiler itself never touches the accumulator file or spills in those kernels: any
+    v_accvgpr_* outside an inline-asm block, or any scratch access, fails the build."""
+    if not os.path.exists(asm_path):
+        raise MoondreamHipError(f"{asm_path} missing: gemm_w4.hip must be compiled with -save-temps=obj for the ISA audit")
+    in_asm, kernel, bad = False, None, []
+    for ln in open(asm_path):
+        t = ln.strip()
+        if t.endswith(":") and "gemm_w4_kernel" in t:
+            kernel = t
+        if ";;#ASMSTART" in t or t.startswith(";ASMSTART") or "ASMSTART" in t:
+            in_asm = True
+        elif "ASMEND" in t:
+            in_asm = False
+        elif kernel and not t.startswith(";"):
+            if ("v_accvgpr" in t and not in_asm) or t.startswith("scratch_"):
+                bad.append(t)
+        if t.startswith("s_endpgm"):
+            kernel = None
+    if bad:
+        raise MoondreamHipError("gemm_w4.hip: compiler-generated accumulator-file / scratch traffic in a kernel whose "
+                                "a[0:255] are owned by inline asm:\n  " + "\n  ".join(bad[:10]))
 
 
 _LIB = None

@@ -25,9 +25,11 @@
 //   * workgroup id -> tile: XCD-contiguous remap, then grouped (8 row panels x
 //     n) ordering so the 32 CUs of one XCD work on a compact 2-D block of
 //     tiles and share A/W slices through their private L2.
-#include "md_common.hpp"
+#include "gemm_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -43,29 +45,33 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 
-struct GemmK {
-  const bf16_t* A;
-  const bf16_t* W;
-  const bf16_t* bias;
-  const bf16_t* R;
-  bf16_t* C;
-  int64_t lda, ldw, ldc, ldr;
-  int M, n_store, n_pad, K;
-  int tiles_m, tiles_n;
-  int res_row_mod;
-  int group_m;  // tile-order grouping (row panels per group)
-  int gelu_from;  // EPI_GELU: columns >= gelu_from get the GELU
-  int prio;       // experiment: raise the wave priority around MFMA groups
-  int nt;         // decode regime: stream the weights with the non-temporal policy
-  // launch-boundary split-K: every K slice stores its fp32 partial tile [slice][m][ldp] and exits;
-  // the consumer kernel sums the slices (md_reduce_residual_layernorm)
-  float* partial;
-  int64_t partial_ld, partial_slice_stride;
-  // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
-  int slices;
-  float* slabs;
-  unsigned* tickets;
+// Experiment knobs, read ONCE (A/B runs; the product path never sets them).
+struct Knobs {
+  int tile = -1;       // MD_GEMM_TILE: force a tile config
+  int group_m = 8;     // MD_GEMM_GROUP_M: row panels per tile-order group
+  int w4 = 1;          // MD_GEMM_W4=0: the eight-wave 256x256 kernels instead of the four-wave one
+  int persist = 1;     // MD_GEMM_PERSIST=0 (eight-wave kernels only)
+  int nt = 0;          // MD_DECODE_NT=1: stream decode-regime weights non-temporally
+  int decode_cfg = 16; // MD_DECODE_CFG: d / 6 = alternatives to the 64x64 + helper-waves config
+  int decode_slices = 0;  // MD_DECODE_SLICES
+  Knobs() {
+    auto geti = [](const char* n, int d) { const char* e = getenv(n); return (e && *e) ? atoi(e) : d; };
+    tile = geti("MD_GEMM_TILE", -1);
+    group_m = std::max(1, geti("MD_GEMM_GROUP_M", 8));
+    w4 = geti("MD_GEMM_W4", 1);
+    persist = geti("MD_GEMM_PERSIST", 1);
+    nt = geti("MD_DECODE_NT", 0);
+    decode_slices = geti("MD_DECODE_SLICES", 0);
+    if (const char* dc = getenv("MD_DECODE_CFG")) {
+      if (dc[0] == 'd') decode_cfg = 3;
+      else if (dc[0] == '6') decode_cfg = 10;
+    }
+  }
 };
+Knobs& knobs() {
+  static Knobs k;
+  return k;
+}
 
 constexpr int BK = 64;  // K granularity of the packing contract (k_pad % 64 == 0) and default slice width
 
@@ -237,94 +243,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  if constexpr (PP == 1) {
-    // ---- ping-pong schedule -------------------------------------------------
-    // 32-wide slices, one slice = one PHASE (barrier + 2 K-steps).  The second half
-    // of the waves (one per SIMD, like the first half) runs ONE PHASE BEHIND the
-    // first: in phase ph the leading group works on slice ph, the lagging group on
-    // slice ph-1.  The lagging group prefetches the first fragments of its NEXT slice
-    // across the barrier (that slice was made visible one phase earlier), so right
-    // after every barrier it can issue MFMAs while the leading group is still
-    // fetching from LDS, and before the barrier the roles are reversed: the matrix
-    // pipe is not idle at slice boundaries the way it is when all eight waves stop,
-    // fetch and restart together.  The DMA of slice ph+DEPTH is issued in phase ph
-    // into the ring slot whose slice (ph-2) the lagging group finished in phase ph-1.
-    static_assert(KSTEPS == 2 && STAGES >= 4 && !SPLITK, "ping-pong config");
-    constexpr int PIECES = NA + NB;
-    constexpr int DEPTH = STAGES - 2;
-    static_assert((DEPTH - 1) * PIECES < 64, "vmcnt is a 6-bit counter");
-    const int lag = (wave >= (WM * WN) / 2) ? 1 : 0;  // wave is an SGPR value: uniform
-    static_for<0, DEPTH>([&](auto sc) {
-      constexpr int SL0 = decltype(sc)::value;
-      if (SL0 < nk) static_for<0, PIECES>([&](auto pc) { issue_piece(pc, SL0); });
-    });
-    bf16x8 af[2][MI], bfr[2][NI];
-    auto issue_reads = [&](auto set_c, auto step_c, uint32_t st) {
-      constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
-      const uint32_t coff = (uint32_t)(((2 * S + hi) ^ swz) * 16);
-      const uint32_t a_addr = st + a_row_off + coff, b_addr = st + b_row_off + coff;
-      static_for<0, NI>([&](auto j) { ds_read_b128<decltype(j)::value * 32 * ROW_BYTES>(bfr[SET][decltype(j)::value], b_addr); });
-      static_for<0, MI>([&](auto i) { ds_read_b128<decltype(i)::value * 32 * ROW_BYTES>(af[SET][decltype(i)::value], a_addr); });
-    };
-    bool prefetched = false;
-    for (int ph = 0; ph <= nk; ++ph) {
-      const int ahead = max(0, min(DEPTH - 1, nk - 1 - ph));
-      static_for<0, DEPTH>([&](auto ac) {
-        constexpr int A = decltype(ac)::value;
-        if (ahead == A) wait_vm<A * PIECES>();
-      });
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const bool has_next = ph + DEPTH < nk;
-      const int nstage = (ph + DEPTH) % STAGES;
-      const int sl = ph - lag;
-      auto mfma_step = [&](auto set_c, auto step_c) {
-        constexpr int SET = decltype(set_c)::value, S = decltype(step_c)::value;
-        constexpr int PPS = (PIECES + KSTEPS - 1) / KSTEPS;
-        if (p.prio) __builtin_amdgcn_s_setprio(1);
-        static_for<0, MI * NI>([&](auto mc) {
-          constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
-          acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
-          static_for<0, PPS>([&](auto qc) {
-            constexpr int Q = decltype(qc)::value, P = S + KSTEPS * Q;
-            if constexpr ((Q * MI * NI) / PPS == Mx && P < PIECES) {
-              __builtin_amdgcn_sched_barrier(0);
-              if (has_next) issue_piece(std::integral_constant<int, P>{}, nstage);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          });
-        });
-        if (p.prio) __builtin_amdgcn_s_setprio(0);
-      };
-      if (sl >= 0 && sl < nk) {
-        const uint32_t st = lds_base + (sl % STAGES) * STAGE;
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        if (!prefetched) issue_reads(I0{}, I0{}, st);
-        issue_reads(I1{}, I1{}, st);
-        wait_lgkm<MI + NI>();  // step-0 fragments are in; step-1 reads still in flight
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(I0{}, I0{});
-        __builtin_amdgcn_sched_barrier(0);
-        const bool pf = lag && (sl + 1 < nk);
-        if (pf) {
-          // next slice's first fragments, across the coming barrier (set 0 is free again)
-          issue_reads(I0{}, I0{}, lds_base + ((sl + 1) % STAGES) * STAGE);
-          wait_lgkm<MI + NI>();
-        } else {
-          wait_lgkm<0>();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(I1{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        prefetched = pf;
-      } else if (has_next) {
-        // this group idles in the first / last phase but still owes its DMA pieces
-        static_for<0, PIECES>([&](auto pc) { issue_piece(pc, nstage); });
-      }
-    }
-  } else if constexpr (ALT) {
+  if constexpr (ALT) {
     // ---- alternating wave groups (cdna guide 5: "8-phase" discipline) ----------
     // 32-wide slices, two PHASES per slice (the wave's upper / lower 64 rows), eight
     // MFMAs (256 matrix-pipe cycles) per phase on four independent accumulators.
@@ -463,7 +382,6 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
         // under the 32-cycle-per-MFMA matrix pipe instead of idling it at the head
         // of the slice.  Piece p goes to step p % KSTEPS, slot p / KSTEPS.
         constexpr int PPS = (NA + NB + KSTEPS - 1) / KSTEPS;  // pieces per K-step
-        if (p.prio) __builtin_amdgcn_s_setprio(1);
         static_for<0, MI * NI>([&](auto mc) {
           constexpr int Mx = decltype(mc)::value, I = Mx / NI, J = Mx % NI;
           acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[SET][J], af[SET][I], acc[I][J], 0, 0, 0);
@@ -477,7 +395,6 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
             }
           });
         });
-        if (p.prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -726,33 +643,16 @@ constexpr int DEC_STAGES = 4;  // decode-regime ring: 3 x 24 KiB slices in fligh
 template <int EPI>
 md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
   switch (tile) {
-    case 0: return launch_cfg<256, 256, 2, 4, EPI>(k, stream);
+    case 20: return md_gemm_w4_launch(k, EPI, stream);                              // 256x256, four waves (gemm_w4.hip)
     case 1: return launch_cfg<256, 128, 4, 2, EPI>(k, stream);
-    case 4: return launch_cfg<256, 128, 4, 2, EPI, false, 3>(k, stream);      // 3-deep ring
-    case 5: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32>(k, stream);  // 32-wide slices, 4-deep ring
-    case 6: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32>(k, stream);  // 32-wide slices, 5-deep ring
     case 3: return k.slices > 1 ? launch_cfg<64, 128, 1, 2, EPI, true, DEC_STAGES>(k, stream)
                                 : launch_cfg<64, 128, 1, 2, EPI, false, DEC_STAGES>(k, stream);
-    // decode regime, co-residency friendly: 4 waves of 32x64, 32-wide slices, 2-deep ring
-    // = 24 KiB LDS and <= 96 VGPRs, so these workgroups fit NEXT TO a resident 256x256
-    // encode tile (128 KiB LDS, 2 x 204 VGPRs per SIMD) when decode and encode overlap
-    // on two streams, instead of waiting for a CU to drain
-    case 7: return k.slices > 1 ? launch_cfg<64, 128, 2, 2, EPI, true, 2, 32>(k, stream)
-                                : launch_cfg<64, 128, 2, 2, EPI, false, 2, 32>(k, stream);
     // decode regime, 64x64 tiles: twice the tiles of 64x128 -> the wide fused layer needs no
     // split-K, the N = 2048 layers get 16 KiB slabs
     case 10: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4>(k, stream)
                                  : launch_cfg<64, 64, 2, 1, EPI, false, 4>(k, stream);
-    // same tiles, deeper rings: a workgroup's stream is latency-bound (slices in flight x 16 KiB
-    // per ~1.3 us round trip), so 7 / 8 slices in flight instead of 3
-    case 13: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 8>(k, stream)
-                                 : launch_cfg<64, 64, 2, 1, EPI, false, 8>(k, stream);
-    case 14: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 9>(k, stream)
-                                 : launch_cfg<64, 64, 2, 1, EPI, false, 9>(k, stream);
-    case 8: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 1>(k, stream);  // ping-pong wave groups
-    case 9: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 1>(k, stream);  // same, 5-deep ring
+    // the eight-wave 256x256 kernels the four-wave one replaced, kept as its A/B baseline (MD_GEMM_W4=0)
     case 11: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 2>(k, stream);  // alternating wave groups, 2 slices ahead
-    case 12: return launch_cfg<256, 256, 2, 4, EPI, false, 5, 32, 2>(k, stream);  // same, 3 slices ahead (160 KiB LDS)
     case 15: return launch_cfg<256, 256, 2, 4, EPI, false, 4, 32, 3>(k, stream);  // alternating + persistent tile loop
     // decode regime, 64x64 tiles + two DMA-only helper waves (4 waves issue the stream)
     case 16: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4, 64, 0, 2>(k, stream)
@@ -767,27 +667,16 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
 // function of (n, k) only.
 constexpr size_t TICKET_BYTES = 8192;
 
-// decode-regime config: "64" = 64x64 tiles (default), "deep" = 64x128 / 4-deep ring, "co" = 64x128 / 24 KiB
-int decode_cfg() {
-  const char* dc = getenv("MD_DECODE_CFG");
-  if (dc && dc[0] == 'd') return 3;
-  if (dc && dc[0] == 'c') return 7;
-  if (dc && dc[0] == 'e') return 13;
-  if (dc && dc[0] == 'f') return 14;
-  if (dc && dc[0] == '6') return 10;  // "64": two waves, no helpers
-  return 16;
-}
-bool decode_is64(int cfg) { return cfg == 10 || cfg == 13 || cfg == 14 || cfg == 16; }
+// decode-regime config: 16 = 64x64 tiles + helper waves (default), 10 = 64x64 without helpers, 3 = 64x128 / 4-deep ring
+int decode_cfg() { return knobs().decode_cfg; }
+bool decode_is64(int cfg) { return cfg == 10 || cfg == 16; }
 int decode_bn() { return decode_is64(decode_cfg()) ? 64 : 128; }
 int decode_slab_floats() { return decode_is64(decode_cfg()) ? 128 * 1 * 2 * 16 : 128 * 2 * 2 * 16; }  // NT * MI * NI * 16
 
 int decode_slices(int n_store, int k_pad) {
   const int DEC_BN = decode_bn();
   const int tiles = (n_store + DEC_BN - 1) / DEC_BN, nk = k_pad / BK;
-  if (const char* e = getenv("MD_DECODE_SLICES")) {  // experiments
-    const int v = atoi(e);
-    if (v >= 1) return std::min(v, std::max(1, nk));
-  }
+  if (knobs().decode_slices >= 1) return std::min(knobs().decode_slices, std::max(1, nk));  // experiments
   // measured model (profiles/r01_decode_gemm_sweep.txt): one workgroup saturates its
   // CU's load path (~40 GB/s), the last arriver pays ~1 us per 32 KiB slab, so
   // t ~ 2 us + bytes / (tiles * S * 40 GB/s) + S * 1 us: aim for ~256 workgroups, S <= 8
@@ -805,10 +694,9 @@ int decode_slices(int n_store, int k_pad) {
 // accumulates K in the same order (sequential 16-wide MFMA steps), so results do
 // not depend on it.
 int pick_tile(int M, int n_store) {
-  const char* e = getenv("MD_GEMM_TILE");  // experiments / tests: force a tile config
-  if (e && *e) return atoi(e);
+  if (knobs().tile >= 0) return knobs().tile;  // experiments / tests: force a tile config
   const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 128};
-  const double eff[3] = {1.0, 0.78, 0.62};
+  const double eff[3] = {1.0, 0.70, 0.55};
   int best = 2;
   double best_cost = 1e300;
   for (int c = 0; c < 3; ++c) {
@@ -820,12 +708,7 @@ int pick_tile(int M, int n_store) {
       best = c;
     }
   }
-  if (best == 0) {
-    // 256x256: the alternating-wave-group schedule (config 11) measured +5..13 % over the
-    // lockstep one on the model's shapes (profiles/r01_gemm_alternating_sweep.txt)
-    const char* alt = getenv("MD_GEMM_ALT");
-    if (!(alt && alt[0] == '0')) best = 11;
-  }
+  if (best == 0) best = knobs().w4 ? 20 : 11;
   return best;
 }
 
@@ -857,30 +740,23 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.K = a->lin.k_pad;
   k.res_row_mod = a->res_row_mod;
   k.tiles_m = k.tiles_n = 0;
-  k.group_m = 8;
+  k.group_m = knobs().group_m;
   k.gelu_from = a->gelu_from_col;
-  if (const char* e = getenv("MD_GEMM_GROUP_M")) k.group_m = std::max(1, atoi(e));  // experiments
-  k.prio = 0;
-  if (const char* e = getenv("MD_GEMM_PRIO")) k.prio = atoi(e);
   k.partial = nullptr;
   k.partial_ld = k.partial_slice_stride = 0;
-  k.nt = 0;  // decode regime: MD_DECODE_NT=1 streams the weights non-temporally (kernel-level +2..10 %, nothing end to end)
-  if (const char* e = getenv("MD_DECODE_NT")) k.nt = atoi(e);
+  k.nt = knobs().nt;  // decode regime: non-temporal weight stream (kernel-level +2..10 %, nothing end to end)
   hipStream_t s = (hipStream_t)stream;
   int tile = pick_tile(k.M, k.n_store);
   k.slices = 1;
   k.slabs = nullptr;
   k.tickets = nullptr;
-  const char* forced = getenv("MD_GEMM_TILE");
-  if (tile == 11 && a->epilogue != MD_EPI_RESIDUAL && !(forced && *forced)) {
-    // bias / GELU layers with more tiles than CUs: persistent tile loop, the next tile's first
-    // slices land under the current epilogue (+3..5 % at K = 1152; residual layers lose, see
-    // profiles/r01_gemm_persistent_tile_loop_sweep*.txt)
-    static const bool persist = [] { const char* e = getenv("MD_GEMM_PERSIST"); return !(e && e[0] == '0'); }();
+  const bool forced = knobs().tile >= 0;
+  if (tile == 11 && a->epilogue != MD_EPI_RESIDUAL && !forced) {
+    // eight-wave baseline: bias / GELU layers with more tiles than CUs run its persistent tile loop
     const long tiles = (long)((k.M + 255) / 256) * ((k.n_store + 255) / 256);
-    if (persist && tiles > 256) tile = 15;
+    if (knobs().persist && tiles > 256) tile = 15;
   }
-  if (a->m <= 64 && !(forced && *forced)) {
+  if (a->m <= 64 && !forced) {
     tile = decode_cfg();
     const int sl = decode_slices(k.n_store, k.K);
     const size_t tiles = (k.n_store + decode_bn() - 1) / decode_bn();
@@ -953,9 +829,7 @@ md_status fill_partial(GemmK& k, const void* a, int64_t lda, const md_linear* li
   k.tiles_n = (lin->n + 63) / 64;
   k.group_m = 8;
   k.gelu_from = 0;
-  k.prio = 0;
-  k.nt = 0;
-  if (const char* e = getenv("MD_DECODE_NT")) k.nt = atoi(e);
+  k.nt = knobs().nt;
   k.slices = md_gemm_partial_slices(lin);
   k.slabs = nullptr;
   k.tickets = nullptr;
@@ -1042,6 +916,21 @@ extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32
   if (sl == 1) return 0;
   const size_t tiles = (n_store + decode_bn() - 1) / decode_bn();
   return TICKET_BYTES + tiles * sl * decode_slab_floats() * sizeof(float);
+}
+
+extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
+  MD_CHECK_ARG(key != nullptr);
+  Knobs& k = knobs();
+  const std::string s(key);
+  if (s == "tile") k.tile = value;
+  else if (s == "group_m") k.group_m = std::max(1, (int)value);
+  else if (s == "w4") k.w4 = value;
+  else if (s == "persist") k.persist = value;
+  else if (s == "decode_nt") k.nt = value;
+  else if (s == "decode_cfg") k.decode_cfg = value;
+  else if (s == "decode_slices") k.decode_slices = value;
+  else return MD_ERR_INVALID_ARG;
+  return MD_OK;
 }
 
 extern "C" void md_profile_gemm(int32_t enable) {

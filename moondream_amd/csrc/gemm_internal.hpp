@@ -1,0 +1,31 @@
+// Internal interface between the GEMM translation units (not part of the C ABI).
+#pragma once
+#include "md_common.hpp"
+
+// One launch of  C = epilogue(A . W^T + b)  as the kernels see it.
+struct GemmK {
+  const bf16_t* A;
+  const bf16_t* W;
+  const bf16_t* bias;
+  const bf16_t* R;
+  bf16_t* C;
+  int64_t lda, ldw, ldc, ldr;
+  int M, n_store, n_pad, K;
+  int tiles_m, tiles_n;
+  int res_row_mod;
+  int group_m;    // tile-order grouping (row panels per group)
+  int gelu_from;  // EPI_GELU: columns >= gelu_from get the GELU
+  int nt;         // decode regime: stream the weights with the non-temporal policy
+  // launch-boundary split-K: every K slice stores its fp32 partial tile [slice][m][ldp] and exits;
+  // the consumer kernel sums the slices (md_reduce_residual_layernorm)
+  float* partial;
+  int64_t partial_ld, partial_slice_stride;
+  // split-K (decode regime only): K slices per output tile, fp32 slabs, arrival tickets
+  int slices;
+  float* slabs;
+  unsigned* tickets;
+};
+
+// gemm_w4.hip: the 256x256 tile kernel with one wave per SIMD (4 waves x 128x128), persistent.
+// epi = MD_EPI_*.  Fills tiles_m / tiles_n itself.
+md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream);

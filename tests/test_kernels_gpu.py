@@ -28,6 +28,18 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+@pytest.fixture
+def force_tile(lib):
+    """Pin the GEMM tile config through the library's measurement hook; automatic again afterwards."""
+    def set_tile(tile):
+        _lib.check(lib.md_gemm_set_tuning(b"tile", int(tile)))
+    yield set_tile
+    lib.md_gemm_set_tuning(b"tile", -1)
+
+
+BIG_TILES = ["20", "1", "2", "11", "15"]  # 20 = four-wave 256x256 (default for big shapes); 11 / 15 = its eight-wave baselines
+
+
 def randn(*shape, scale=1.0, seed=0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(BF16).cuda()
@@ -62,10 +74,10 @@ def pad_k(a, k_pad):
     return out
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12", "15"])
-def test_gemm_identity_detects_transposes(lib, tile, monkeypatch):
+@pytest.mark.parametrize("tile", BIG_TILES)
+def test_gemm_identity_detects_transposes(lib, tile, force_tile):
     """A = I with an ASYMMETRIC W: C must equal W^T bit for bit."""
-    monkeypatch.setenv("MD_GEMM_TILE", tile)
+    force_tile(tile)
     n = k = 512
     w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(BF16).cuda()
     a = torch.eye(k, dtype=BF16, device="cuda")
@@ -74,30 +86,62 @@ def test_gemm_identity_detects_transposes(lib, tile, monkeypatch):
     assert torch.equal(c, w.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "4", "5", "6", "8", "9", "11", "12", "15"])
+@pytest.mark.parametrize("tile", BIG_TILES)
 @pytest.mark.parametrize("m,k,n", [(300, 588, 1152), (777, 1152, 3456), (1000, 2048, 6144), (64, 2048, 1024), (1, 256, 64)])
-def test_gemm_bias(lib, tile, m, k, n, monkeypatch):
-    monkeypatch.setenv("MD_GEMM_TILE", tile)
+def test_gemm_bias(lib, tile, m, k, n, force_tile):
+    force_tile(tile)
     a, w, b = randn(m, k, seed=1), randn(n, k, scale=1 / math.sqrt(k), seed=2), randn(n, scale=0.1, seed=3)
     lin = PackedLinear(w, b, "cuda")
     c = gemm(lib, pad_k(a, lin.k_pad), lin)
     compare(f"gemm_bias {m}x{k}x{n} tile{tile}", c, ref_linear(a, w, b), 3e-3, 2e-2)
 
 
-def test_gemm_tile_configs_agree_bitwise(lib, monkeypatch):
+def test_gemm_tile_configs_agree_bitwise(lib, force_tile):
     """Every tile config accumulates K in the same order, so a layer's output does not
     depend on which one the heuristic picks; repeated launches double as a race screen
     for the hand-synchronised operand rings."""
     m, k, n = 2100, 4096, 2304
     a, w, b = randn(m, k, seed=11), randn(n, k, scale=1 / math.sqrt(k), seed=12), randn(n, scale=0.1, seed=13)
     lin = PackedLinear(w, b, "cuda")
-    monkeypatch.setenv("MD_GEMM_TILE", "2")
+    force_tile(2)
     want = gemm(lib, a, lin)
-    for tile in ("0", "1", "4", "5", "8", "11", "12", "15"):
-        monkeypatch.setenv("MD_GEMM_TILE", tile)
+    for tile in ("20", "1", "11", "15"):
+        force_tile(tile)
         for rep in range(6):
             got = gemm(lib, a, lin)
             assert torch.equal(got, want), f"tile {tile} rep {rep}"
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("m,k,n", [(46720 // 8, 2048, 2048), (2 * 729 * 4 + 77, 1152, 4304), (3000, 4352, 1152), (257, 64, 8), (5000, 640, 1152)])
+def test_gemm_w4_persistent_stream(lib, force_tile, m, k, n, epi):
+    """The four-wave 256x256 kernel (gemm_w4.hip): several tiles per workgroup through ONE continuous
+    slice stream (tile boundaries, ragged M and N edges, K = 64 .. 4352), all three epilogues, in-place
+    residual; bit-identical to the 128x128 config and repeated as a race screen for its hand-placed
+    barrier / counted waits."""
+    a, w, b = randn(m, k, seed=21), randn(n, k, scale=1 / math.sqrt(k), seed=22), randn(n, scale=0.1, seed=23)
+    lin = PackedLinear(w, b, "cuda")
+    x = randn(m, lin.n_pad if epi == 1 else n, seed=24)
+    store_pad = 1 if epi == 1 else 0
+
+    def run():
+        if epi == 2:
+            out = x.clone()
+            return gemm(lib, pad_k(a, lin.k_pad), lin, epi=2, r=out, out=out)
+        return gemm(lib, pad_k(a, lin.k_pad), lin, epi=epi, store_pad=store_pad)
+
+    force_tile(2)
+    want = run()
+    ref = ref_linear(a, w, b)
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref.float(), approximate="tanh").to(BF16)
+    if epi == 2:
+        ref = (x.float() + ref.float()).to(BF16)
+    compare(f"w4 reference m{m} k{k} n{n} epi{epi}", want[:, :n], ref, 3e-3, 2e-2)
+    force_tile(20)
+    for rep in range(4):
+        got = run()
+        assert torch.equal(got, want), f"rep {rep}: {(got != want).sum().item()} elements differ"
 
 
 def test_gemm_gelu_writes_zero_pad_columns(lib):

@@ -34,7 +34,7 @@ def timeit(fn, iters=10, warm=3):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def bench_gemm(m, k, n, epi=0, tiles=("0", "1", "2")):
+def bench_gemm(m, k, n, epi=0, tiles=("20", "11", "1", "2")):
     a = (torch.randn(m, (k + 63) // 64 * 64, device="cuda") * 0.5).to(BF16)
     w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(BF16)
     lin = PackedLinear(w, torch.zeros(n, dtype=BF16), "cuda")
@@ -48,10 +48,10 @@ def bench_gemm(m, k, n, epi=0, tiles=("0", "1", "2")):
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, ws.data_ptr(), need)
     res = []
     for t in tiles:
-        os.environ["MD_GEMM_TILE"] = t
+        lib.md_gemm_set_tuning(b"tile", int(t))
         dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())))
         res.append(2.0 * m * n * k / dt / 1e12)
-    os.environ.pop("MD_GEMM_TILE", None)
+    lib.md_gemm_set_tuning(b"tile", -1)
     dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())))
     auto = 2.0 * m * n * k / dt / 1e12
     extra = f"  ({2.0*n*k/dt/1e12:5.2f} TB/s weights, {dt*1e6:6.1f} us)" if m <= 64 else ""

@@ -4,9 +4,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tools import kernel_bench as kb
-os.environ["MD_GEMM_TILE"] = "11"
-kb.bench_gemm(8192, 8192, 8192, 0, tiles=("11",))
-kb.bench_gemm(23328, 1152, 3456, 0, tiles=("11",))
-os.environ.pop("MD_GEMM_TILE", None)
+TILE = os.environ.get("PMC_TILE", "20")  # 20 = four-wave 256x256, 11 = eight-wave baseline
+kb.bench_gemm(8192, 8192, 8192, 0, tiles=(TILE,))
+kb.bench_gemm(46720, 2048, 2048, 2, tiles=(TILE,))
+kb.bench_gemm(93312, 1152, 3456, 0, tiles=(TILE,))
 kb.bench_attn(32, 16, 729, 72)
 kb.bench_attn(64, 32, 730, 64, prefix=730)

@@ -19,13 +19,13 @@ for (m, k, n, epi) in [(64, 2048, 14336, 1), (64, 2048, 6144, 0), (64, 2048, 204
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr(), r.stride(0), 0, m, epi, 0, 0, ws.data_ptr(), ws.numel())
     out = []
     for cfg, nt in (("64", "0"), ("helpers", "0")):
-        os.environ["MD_DECODE_CFG"] = cfg; os.environ["MD_DECODE_NT"] = nt
+        lib.md_gemm_set_tuning(b"decode_cfg", 10 if cfg == "64" else 16); lib.md_gemm_set_tuning(b"decode_nt", int(nt))
         best = None
         for sl in (1, 2, 4, 8):
-            os.environ["MD_DECODE_SLICES"] = str(sl)
+            lib.md_gemm_set_tuning(b"decode_slices", sl)
             dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=20)
             if best is None or dt < best[0]: best = (dt, sl)
-        os.environ.pop("MD_DECODE_SLICES")
+        lib.md_gemm_set_tuning(b"decode_slices", 0)
         dflt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=20)
         out.append(f"cfg={cfg}{'+nt' if nt=='1' else ''}: default {dflt*1e6:5.1f}us best {best[0]*1e6:5.1f}us@S={best[1]}")
     print(f"m={m} k={k} n={n}: " + " | ".join(out) + f"   (ideal {2*n*k/6e12*1e6:.1f}us @6TB/s)", flush=True)

@@ -35,8 +35,8 @@ constexpr int BM = 256, BN = 256, BKT = 32;
 constexpr int ROW_BYTES = BKT * 2;             // 64-byte rows: 4 chunks of 16 bytes
 constexpr int A_BYTES = BM * ROW_BYTES;        // 16 KiB
 constexpr int STAGE = (BM + BN) * ROW_BYTES;   // 32 KiB
-constexpr int RING = 2 * STAGE;                // 64 KiB
-constexpr int XPOSE_BYTES = 32 * 256;          // 32 rows x 128 bf16: the epilogue's transposition tile
+constexpr int RING = 4 * STAGE;                // 128 KiB: the pair of slices being multiplied + the pair being written
+constexpr int XPOSE_BYTES = 32 * 128;          // 32 rows x 64 bf16: the epilogue's transposition tile
 constexpr int SCRATCH_PER_WAVE = XPOSE_BYTES + 256;  // + the wave's 128 bias values
 constexpr int LDS_BYTES = RING + 4 * SCRATCH_PER_WAVE;
 
@@ -73,6 +73,15 @@ __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
 }
 #define MD_PIN() __builtin_amdgcn_sched_barrier(0)
+// ablation builds: keep a value opaque / alive without emitting an instruction
+template <class T>
+__device__ __forceinline__ void opaque(T& v) {
+  asm volatile("" : "+v"(v));
+}
+template <class T>
+__device__ __forceinline__ void keep_alive(const T& v) {
+  asm volatile("" ::"v"(v));
+}
 
 // The 16 accumulator blocks of a wave (256 registers) live in a[0:255], OWNED BY INLINE ASM: block X is
 // a[16X : 16X+15].  As compiler-visible f32x16 values they made the register allocator shuffle and spill
@@ -101,7 +110,39 @@ __device__ __forceinline__ float acc_read() {
   return v;
 }
 
-template <int EPI>
+// ---- the filler schedule of one PAIR of slices (64 MFMAs, 64 gaps), as compile-time tables --------
+// Fillers are issued right AFTER the MFMA of their gap, in the order read, write, load:
+//   ds_read      every odd gap: 8 fragment reads per 16-gap half, for the half that follows
+//   ds_write     gaps 0, 3, 6, .., 45: the 16 pieces of the NEXT pair of slices (published by the barrier in gap 48)
+//   buffer_load  one gap after each write: the same registers are re-requested for the pair after that
+// The k-th read of a half fetches fragment kReadOrder[k] (0-3 = weight blocks j, 4-7 = activation blocks i) in
+// the order the MFMAs first need them: MFMA m = 4 i + j uses B_j and A_i, so B0 A0 B1 B2 B3 A1 A2 A3 are first
+// used by MFMAs 0 0 1 2 3 4 8 12 of the consuming half.
+constexpr int kReadOrder[8] = {0, 4, 1, 2, 3, 5, 6, 7};
+constexpr int kFirstUse[8] = {0, 0, 1, 2, 3, 4, 8, 12};  // by read position k
+constexpr bool gap_has_write(int g) { return ((g % 64) + 64) % 64 % 3 == 0 && ((g % 64) + 64) % 64 < 48; }
+// LDS operations issued strictly after the read of gap g_issue and before MFMA x_need (gaps along the periodic stream)
+constexpr int lds_ops_between(int g_issue, int x_need) {
+  int n = gap_has_write(g_issue) ? 1 : 0;  // the write of the read's own gap is issued after the read
+  for (int g = g_issue + 1; g < x_need; ++g) n += (((g % 2) + 2) % 2 == 1) + (gap_has_write(g) ? 1 : 0);
+  return n;
+}
+// lgkmcnt to wait for before MFMA m of half h (0..3) of a pair; -1: the MFMA introduces no new fragment.  The
+// fragments of half h are read in gaps 16 (h - 1) + 1 + 2 k  (half 0: at the end of the previous pair).
+constexpr int frag_wait(int h, int m) {
+  int w = -1;
+  for (int k = 0; k < 8; ++k)
+    if (kFirstUse[k] == m) {
+      const int c = lds_ops_between(16 * (h - 1) + 1 + 2 * k, 16 * h + m);
+      w = (w < 0 || c < w) ? c : w;
+    }
+  return w;
+}
+static_assert(frag_wait(0, 0) <= 15 && frag_wait(1, 12) <= 15 && frag_wait(2, 12) <= 15 && frag_wait(3, 0) <= 15, "lgkmcnt is a 4-bit counter");
+
+// ABL: timing ablations for profiling (bit 0: no ds_write, 1: no global loads, 2: no barrier, 3: no
+// fragment reads, 4: no epilogue stores); results are garbage with any bit set.
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -112,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int nk = p.K / BKT;  // even: K % 64 == 0
+  const int npair = p.K / 64;  // pairs of 32-wide slices per tile
 
   // workgroup sequence number -> tile: XCD-contiguous remap, then grouped (group_m row panels x all
   // column panels) order, so the 32 workgroups of an XCD that run together cover a compact block
@@ -125,39 +166,46 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     n0 = ((L % per_group) / gsz) * BN;
   };
 
-  // ---- load cursor: runs ~3 slices ahead of the MFMAs, across tile boundaries -----------------
-  // piece j of this thread: LDS slot j*256 + tid = row (slot >> 2), PHYSICAL chunk (slot & 3); it holds the
-  // row's LOGICAL chunk (slot & 3) ^ ((row >> 2) & 3), so a ds_read_b128 of one chunk column over 16
-  // consecutive-ish rows touches 16 distinct 16-byte bank slots.
+  // ---- load cursor: one pair of slices (64 K elements) at a time, across tile boundaries --------
+  // A load instruction covers 8 rows x 128 bytes: WHOLE cache lines (with 64-byte row pieces every line
+  // would be fetched twice, once per slice, ~1000 cycles apart, and the 32 KiB L1 does not keep it).  Piece
+  // j (0-7: activations, 8-15: weights) of this thread: row 32 (j & 7) + (tid >> 3), 16-byte chunk c8 = tid & 7
+  // of the row's 128 bytes: chunks 0-3 belong to the even slice of the pair, 4-7 to the odd one.
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffffu, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffffu, 0x00020000);
-  uint32_t a_voff[4], b_voff[4];
-  int ld_tile = blockIdx.x, ld_slice = 0;
+  uint32_t voff[16];
+  int ld_tile = blockIdx.x, ld_pair = 0;
   uint32_t ld_soff = 0;
   auto set_load_tile = [&](int vv) {
     int m0, n0;
     tile_origin(vv, m0, n0);
+    const int r8 = tid >> 3, c8 = tid & 7;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int slot = j * 256 + tid, r = slot >> 2, c = (slot & 3) ^ ((r >> 2) & 3);
-      a_voff[j] = (uint32_t)min(m0 + r, p.M - 1) * (uint32_t)(p.lda * 2) + c * 16;
-      b_voff[j] = (uint32_t)min(n0 + r, p.n_pad - 1) * (uint32_t)(p.ldw * 2) + c * 16;
+    for (int j = 0; j < 8; ++j) {
+      voff[j] = (uint32_t)min(m0 + 32 * j + r8, p.M - 1) * (uint32_t)(p.lda * 2) + c8 * 16;
+      voff[8 + j] = (uint32_t)min(n0 + 32 * j + r8, p.n_pad - 1) * (uint32_t)(p.ldw * 2) + c8 * 16;
     }
   };
   set_load_tile(ld_tile);
 
-  u32x4 R[2][8];  // two slices in registers: one landed / being written to LDS, one in flight
-  auto load_piece = [&](auto rs_c, auto j_c) {
-    constexpr int RS = decltype(rs_c)::value, J = decltype(j_c)::value;
-    if constexpr (J < 4)
-      R[RS][J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[J], ld_soff, 0));
+  u32x4 R[16];  // one pair of slices in registers; each piece is re-requested right after it is written out
+  if constexpr (ABL != 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) R[j] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  }
+  auto load_piece = [&](auto j_c) {
+    constexpr int J = decltype(j_c)::value;
+    if constexpr (ABL & 2)
+      opaque(R[J]);
+    else if constexpr (J < 8)
+      R[J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[J], ld_soff, 0));
     else
-      R[RS][J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff[J - 4], ld_soff, 0));
+      R[J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff[J], ld_soff, 0));
   };
   auto advance_load_cursor = [&]() {
-    ld_soff += ROW_BYTES;
-    if (++ld_slice == nk) {
-      ld_slice = 0;
+    ld_soff += 128;
+    if (++ld_pair == npair) {
+      ld_pair = 0;
       ld_soff = 0;
       // past the end of the stream the cursor stays on the last tile: the loads keep going
       // (their data is never written anywhere that is read), which keeps the loop free of branches
@@ -167,94 +215,113 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       }
     }
   };
-  const uint32_t wr_addr = lds_base + tid * 16;
-  auto write_piece = [&](auto rs_c, auto j_c, auto stage_c) {
-    constexpr int RS = decltype(rs_c)::value, J = decltype(j_c)::value, ST = decltype(stage_c)::value;
-    ds_write_b128<ST * STAGE + (J < 4 ? J * 4096 : A_BYTES + (J - 4) * 4096)>(wr_addr, R[RS][J]);
+
+  // ---- the LDS ring: four 32 KiB stages = two pairs, roles swapping after every pair (byte offsets,
+  // wave-uniform).  A stage holds one 32-wide slice: A rows then W rows, 64 bytes each, logical chunk c
+  // of row r at physical chunk c ^ ((r >> 2) & 3) (a ds_read_b128 of one chunk column over a 16-lane
+  // group's rows then touches 16 distinct 16-byte bank slots).  ODD slices additionally store row r at
+  // row r ^ 1: the two halves of a ds_write_b128's 8-lane group (even slice | odd slice of one row)
+  // would otherwise hit the same banks.
+  uint32_t pair_cur = 0, pair_wr = 2 * STAGE;
+  const uint32_t r8w = tid >> 3, c8w = tid & 7;
+  const uint32_t wr_even = lds_base + r8w * ROW_BYTES + (((c8w & 3) ^ ((r8w >> 2) & 3)) * 16);
+  const uint32_t wr_odd = lds_base + STAGE + (r8w ^ 1) * ROW_BYTES + (((c8w & 3) ^ ((r8w >> 2) & 3)) * 16);
+  const uint32_t wr_lane = (c8w < 4) ? wr_even : wr_odd;
+  auto write_piece = [&](auto j_c, uint32_t pair) {
+    constexpr int J = decltype(j_c)::value;
+    if constexpr (ABL & 1)
+      keep_alive(R[J]);
+    else
+      ds_write_b128<(J < 8 ? J * 32 * ROW_BYTES : A_BYTES + (J - 8) * 32 * ROW_BYTES)>(wr_lane + pair, R[J]);
   };
 
   // ---- fragment reads: K step s of a slice = logical chunks 2s (lanes 0-31) and 2s+1 (lanes 32-63)
   const uint32_t swz = (l31 >> 2) & 3;
-  const uint32_t a_row = lds_base + (wm * 128 + l31) * ROW_BYTES;
-  const uint32_t b_row = lds_base + A_BYTES + (wn * 128 + l31) * ROW_BYTES;
-  const uint32_t coff0 = ((0 + hi) ^ swz) * 16, coff1 = ((2 + hi) ^ swz) * 16;
-  const uint32_t ra[2] = {a_row + coff0, a_row + coff1}, rb[2] = {b_row + coff0, b_row + coff1};
+  const uint32_t coff[2] = {((0 + hi) ^ swz) * 16, ((2 + hi) ^ swz) * 16};
+  // [slice parity within the pair][K step]
+  uint32_t ra[2][2], rb[2][2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      ra[par][st] = lds_base + par * STAGE + ((wm * 128 + l31) ^ par) * ROW_BYTES + coff[st];
+      rb[par][st] = lds_base + par * STAGE + A_BYTES + ((wn * 128 + l31) ^ par) * ROW_BYTES + coff[st];
+    }
   bf16x8 fa[2][4], fb[2][4];  // [fragment set][32-row block]
-  // read q (0..7) of K step S of the slice in ring stage ST into fragment set SET: B blocks first
-  auto read_frag = [&](auto set_c, auto st_c, auto s_c, auto q_c) {
-    constexpr int SET = decltype(set_c)::value, ST = decltype(st_c)::value, S = decltype(s_c)::value, Q = decltype(q_c)::value;
-    if constexpr (Q < 4)
-      ds_read_b128<ST * STAGE + Q * 32 * ROW_BYTES>(fb[SET][Q], rb[S]);
+  if constexpr (ABL != 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fa[0][j] = fa[1][j] = fb[0][j] = fb[1][j] = bf16x8{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  }
+  auto read_frag = [&](auto set_c, auto q_c, uint32_t a_addr, uint32_t b_addr) {
+    constexpr int SET = decltype(set_c)::value, Q = decltype(q_c)::value;
+    if constexpr (ABL & 8) {
+      if constexpr (Q < 4) opaque(fb[SET][Q]); else opaque(fa[SET][Q - 4]);
+    } else if constexpr (Q < 4)
+      ds_read_b128<Q * 32 * ROW_BYTES>(fb[SET][Q], b_addr);
     else
-      ds_read_b128<ST * STAGE + (Q - 4) * 32 * ROW_BYTES>(fa[SET][Q - 4], ra[S]);
+      ds_read_b128<(Q - 4) * 32 * ROW_BYTES>(fa[SET][Q - 4], a_addr);
   };
 
   acc_reserve();
 
-  // ---- stream prologue: slices 0 and 1 requested, slice 0 written, slice 2 requested ----------
+  // ---- stream prologue: pair 0 written, pair 1 requested ---------------------------------------
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  static_for<0, 8>([&](auto j) { load_piece(I0{}, j); });
-  advance_load_cursor();
-  static_for<0, 8>([&](auto j) { load_piece(I1{}, j); });
+  static_for<0, 16>([&](auto j) { load_piece(j); });
   advance_load_cursor();
   asm volatile("" ::: "memory");
-  static_for<0, 8>([&](auto j) { write_piece(I0{}, j, I0{}); });
+  static_for<0, 16>([&](auto j) { write_piece(j, pair_cur); });
   asm volatile("" ::: "memory");
-  static_for<0, 8>([&](auto j) { load_piece(I0{}, j); });
+  static_for<0, 16>([&](auto j) { load_piece(j); });
   advance_load_cursor();
   wait_lgkm<0>();
   __builtin_amdgcn_s_barrier();
-  static_for<0, 8>([&](auto q) { read_frag(I0{}, I0{}, I0{}, q); });
+  static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, ra[0][0] + pair_cur, rb[0][0] + pair_cur); });
   wait_lgkm<0>();
   MD_PIN();
 
-  // One slice = two halves of 16 MFMAs.  P = parity of the stream slice g being multiplied:
-  //   ring stage P holds slice g; stage 1-P receives slice g+1 from R[1-P] during the FIRST half, and
-  //   R[1-P] is then re-requested for slice g+3; the barrier that publishes slice g+1 sits in the
-  //   SECOND half, followed by the reads of its first fragments (slice g+2 stays in flight in R[P]).
-  // There is ONE straight-line body per parity and no branch inside it: a second code path would
-  // merge 256 live accumulator registers at its join (the compiler then shuffles them through
-  // copies).  Past the end of the stream the fillers simply keep running on data nobody reads.
-  auto slice_body = [&](auto p_c, auto first_c) {
-    constexpr int P = decltype(p_c)::value;
+  // One pair of slices = 64 MFMAs = 64 gaps (four halves of 16: even slice K steps 0, 1, odd slice K steps 0, 1;
+  // fragment sets 0, 1, 0, 1).  The four waves run in lockstep between barriers, so whatever one wave does in a
+  // gap all four do: fillers of one kind are spread out so that neither the LDS nor the vector-memory front end
+  // sees a burst.  The pair being written was requested one pair (64 gaps, ~2000 cycles) earlier.  The barrier in
+  // gap 48 publishes it (every wave drains its own writes first); its stages were last read in gap 47 of the
+  // PREVIOUS pair, before that pair's barrier.  ONE straight-line body, no branch inside it (a second code path
+  // would be a join over ~200 live registers); past the end of the stream the fillers keep running on data nobody reads.
+  auto pair_body = [&](auto first_c) {
     constexpr bool FIRST = decltype(first_c)::value;  // first K step of a tile: accumulate onto zero
-    using PP = std::integral_constant<int, P>;
-    using NP = std::integral_constant<int, 1 - P>;
-    // ---- first half: K step 0 (fragment set 0)
-    static_for<0, 16>([&](auto mc) {
-      constexpr int X = decltype(mc)::value, I = X / 4, J = X % 4;
-      mfma_acc<X, FIRST>(fb[0][J], fa[0][I]);
-      MD_PIN();
-      if constexpr (X < 8) {
-        read_frag(I1{}, PP{}, I1{}, mc);   // set 1 <- slice g, K step 1
-        write_piece(NP{}, mc, NP{});       // slice g+1 -> the other stage
-      } else {
-        load_piece(NP{}, std::integral_constant<int, X - 8>{});  // slice g+3
-      }
-      MD_PIN();
-    });
-    advance_load_cursor();
-    wait_lgkm<0>();
-    MD_PIN();
-    // ---- second half: K step 1 (fragment set 1)
-    static_for<0, 16>([&](auto mc) {
-      constexpr int X = decltype(mc)::value, I = X / 4, J = X % 4;
-      mfma_acc<X, false>(fb[1][J], fa[1][I]);
-      MD_PIN();
-      if constexpr (X == 1) {
-        // every wave's writes of slice g+1 were waited for above; every wave's reads of stage 1-P
-        // (slice g-1) finished an iteration ago
+    const uint32_t a_e1 = ra[0][1] + pair_cur, b_e1 = rb[0][1] + pair_cur;   // even slice, K step 1
+    const uint32_t a_o0 = ra[1][0] + pair_cur, b_o0 = rb[1][0] + pair_cur;   // odd slice, K step 0
+    const uint32_t a_o1 = ra[1][1] + pair_cur, b_o1 = rb[1][1] + pair_cur;   // odd slice, K step 1
+    const uint32_t a_n0 = ra[0][0] + pair_wr, b_n0 = rb[0][0] + pair_wr;     // next pair's even slice, K step 0
+    const uint32_t wr = pair_wr;
+    static_for<0, 64>([&](auto xc) {
+      constexpr int X = decltype(xc)::value, H = X / 16, M = X % 16, I = M / 4, J = M % 4, SET = H & 1;
+      if constexpr (X == 48 && !(ABL & 4)) {
+        // this wave's writes (the last one in gap 45; one younger read in gap 47) are complete
+        wait_lgkm<1>();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      if constexpr (X >= 2 && X < 10)
-        read_frag(I0{}, NP{}, I0{}, std::integral_constant<int, X - 2>{});  // set 0 <- slice g+1, K step 0
+      // counted wait: the fragments this MFMA is the first to use have landed, younger LDS operations stay in flight
+      if constexpr (frag_wait(H, M) >= 0 && !(ABL & 8)) wait_lgkm<frag_wait(H, M)>();
+      mfma_acc<M, FIRST && H == 0>(fb[SET][J], fa[SET][I]);
+      MD_PIN();
+      if constexpr (X % 2 == 1) {
+        using Q = std::integral_constant<int, kReadOrder[(X % 16) / 2]>;
+        if constexpr (H == 0) read_frag(I1{}, Q{}, a_e1, b_e1);
+        if constexpr (H == 1) read_frag(I0{}, Q{}, a_o0, b_o0);
+        if constexpr (H == 2) read_frag(I1{}, Q{}, a_o1, b_o1);
+        if constexpr (H == 3) read_frag(I0{}, Q{}, a_n0, b_n0);
+      }
+      if constexpr (X % 3 == 0 && X < 48) write_piece(std::integral_constant<int, X / 3>{}, wr);
+      if constexpr (X % 3 == 1 && X < 48) load_piece(std::integral_constant<int, X / 3>{});
       MD_PIN();
     });
-    wait_lgkm<0>();
-    MD_PIN();
+    advance_load_cursor();
+    const uint32_t t = pair_cur;  // swap the roles of the two pairs of stages
+    pair_cur = pair_wr;
+    pair_wr = t;
   };
 
   // ---- tile loop ------------------------------------------------------------------------------
@@ -262,12 +329,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   for (int vtile = blockIdx.x; vtile < nwg; vtile += gridDim.x) {
     // the accumulators are (re)defined by the first K step of every tile: nothing is carried from
     // one tile to the next in them
-    slice_body(I0{}, std::true_type{});
-    slice_body(I1{}, std::false_type{});
-    for (int u = 2; u < nk; u += 2) {
-      slice_body(I0{}, std::false_type{});
-      slice_body(I1{}, std::false_type{});
-    }
+    pair_body(std::true_type{});
+    for (int u = 1; u < npair; ++u) pair_body(std::false_type{});
+    wait_lgkm<0>();
+    MD_PIN();
 
     // ---- epilogue of tile vtile (the next tile's first slices are already in the ring / in flight)
     // block X = 4 i + j, register r: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)   within the wave's quarter
@@ -275,9 +340,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     int m0c, n0c;
     tile_origin(vtile, m0c, n0c);
     const int wm0 = m0c + wm * 128, wn0 = n0c + wn * 128;
-    // the wave's 128 bias values go to LDS once per tile and are re-read per 32-row block (16 broadcast
-    // ds_read_b64): held in registers for the whole epilogue they cost 32 VGPRs that the residual
-    // variant does not have
+    // the wave's 128 bias values go to LDS once per tile and are re-read per pass (broadcast ds_read_b64)
     const uint32_t bias_lds = tile_lds + XPOSE_BYTES;
     if (lane < 32) {
       const int n = wn0 + 4 * lane;
@@ -285,52 +348,56 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       if (p.bias != nullptr && n < p.n_pad) bw = *(const u32x2*)(p.bias + n);
       ds_write_b64_asm(bias_lds + lane * 8, bw);
     }
-    // piece q of this lane in a 32 x 128 block: row (q*64 + lane) >> 4, 16-byte chunk (q*64 + lane) & 15
-    u32x4 rres[8];
-    auto load_residual = [&](int i) {
+    // eight passes of 32 rows x 64 columns (row block i, column half jp): bias add + ONE bf16 rounding on the
+    // accumulator layout, transposition through the wave's 4 KiB LDS tile, then GELU / residual and the global
+    // stores on whole 16-byte row pieces.  Piece q of this lane: row (q*64 + lane) >> 3, chunk (q*64 + lane) & 7.
+    auto load_residual = [&](int pass, u32x4 (&rv)[4]) {
+      const int i = pass >> 1, jp = pass & 1;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 4, ch = idx & 15;
-        const int m = wm0 + 32 * i + row, n = wn0 + ch * 8;
-        rres[q] = u32x4{0, 0, 0, 0};
+      for (int q = 0; q < 4; ++q) {
+        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+        const int m = wm0 + 32 * i + row, n = wn0 + 64 * jp + ch * 8;
+        rv[q] = u32x4{0, 0, 0, 0};
         if (m < p.M && n < p.n_store) {
           const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
-          rres[q] = *(const u32x4*)(p.R + rrow * p.ldr + n);
+          rv[q] = *(const u32x4*)(p.R + rrow * p.ldr + n);
         }
       }
     };
-    if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0);
+    u32x4 rres[2][4];
+    if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
     MD_PIN();
-    static_for<0, 4>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      u32x2 bias_w[4][4];
-      static_for<0, 16>([&](auto jq) {
-        constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
-        ds_read_b64_u32<(32 * j + 8 * q) * 2>(bias_w[j][q], bias_lds + hi * 8);
+    static_for<0, 8>([&](auto pc) {
+      constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
+      u32x2 bias_w[2][4];
+      static_for<0, 8>([&](auto jq) {
+        constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
+        ds_read_b64_u32<(32 * (2 * jp + jj) + 8 * q) * 2>(bias_w[jj][q], bias_lds + hi * 8);
       });
+      if constexpr (EPI == MD_EPI_RESIDUAL && PASS + 1 < 8) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
       wait_lgkm<0>();
       MD_PIN();
-      static_for<0, 16>([&](auto jq) {
-        constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4, base = 16 * (4 * i + j) + 4 * q;
+      static_for<0, 8>([&](auto jq) {
+        constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4, base = 16 * (4 * i + 2 * jp + jj) + 4 * q;
         u32x2 w;
-        w[0] = pack_bf16x2(acc_read<base + 0>() + lo_bf(bias_w[j][q][0]), acc_read<base + 1>() + hi_bf(bias_w[j][q][0]));
-        w[1] = pack_bf16x2(acc_read<base + 2>() + lo_bf(bias_w[j][q][1]), acc_read<base + 3>() + hi_bf(bias_w[j][q][1]));
-        constexpr int ch = 4 * j + q;
-        ds_write_b64_asm(tile_lds + l31 * 256 + ((ch ^ (l31 & 15)) * 16) + hi * 8, w);
+        w[0] = pack_bf16x2(acc_read<base + 0>() + lo_bf(bias_w[jj][q][0]), acc_read<base + 1>() + hi_bf(bias_w[jj][q][0]));
+        w[1] = pack_bf16x2(acc_read<base + 2>() + lo_bf(bias_w[jj][q][1]), acc_read<base + 3>() + hi_bf(bias_w[jj][q][1]));
+        constexpr int ch = 4 * jj + q;
+        ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, w);
       });
       MD_PIN();
-      u32x4 tv[8];
+      u32x4 tv[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 4, ch = idx & 15;
-        ds_read_b128_u32(tv[q], tile_lds + row * 256 + ((ch ^ (row & 15)) * 16));
+      for (int q = 0; q < 4; ++q) {
+        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+        ds_read_b128_u32(tv[q], tile_lds + row * 128 + ((ch ^ (row & 7)) * 16));
       }
       wait_lgkm<0>();
       MD_PIN();
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 4, ch = idx & 15;
-        const int m = wm0 + 32 * i + row, n = wn0 + ch * 8;
+      for (int q = 0; q < 4; ++q) {
+        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+        const int m = wm0 + 32 * i + row, n = wn0 + 64 * jp + ch * 8;
         u32x4 v = tv[q];
         if (m < p.M && n < p.n_store) {
           if constexpr (EPI == MD_EPI_GELU) {
@@ -344,27 +411,27 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
           } else if constexpr (EPI == MD_EPI_RESIDUAL) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = pack_bf16x2(lo_bf(rres[q][e]) + lo_bf(v[e]), hi_bf(rres[q][e]) + hi_bf(v[e]));
+              v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][q][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][q][e]) + hi_bf(v[e]));
           }
-          *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+          if constexpr (!(ABL & 16)) *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+          else keep_alive(v);
         }
       }
       MD_PIN();
-      // the next block's residual rows: requested now, used after its transposition
-      if constexpr (EPI == MD_EPI_RESIDUAL && i + 1 < 4) load_residual(i + 1);
-      MD_PIN();
     });
     // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
-    // registers the epilogue needs); its first slice was published by the last barrier above
-    static_for<0, 8>([&](auto q) { read_frag(I0{}, I0{}, I0{}, q); });
+    // registers the epilogue does not have to carry); its first pair was published by the last barrier above
+    static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, ra[0][0] + pair_cur, rb[0][0] + pair_cur); });
     wait_lgkm<0>();
     MD_PIN();
   }
 }
 
-template <int EPI>
+int g_w4_variant = 0;  // measurement hook (md_gemm_set_tuning "w4_variant"): 16 * ABL, bias epilogue only
+
+template <int EPI, int ABL = 0>
 md_status launch(const GemmK& k, hipStream_t stream) {
-  auto fn = gemm_w4_kernel<EPI>;
+  auto fn = gemm_w4_kernel<EPI, ABL>;
   static bool attr_set = false;  // per process: the library serves the process's current device
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
@@ -389,11 +456,26 @@ md_status launch(const GemmK& k, hipStream_t stream) {
 
 }  // namespace
 
+void md_gemm_w4_set_variant(int v) { g_w4_variant = v; }
+
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   if (k.K % 64 != 0 || k.M <= 0) return MD_ERR_INVALID_ARG;
   // 32-bit byte offsets into A and W
   if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32))
     return MD_ERR_UNSUPPORTED;
+  if (epi == MD_EPI_BIAS && g_w4_variant != 0) {
+    switch (g_w4_variant) {
+      case 16 * 1: return launch<MD_EPI_BIAS, 1>(k, stream);
+      case 16 * 2: return launch<MD_EPI_BIAS, 2>(k, stream);
+      case 16 * 3: return launch<MD_EPI_BIAS, 3>(k, stream);
+      case 16 * 4: return launch<MD_EPI_BIAS, 4>(k, stream);
+      case 16 * 8: return launch<MD_EPI_BIAS, 8>(k, stream);
+      case 16 * 16: return launch<MD_EPI_BIAS, 16>(k, stream);
+      case 16 * 15: return launch<MD_EPI_BIAS, 15>(k, stream);
+      case 16 * 31: return launch<MD_EPI_BIAS, 31>(k, stream);
+      default: return MD_ERR_INVALID_ARG;
+    }
+  }
   switch (epi) {
     case MD_EPI_BIAS: return launch<MD_EPI_BIAS>(k, stream);
     case MD_EPI_GELU: return launch<MD_EPI_GELU>(k, stream);

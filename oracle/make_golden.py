@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [0.5b] [2b] [bench64]
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [0.5b] [2b] [bench64] [reftime]
 """
 from __future__ import annotations
 
@@ -365,10 +365,7 @@ def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tok
     seed-1 378x378 images and caption prompt that bench.py times, Moondream-2B, greedy, 32 tokens.
     No survivorship filter: every image is kept, with the reference's top-1/top-2 margin of every
     decision, so bench.py / the GPU tests can compare the batched HIP ids margin-aware
-    (reference: moondream.py:434-539 behind caption(), moondream.py:625-651).  Also records the
-    reference's own CPU wall-clock per image (sample.py:159-207 style) -> profiles/."""
-    import json
-
+    (reference: moondream.py:434-539 behind caption(), moondream.py:625-651)."""
     cfg = get_config(cfg_name)
     sd = synth.synthetic_state_dict(cfg, seed=seed)
     model, ref_md = load_reference(cfg, sd)
@@ -394,21 +391,6 @@ def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tok
     path = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
-    timing = {
-        "what": "unmodified /root/reference moondream/torch (tokenizer stub + seeded synthetic weights), Moondream-2B bf16, "
-                "B=1 sequential, 378x378 synthetic images, caption prompt, greedy, 32 tokens; wall clock (time.perf_counter) "
-                "around encode_image and around the _generate_answer generator",
-        "host": {"cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "torch": torch.__version__},
-        "images": n_images,
-        "encode_s_p50": float(np.median(t_enc[1:])), "generate_s_p50": float(np.median(t_gen[1:])),
-        "images_per_sec": float(1.0 / (np.median(t_enc[1:]) + np.median(t_gen[1:]))),
-        "encode_s": [round(x, 3) for x in t_enc], "generate_s": [round(x, 3) for x in t_gen],
-        "note": "image 0 is the warm-up and is excluded from the medians",
-    }
-    prof = os.path.join(REPO, "profiles", "r02_reference_cpu_timing_build_container.json")
-    with open(prof, "w") as f:
-        json.dump(timing, f, indent=1)
-    print(f"[{name}] wrote {prof}", flush=True)
 
 
 def gen_detect(name="tiny_detect", cfg_name="tiny", seed=1, n_cases=2, max_objects=3, min_margin=4.0):
@@ -580,6 +562,42 @@ def gen_sampling(name="sampling_top_p", seed=7):
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
 
 
+def gen_reftime(cfg_name="2b", seed=1, n_images=5, max_tokens=32):
+    """The REFERENCE's own CPU wall clock on the bench workload, measured in the build container with
+    nothing else running (method of sample.py:159-207: warm-up, then timed runs; time.perf_counter
+    around encode_image and around the answer generator).  Committed under profiles/ as the
+    cross-check of bench.py's cpu_baseline (which has to use the oracle: /root/reference does not
+    exist on the GPU box)."""
+    import json
+
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    caption_ids = cfg.tokenizer.templates["caption"]["normal"]
+    t_enc, t_gen = [], []
+    for i in range(n_images):
+        r = run_reference_caption(model, ref_md, synth.synthetic_image_array(i, seed, (378, 378)), caption_ids, max_tokens)
+        t_enc.append(r["t_enc"])
+        t_gen.append(r["t_gen"])
+        print(f"[reftime] image {i}: encode {r['t_enc']:.2f}s generate {r['t_gen']:.2f}s ({len(r['tokens'])} tokens)", flush=True)
+    timing = {
+        "what": "unmodified /root/reference moondream/torch (tokenizer stub + seeded synthetic weights), Moondream-2B bf16, "
+                "B=1 sequential, 378x378 synthetic images, caption prompt, greedy, 32 tokens; wall clock (time.perf_counter) "
+                "around encode_image and around the _generate_answer generator",
+        "host": {"cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "torch": torch.__version__},
+        "images_timed": n_images - 1,
+        "encode_s_p50": float(np.median(t_enc[1:])), "generate_s_p50": float(np.median(t_gen[1:])),
+        "seconds_per_token": float(np.median(t_gen[1:]) / max_tokens),
+        "images_per_sec": float(1.0 / (np.median(t_enc[1:]) + np.median(t_gen[1:]))),
+        "encode_s": [round(x, 3) for x in t_enc], "generate_s": [round(x, 3) for x in t_gen],
+        "note": "image 0 is the warm-up and is excluded from the medians",
+    }
+    prof = os.path.join(REPO, "profiles", "r02_reference_cpu_timing_build_container.json")
+    with open(prof, "w") as f:
+        json.dump(timing, f, indent=1)
+    print(f"[reftime] {timing['images_per_sec']:.3f} images/s on {os.cpu_count()} cores -> {prof}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -599,6 +617,8 @@ def main():
         gen_sampling()
     if "detect" in which:
         gen_detect()
+    if "reftime" in which:
+        gen_reftime()
     if "bench64" in which:
         gen_bench64()
     if "2b" in which:

@@ -567,7 +567,7 @@ def test_sample_top_p_distribution_and_suppression(lib):
     a handful of tokens; empirical frequencies within 5 sigma of q.  The suppressed id is never drawn."""
     v = 2048
     g = torch.Generator().manual_seed(3)
-    row = (torch.randn(v, generator=g) * 1.0).to(BF16)
+    row = (torch.randn(v, generator=g) * 0.5 - 4.0).to(BF16)  # background: ~4 % of the mass
     hot = torch.tensor([5, 77, 300, 301, 1024, 2000])
     row[hot] = torch.tensor([6.0, 5.5, 5.0, 5.0, 4.5, 7.0]).to(BF16)  # id 2000 is the best and will be suppressed
     n = 20000

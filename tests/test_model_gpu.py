@@ -383,9 +383,10 @@ def test_kv_slab_growth_keeps_loaded_slots_and_context_is_bounded(tiny):
     from moondream_amd.moondream import MoondreamModel, IdTokenizer
 
     model = MoondreamModel(cfg, sd, device="cuda", tokenizer=IdTokenizer(), max_batch=1)
-    enc = model.encode_image(golden_image(g, 0))
+    enc1 = model.encode_image(golden_image(g, 1))
+    enc = model.encode_image(golden_image(g, 0))   # encode_image works in slot 0: do it before loading slots
     model.load_encoded_image(enc, 0)
-    model.load_encoded_image(model.encode_image(golden_image(g, 1)), 2)  # grows the slabs to 3 slots
+    model.load_encoded_image(enc1, 2)               # grows the slabs to 3 slots
     assert model._max_batch >= 3
     assert torch.equal(model._kv_k[0, 0:1, :, :730], enc.caches[0][0])   # slot 0 survived the growth
     with pytest.raises(ValueError):                                       # no silent slab overrun

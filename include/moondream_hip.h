@@ -151,6 +151,10 @@ md_status md_gemm_set_tuning(const char* key, int32_t value);
  * hipGraph capture. */
 void md_profile_gemm(int32_t enable);
 md_status md_profile_gemm_read(int32_t kind, double* work, double* ms, int64_t* launches);
+/* Algorithmic HBM bytes of the logged launches of one family: operands read once (A rows x k_pad,
+ * W n_pad x k_pad, residual rows) and results written once -- the yard-stick for the PMC traffic
+ * counters (FETCH_SIZE / WRITE_SIZE) of the same step. */
+md_status md_profile_gemm_bytes(int32_t kind, double* read_bytes, double* written_bytes);
 
 /* y[r, :dim] = LN(x[r, :dim]) * w + b, fp32 statistics, eps as given
  * (reference: layers.py:118-119, default eps 1e-5).  dim % 8 == 0, dim <= 4096. */

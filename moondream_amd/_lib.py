@@ -102,6 +102,7 @@ SIGNATURES = {
     "md_gemm_set_tuning": (C.c_int, [C.c_char_p, c_int32]),
     "md_profile_gemm": (None, [c_int32]),
     "md_profile_gemm_read": (C.c_int, [c_int32, P(C.c_double), P(C.c_double), P(c_int64)]),
+    "md_profile_gemm_bytes": (C.c_int, [c_int32, P(C.c_double), P(C.c_double)]),
     "md_layernorm_bf16": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_float, c_void_p]),
     "md_patchify_u8": (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "md_patchify_bf16": (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),

@@ -40,6 +40,7 @@ namespace {
 struct ProfRec {
   hipEvent_t start, stop;
   double work;  // kind 0: algorithmic flops; kind 1: weight bytes streamed
+  double rd, wr;  // algorithmic operand bytes read (A + W + residual, padded dims) / result bytes written
   int kind;     // 0 = MFMA tile kernel, 1 = decode-regime weight-streaming kernel
 };
 bool g_prof_on = false;
@@ -776,6 +777,9 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
     rec.kind = a->m <= 64 ? 1 : 0;
     rec.work = rec.kind ? 2.0 * (double)a->lin.n * (double)a->lin.k           // bf16 weight bytes, logical n, k
                         : 2.0 * a->m * (double)a->lin.n * (double)a->lin.k;  // algorithmic flops
+    rec.rd = 2.0 * ((double)a->m * a->lin.k_pad + (double)a->lin.n_pad * a->lin.k_pad +
+                    (a->epilogue == MD_EPI_RESIDUAL ? (double)(a->res_row_mod ? a->res_row_mod : a->m) * k.n_store : 0.0));
+    rec.wr = 2.0 * (double)a->m * k.n_store;
     (void)hipEventRecord(rec.start, s);
   }
   md_status st;
@@ -850,6 +854,8 @@ struct ProfScope {  // HIP-event bracket of one launch for md_profile_gemm (kind
     if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return MD_ERR_LAUNCH;
     rec.kind = 1;
     rec.work = work;
+    rec.rd = work;
+    rec.wr = 0;
     (void)hipEventRecord(rec.start, s);
     return MD_OK;
   }
@@ -941,6 +947,19 @@ extern "C" void md_profile_gemm(int32_t enable) {
   }
   g_prof.clear();
   g_prof_on = enable != 0;
+}
+
+extern "C" md_status md_profile_gemm_bytes(int32_t kind, double* read_bytes, double* written_bytes) {
+  MD_CHECK_ARG(read_bytes && written_bytes);
+  double r = 0, w = 0;
+  for (auto& rec : g_prof)
+    if (rec.kind == kind) {
+      r += rec.rd;
+      w += rec.wr;
+    }
+  *read_bytes = r;
+  *written_bytes = w;
+  return MD_OK;
 }
 
 extern "C" md_status md_profile_gemm_read(int32_t kind, double* work, double* ms, int64_t* launches) {

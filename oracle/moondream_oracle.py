@@ -65,9 +65,24 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], fast: bo
     return _r(y)
 
 
+# Timed-baseline switch (bench.py's cpu_baseline only): when set, the elementwise / normalisation ops below are
+# issued as the single ATen calls the reference makes on bf16 tensors (F.layer_norm, F.gelu, bf16 adds) instead
+# of their explicit fp32 restatements -- same roundings, a fraction of the memory passes.  Never set by tests.
+ATEN_CALLS = False
+
+
+def add_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """bf16 + bf16 -> bf16 (one rounding): the reference's residual adds (vision.py:70-71, text.py:158)."""
+    if ATEN_CALLS:
+        return a + b
+    return _r(a.float() + b.float())
+
+
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
     """reference: layers.py:118-119 (F.layer_norm, default eps, affine).
     Statistics in fp32 over the last dim, biased variance, one rounding."""
+    if ATEN_CALLS:
+        return F.layer_norm(x, (x.shape[-1],), w, b, eps)
     xf = x.float()
     mu = xf.mean(dim=-1, keepdim=True)
     var = ((xf - mu) ** 2).mean(dim=-1, keepdim=True)
@@ -77,6 +92,8 @@ def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1
 
 def gelu_tanh(x: torch.Tensor):
     """reference: layers.py:24-25 (F.gelu(approximate="tanh")), fp32 inside."""
+    if ATEN_CALLS:
+        return F.gelu(x, approximate="tanh")
     xf = x.float()
     k = math.sqrt(2.0 / math.pi)
     inner = k * (xf + 0.044715 * xf * xf * xf)
@@ -91,12 +108,19 @@ def mlp(x, sd, prefix, fast=False):
     return linear(h, sd[prefix + ".fc2.weight"], sd[prefix + ".fc2.bias"], fast)
 
 
-def softmax_attention(q, k, v, allowed: Optional[torch.Tensor], scale: float):
+def softmax_attention(q, k, v, allowed: Optional[torch.Tensor], scale: float, fast: bool = False):
     """softmax(q k^T * scale) v per head, fp32 scores, probabilities rounded to
     bf16 for the second contraction, fp32 row-sum normalisation at the end
     (flash-style; reference: F.scaled_dot_product_attention at layers.py:163
     and text.py:48-50).  q [.., Tq, d], k/v [.., Tk, d]; ``allowed`` is a bool
     [Tq, Tk] (True = attend) or None."""
+    if fast:
+        # the very call the reference makes (bf16 operands, optional bool mask): used by the timed CPU baseline
+        if q.dim() == 3:  # [H, T, d]: give SDPA the reference's 4-D shapes (batch 1, mask [1, 1, Tq, Tk]) so that it
+            # takes the same fused CPU kernel as in the reference instead of the unfused math path
+            m4 = None if allowed is None else allowed[None, None]
+            return F.scaled_dot_product_attention(q[None], k[None], v[None], attn_mask=m4, scale=scale)[0]
+        return F.scaled_dot_product_attention(q, k, v, attn_mask=allowed, scale=scale)
     s = (q.float() @ k.float().transpose(-1, -2)) * scale
     if allowed is not None:
         s = s.masked_fill(~allowed, float("-inf"))
@@ -152,7 +176,7 @@ def vit_attention(x, sd, prefix, n_heads, fast=False):
         qkv[..., i * d : (i + 1) * d].reshape(n, t, n_heads, hd).permute(0, 2, 1, 3)
         for i in range(3)
     )
-    o = softmax_attention(q, k, v, None, 1.0 / math.sqrt(hd))
+    o = softmax_attention(q, k, v, None, 1.0 / math.sqrt(hd), fast)
     o = o.permute(0, 2, 1, 3).reshape(n, t, d)
     return linear(o, sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"], fast)
 
@@ -170,9 +194,9 @@ def vision_encoder(x_bchw: torch.Tensor, sd, cfg, tap: Optional[dict] = None, fa
         a = vit_attention(
             layer_norm(x, sd[p + ".ln1.weight"], sd[p + ".ln1.bias"]), sd, p + ".attn", v.enc_n_heads, fast
         )
-        x = _r(x.float() + a.float())
+        x = add_bf16(x, a)
         m = mlp(layer_norm(x, sd[p + ".ln2.weight"], sd[p + ".ln2.bias"]), sd, p + ".mlp", fast)
-        x = _r(x.float() + m.float())
+        x = add_bf16(x, m)
         if tap is not None and i in (0, v.enc_n_layers - 1):
             tap[f"vit.block{i}"] = x
     x = layer_norm(x, sd["vision.post_ln.weight"], sd["vision.post_ln.bias"])
@@ -326,11 +350,13 @@ def text_attention(x, sd, prefix, cfg, layer, kv: OracleKV, pos: torch.Tensor, c
     kv.k[layer][:, pos] = k
     kv.v[layer][:, pos] = v
     n_kv = int(pos.max()) + 1  # slots beyond are masked out in the reference
+    if fast:
+        n_kv = t.max_context  # the reference attends over all cache slots under its bool mask (text.py:48-50)
     kk, vv = kv.k[layer][:, :n_kv], kv.v[layer][:, :n_kv]
     if t.n_kv_heads != t.n_heads:
         rep = t.n_heads // t.n_kv_heads
         kk, vv = kk.repeat_interleave(rep, 0), vv.repeat_interleave(rep, 0)
-    o = softmax_attention(q, kk, vv, allowed[:, :n_kv], 1.0 / math.sqrt(hd))
+    o = softmax_attention(q, kk, vv, allowed[:, :n_kv], 1.0 / math.sqrt(hd), fast)
     o = o.permute(1, 0, 2).reshape(T, qd)
     return linear(o, sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"], fast)
 
@@ -347,7 +373,7 @@ def text_decoder(x, sd, cfg, kv: OracleKV, pos: torch.Tensor, cos, sin, tap=None
         h = layer_norm(x, sd[p + ".ln.weight"], sd[p + ".ln.bias"])
         a = text_attention(h, sd, p + ".attn", cfg, i, kv, pos, cos, sin, allowed, fast)
         m = mlp(h, sd, p + ".mlp", fast)
-        x = _r(_r(x.float() + a.float()).float() + m.float())
+        x = add_bf16(add_bf16(x, a), m)
         if tap is not None and i in (0, t.n_layers - 1):
             tap[f"text.block{i}"] = x
     return x

@@ -98,7 +98,6 @@ def cpu_baseline(cfg, sd, seed, T, budget_s=25.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, cores))
     O.ATEN_CALLS = True  # layer norm / GELU / residual adds as the single ATen calls the reference makes
     t_begin = time.perf_counter()
     v, t = cfg.vision, cfg.text
@@ -124,8 +123,20 @@ def cpu_baseline(cfg, sd, seed, T, budget_s=25.0):
 
     with torch.inference_mode():
         x = torch.randn(2, v.n_patches, v.enc_dim, generator=g).to(torch.bfloat16)
-        t_vblock = timed(lambda: vit_block(x))
-        log(f"ViT block on 2 crops {t_vblock:.3f}s")
+        # thread count: all logical cores is NOT the fastest setting on a many-core host (256 threads ran this
+        # block 50x slower than 8 do on the build container); try a few counts on the ViT block, keep the best
+        best = None
+        for nthreads in sorted({min(cores, c) for c in (16, 32, 64, 128)}):
+            torch.set_num_threads(nthreads)
+            tb = timed(lambda: vit_block(x))
+            log(f"ViT block on 2 crops, {nthreads} threads: {tb:.3f}s")
+            if best is None or tb < best[0]:
+                best = (tb, nthreads)
+            if tb > 1.0 or time.perf_counter() - t_begin > 0.25 * budget_s:
+                break
+        t_vblock, threads = best
+        torch.set_num_threads(threads)
+        cores = threads  # reported as the threads actually used
         cfg1 = type(cfg)(text=type(t)(**{**t.__dict__, "n_layers": 1}), vision=v, region=cfg.region, tokenizer=cfg.tokenizer)
         cos, sin = O.rope_table(t.rot_dim // 2, t.max_context)
         kv1 = O.OracleKV.empty(cfg1)

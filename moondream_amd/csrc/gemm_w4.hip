@@ -413,12 +413,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
             for (int e = 0; e < 4; ++e)
               v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][q][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][q][e]) + hi_bf(v[e]));
           }
-          if constexpr (!(ABL & 16)) *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+          if constexpr (ABL & 128) __builtin_nontemporal_store(v, (u32x4*)(p.C + (int64_t)m * p.ldc + n));
+          else if constexpr (!(ABL & 16)) *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
           else keep_alive(v);
         }
       }
       MD_PIN();
     });
+    if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
     // registers the epilogue does not have to carry); its first pair was published by the last barrier above
     static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, ra[0][0] + pair_cur, rb[0][0] + pair_cur); });
@@ -473,6 +475,8 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
       case 16 * 16: return launch<MD_EPI_BIAS, 16>(k, stream);
       case 16 * 15: return launch<MD_EPI_BIAS, 15>(k, stream);
       case 16 * 31: return launch<MD_EPI_BIAS, 31>(k, stream);
+      case 16 * 64: return launch<MD_EPI_BIAS, 64>(k, stream);
+      case 16 * 128: return launch<MD_EPI_BIAS, 128>(k, stream);
       default: return MD_ERR_INVALID_ARG;
     }
   }

@@ -20,7 +20,7 @@ lib = _lib.load()
 BF16 = torch.bfloat16
 VARIANTS = [("w4", 20, 0), ("no ds_write", 20, 16), ("no loads", 20, 32), ("no write+loads", 20, 48),
             ("no barrier", 20, 64), ("no frag reads", 20, 128), ("no stores", 20, 256), ("mfma+stores only", 20, 240),
-            ("mfma only", 20, 496), ("full-line loads", 20, 512), ("8-wave alt", 11, 0)]
+            ("mfma only", 20, 496), ("vmcnt0 after stores", 20, 1024), ("nt stores", 20, 2048), ("8-wave alt", 11, 0)]
 SHAPES = [(8192, 8192, 8192), (46720, 2048, 2048), (93312, 1152, 3456)]
 if len(sys.argv) > 1:
     VARIANTS = [v for v in VARIANTS if v[0] in sys.argv[1:] or str(v[2]) in sys.argv[1:]] or VARIANTS

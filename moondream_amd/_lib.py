@@ -175,6 +175,8 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(objdir, name + ".o")
         objs.append(o)
         flags = base + (["-save-temps=obj"] if name == "gemm_w4.hip" else vgpr_form)
+        if name == "gemm_w4.hip" and os.environ.get("MD_W4_ABLATIONS"):
+            flags.append("-DMD_W4_ABLATIONS")  # tools/w4_probe.py's timing-ablation variants
         cmd = [hipcc_path(), *flags, "-c", s, "-o", o]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)

@@ -2,16 +2,23 @@
 //
 // One workgroup = FOUR waves, one per SIMD, each owning a 128 x 128 quarter of a 256 x 256 tile
 // of C with its 16 accumulator blocks (256 registers) in the accumulator half of the register
-// file.  Per 16-wide K step a wave issues 16 v_mfma_f32_32x32x16_bf16 (512 matrix-pipe cycles) for
-// 8 ds_read_b128 -- two thirds of the LDS reads per FLOP of an eight-wave 128 x 64 split, and no
-// second wave on the SIMD to arbitrate with.  Because nothing else runs on the SIMD, everything
-// that is not an MFMA is a FILLER placed by hand between two MFMAs (<= 2 per 32-cycle gap):
+// file, named literally by inline asm.  Per 16-wide K step a wave issues 16
+// v_mfma_f32_32x32x16_bf16 (512 matrix-pipe cycles) for 8 ds_read_b128 -- two thirds of the LDS
+// reads per FLOP of an eight-wave 128 x 64 split, and no second wave on the SIMD to arbitrate with.
+// Because nothing else runs on the SIMD, everything that is not an MFMA is a FILLER placed by hand
+// between two MFMAs (tables below), and since the four waves run in lockstep between barriers the
+// fillers of one kind are spread out evenly so that neither the LDS nor the vector-memory front
+// end sees a burst:
 //
-//   stream of 32-wide K slices, software pipelined over three levels
-//     HBM/L2 -> registers   raw buffer loads, 16 B per lane, issued ~2 slices (2 x 1024 cycles) ahead
-//     registers -> LDS      ds_write_b128 into a 2-stage ring, chunk-swizzled on the WRITE side
-//     LDS -> fragments      ds_read_b128 one 16-wide K step ahead of the MFMAs that consume them
-//   one s_barrier per slice, sitting between two MFMAs.
+//   stream of K in PAIRS of 32-wide slices, software pipelined over three levels
+//     HBM/L2 -> registers   raw buffer loads of 8 rows x 128 bytes (whole cache lines; with 64-byte row
+//                           pieces every line crossed L2 -> L1 twice), issued one pair (~2000 cycles) ahead
+//     registers -> LDS      ds_write_b128 into a 4-stage ring (pair being multiplied + pair being written),
+//                           chunk-swizzled on the WRITE side; each register is re-requested right after it
+//                           is written out, so ONE pair's worth of registers carries the whole stream
+//     LDS -> fragments      ds_read_b128 one 16-wide K step ahead of the MFMAs that consume them, waited
+//                           for with COUNTED lgkmcnt (only the fragment an MFMA is first to use)
+//   one s_barrier per pair (64 MFMAs).
 //
 // (LDS-DMA is deliberately not used here: an LDS-DMA issue costs its wave 60-180 cycles, which a
 // second wave on the SIMD can cover but a lone wave cannot; a buffer load and a ds_write cost a
@@ -24,6 +31,10 @@
 //
 // Numerics: K is accumulated in the same order as every other tile config (sequential 16-wide
 // steps into one fp32 accumulator), so results are bit-identical to them.
+//
+// Measured (profiles/r02_gemm_w4_*): 1.37 PF/s at 8192^3, 1.09-1.26 PF/s on the decoder-prefill / projector
+// shapes, 0.84-0.97 on the K = 1152 ViT shapes (random operands; the chip runs ~1.75 GHz under it: MFMA-busy
+// 70 %, 18 % of wave cycles parked at waits / the barrier).
 #include "gemm_internal.hpp"
 
 #include <algorithm>
@@ -465,6 +476,7 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   // 32-bit byte offsets into A and W
   if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32))
     return MD_ERR_UNSUPPORTED;
+#ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
   if (epi == MD_EPI_BIAS && g_w4_variant != 0) {
     switch (g_w4_variant) {
       case 16 * 1: return launch<MD_EPI_BIAS, 1>(k, stream);
@@ -480,6 +492,7 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
       default: return MD_ERR_INVALID_ARG;
     }
   }
+#endif
   switch (epi) {
     case MD_EPI_BIAS: return launch<MD_EPI_BIAS>(k, stream);
     case MD_EPI_GELU: return launch<MD_EPI_GELU>(k, stream);

@@ -870,7 +870,8 @@ class MoondreamModel:
 
     def query(self, image=None, question: str = None, reasoning: bool = False,
               spatial_refs: Optional[SpatialRefs] = None, stream: bool = False, settings: Optional[dict] = None):
-        """reference: moondream.py:541-618 (the ``reasoning`` branch is not on the native path)."""
+        """reference: moondream.py:541-618, including the ``reasoning`` branch (thinking token -> _generate_reasoning
+        -> answer after a second suffix)."""
         tpl = self.config.tokenizer.templates["query"]
         if tpl is None:
             raise NotImplementedError("Model does not support querying.")
@@ -878,8 +879,6 @@ class MoondreamModel:
             raise ValueError("question must be provided.")
         if spatial_refs and image is None:
             raise ValueError("spatial_refs can only be used with an image.")
-        if reasoning:
-            raise NotImplementedError("reasoning mode is not on the native path yet")
         if image is not None:
             enc = self.encode_image(image)
             self.load_encoded_image(enc)
@@ -894,9 +893,68 @@ class MoondreamModel:
             tk = self.config.tokenizer
             for ref in spatial_refs:
                 spatial.extend([tk.coord_id, tk.coord_id] if len(ref) == 2 else [tk.coord_id, tk.coord_id, tk.size_id])
-        prompt = head + spatial + list(self.tokenizer.encode(question).ids) + list(tpl["suffix"]) + list(tpl["suffix"])
-        gen = self._generate_answer(torch.tensor([prompt]), pos, settings, spatial_refs, causal=causal)
-        return {"answer": gen} if stream else {"answer": "".join(list(gen))}
+        prompt = head + spatial + list(self.tokenizer.encode(question).ids) + list(tpl["suffix"])
+        extra = {}
+        if reasoning:
+            # moondream.py:593-603: [.., suffix, thinking] -> reasoning text until answer_id, then the answer after [suffix]
+            prompt = prompt + [self.config.tokenizer.thinking_id]
+            pos, text, grounding = self._generate_reasoning(torch.tensor([prompt]), pos, settings, spatial_refs, causal=causal)
+            extra = {"reasoning": {"text": text, "grounding": grounding}}
+            gen = self._generate_answer(torch.tensor([list(tpl["suffix"])]), pos, settings, None, causal=causal)
+        else:
+            prompt = prompt + list(tpl["suffix"])
+            gen = self._generate_answer(torch.tensor([prompt]), pos, settings, spatial_refs, causal=causal)
+        return {**extra, "answer": gen} if stream else {**extra, "answer": "".join(list(gen))}
+
+    def _generate_reasoning(self, prompt_tokens: torch.Tensor, pos: int, settings: Optional[dict] = None,
+                            spatial_refs: Optional[SpatialRefs] = None, attn_mask=None, causal: bool = False):
+        """reference: moondream.py:323-432.  Generates the reasoning text (stops at ``answer_id``; ``eos`` and
+        ``size`` tokens suppressed), grounding every ``coord`` token through the region head: the token's
+        coordinate is decoded from the hidden state that predicted it and fed back as the next embedding.
+        Returns (pos, text, grounding).  One host decision per token, like the reference."""
+        settings = settings or {}
+        max_tokens = settings.get("max_tokens", DEFAULT_MAX_TOKENS)
+        temperature = settings.get("temperature", DEFAULT_TEMPERATURE)
+        top_p = settings.get("top_p", DEFAULT_TOP_P)
+        if settings.get("variant") is not None:
+            raise NotImplementedError("LoRA variants are not on the native path")
+        tk = self.config.tokenizer
+        _, hidden, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask, causal=causal)
+        last_hidden = hidden[:, -1:, :].reshape(1, -1)
+        text_chunks: List[List[int]] = [[]]
+        grounding_chunks: List[List[float]] = [[]]
+        generated = 0
+        bins = torch.zeros(1, 1, dtype=torch.int32, device=self._device)
+        n_bins = self.config.region.coord_out_dim
+        suppress = torch.tensor([tk.eos_id, tk.size_id], device=self._device)
+        with torch.inference_mode():
+            tok = int(nxt.reshape(-1)[0])
+            while tok != tk.answer_id and generated < max_tokens and pos < self.config.text.max_context:
+                if tok in (tk.start_ground_points_id, tk.end_ground_id):
+                    text_chunks.append([])
+                    grounding_chunks.append([])
+                text_chunks[-1].append(tok)
+                if tok == tk.coord_id:
+                    # coordinate bin from the hidden state, value fed back through the coordinate encoder (device resident)
+                    emb = self._region_pick_encode(last_hidden, "coord", bins)
+                    grounding_chunks[-1].append((bins[0, 0].to(torch.int64) / n_bins).item())
+                else:
+                    emb = self._embed(torch.tensor([[tok]]))
+                h = self._text_forward(emb.reshape(1, 1, -1), pos, 0)
+                logits = self._lm_head(h)
+                logits[:, suppress] = float("-inf")  # moondream.py:397-398
+                pos += 1
+                last_hidden = h.reshape(1, -1)
+                tok = int(self._pick(logits, temperature, top_p)[0])
+                generated += 1
+        texts = [self.tokenizer.decode(c) for c in text_chunks]
+        grounding, start = [], 0
+        for t, g in zip(texts, grounding_chunks):
+            if len(g) > 1:
+                pts = [(g[i], g[i + 1]) for i in range(0, len(g) - (len(g) % 2), 2)]
+                grounding.append({"start_idx": start, "end_idx": start + len(t), "points": pts})
+            start += len(t)
+        return pos, "".join(texts), grounding
 
     # ------------------------------------------------------------ region head
     # Device-resident and batched: the heads are decode-regime GEMMs over B rows, "argmax the bin,

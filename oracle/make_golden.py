@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [0.5b] [2b] [bench64] [reftime]
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [0.5b] [2b] [bench64] [reftime]
 """
 from __future__ import annotations
 
@@ -598,6 +598,81 @@ def gen_reftime(cfg_name="2b", seed=1, n_images=5, max_tokens=32):
     print(f"[reftime] {timing['images_per_sec']:.3f} images/s on {os.cpu_count()} cores -> {prof}", flush=True)
 
 
+def gen_reasoning(name="tiny_reasoning", cfg_name="tiny", seed=1, n_cases=2, max_tokens=8, min_margin=0.75):
+    """query(image, question, reasoning=True) through the reference's public API (moondream.py:541-618 ->
+    _generate_reasoning moondream.py:323-432 -> _generate_answer): reasoning text ids, grounding, answer ids and
+    the top-1/top-2 margin of every decision.  Cases are kept when every decision has margin >= min_margin."""
+    from PIL import Image
+
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    tk = cfg.tokenizer
+    out = {"seed": np.int64(seed), "cfg": np.array(cfg_name), "max_tokens": np.int64(max_tokens)}
+    orig_decode, orig_lm_head = model._decode_one_tok, ref_md.lm_head
+    kept, src = 0, -1
+    while kept < n_cases:
+        src += 1
+        assert src < 200, "could not find enough wide-margin reasoning cases"
+        image = synth.synthetic_image_array(src, seed, (378, 378))
+        rec = {"logits": []}
+
+        def decode_tap(x, mask, pos_ids, lora):
+            logits, hidden = orig_decode(x, mask, pos_ids, lora)
+            rec["logits"].append(("decode", logits[0].clone()))
+            return logits, hidden
+
+        def lm_head_tap(h, w):
+            o = orig_lm_head(h, w)
+            if not rec["logits"] or rec["logits"][-1][0] != "pending":
+                rec["logits"].append(("prefill", o[0].clone()))
+            return o
+
+        model._decode_one_tok, ref_md.lm_head = decode_tap, lm_head_tap
+        try:
+            res = model.query(Image.fromarray(image, "RGB"), "11 12 13", reasoning=True,
+                              settings={"temperature": 0, "max_tokens": max_tokens, "variant": None})
+        finally:
+            model._decode_one_tok, ref_md.lm_head = orig_decode, orig_lm_head
+        # lm_head is also called inside _decode_one_tok (its tap fires first): drop those twins, keep the prompt prefills
+        seq = []
+        for kind, lg in rec["logits"]:
+            if kind == "decode" and seq and seq[-1][0] == "prefill" and torch.equal(seq[-1][1], lg):
+                seq[-1] = (kind, lg)
+            else:
+                seq.append((kind, lg))
+        r_ids = [int(t) for t in res["reasoning"]["text"].split()]
+        a_ids = [int(t) for t in res["answer"].split()]
+        # decisions in order: reasoning prompt prefill, one decode per reasoning token (eos / size suppressed,
+        # moondream.py:397-398), answer prompt prefill, one decode per answer token (answer_id suppressed, :517)
+        assert len(seq) == 2 + len(r_ids) + len(a_ids), (len(seq), len(r_ids), len(a_ids))
+        margins = []
+        for i, (kind, lg) in enumerate(seq):
+            lg = lg.clone().float()
+            if 1 <= i <= len(r_ids):
+                lg[tk.eos_id] = lg[tk.size_id] = float("-inf")
+            elif i > len(r_ids) + 1:
+                lg[tk.answer_id] = float("-inf")
+            top = torch.topk(lg, 2).values
+            margins.append(float(top[0] - top[1]))
+        if min(margins) < min_margin:
+            print(f"[{name}] skip image {src}: min margin {min(margins):.3f}", flush=True)
+            continue
+        pfx = f"case{kept}."
+        out[pfx + "image_index"] = np.int64(src)
+        out[pfx + "reasoning_tokens"] = np.array(r_ids)
+        out[pfx + "answer_tokens"] = np.array(a_ids)
+        out[pfx + "n_grounding"] = np.int64(len(res["reasoning"]["grounding"]))
+        out[pfx + "margins"] = np.array(margins, dtype=np.float32)
+        print(f"[{name}] case{kept}: image {src}: reasoning {r_ids} answer {a_ids} grounding {res['reasoning']['grounding']} "
+              f"(min margin {min(margins):.3f})", flush=True)
+        kept += 1
+    out["n_cases"] = np.int64(kept)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -613,6 +688,8 @@ def main():
         gen_textonly()
     if "0.5b" in which:
         gen_model_case("md05b_seed1", "0.5b", 1, [(378, 378)], 32, False, n_images=2, min_margin=0.5)
+    if "reasoning" in which:
+        gen_reasoning()
     if "sampling" in which:
         gen_sampling()
     if "detect" in which:

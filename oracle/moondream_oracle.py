@@ -622,3 +622,32 @@ class Oracle:
         logits, h, pos = self.prefill_prompt(prompt, pos, kv)
         nxt = int(torch.argmax(logits.float()))
         return self.generate_points(h[-1:].clone(), nxt, pos, kv, kind == "detect", max_objects, trace)
+
+    def generate_reasoning(self, prompt_ids, pos0: int, kv: OracleKV, max_tokens: int):
+        """Greedy reasoning text.  reference: moondream.py:323-432 at temperature 0: prefill the prompt
+        (which ends with the thinking token), then per token: stop on ``answer_id`` or max_tokens; a
+        ``coord`` token is grounded through the region head (coordinate decoded from the hidden state
+        that predicted it, fed back through the coordinate encoder), any other token through the
+        embedding table; ``eos`` and ``size`` logits are suppressed (moondream.py:397-398).
+        Returns (tokens, grounding coordinates, pos)."""
+        tk = self.cfg.tokenizer
+        logits, h, pos = self.prefill_prompt(prompt_ids, pos0, kv)
+        last = h[-1:].clone()
+        tok = int(torch.argmax(logits.float()))
+        out, coords = [], []
+        while tok != tk.answer_id and len(out) < max_tokens:
+            out.append(tok)
+            if tok == tk.coord_id:
+                cl = self.decode_coordinate(last)
+                c = torch.argmax(cl.float(), dim=-1) / cl.size(-1)
+                coords.append(c.item())
+                emb = self.encode_coordinate(c.to(BF16))
+            else:
+                emb = self.embed([tok])
+            logits, h = self.decode_token(emb.reshape(1, -1), pos, kv)
+            last = h[-1:].clone()
+            logits[tk.eos_id] = float("-inf")
+            logits[tk.size_id] = float("-inf")
+            pos += 1
+            tok = int(torch.argmax(logits.float()))
+        return out, coords, pos

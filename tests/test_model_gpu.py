@@ -340,6 +340,31 @@ def test_spatial_ref_query_vs_reference(tiny, detect_gold):
     assert [int(t) for t in ans.split()] == want
 
 
+def test_reasoning_query_vs_reference(tiny, golden_dir):
+    """query(..., reasoning=True): reasoning text and answer ids recorded from the reference's public API."""
+    g0, cfg, sd, model = tiny
+    g = load_golden(golden_dir, "tiny_reasoning.npz")
+    for i in range(int(g["n_cases"])):
+        img = Image.fromarray(synth.synthetic_image_array(int(g[f"case{i}.image_index"]), int(g["seed"]), (378, 378)), "RGB")
+        res = model.query(img, "11 12 13", reasoning=True, settings={"temperature": 0, "max_tokens": int(g["max_tokens"])})
+        assert [int(t) for t in res["reasoning"]["text"].split()] == g[f"case{i}.reasoning_tokens"].tolist()
+        assert [int(t) for t in res["answer"].split()] == g[f"case{i}.answer_tokens"].tolist()
+        assert len(res["reasoning"]["grounding"]) == int(g[f"case{i}.n_grounding"])
+    # the grounding branch: a prompt whose first generated token is forced to be the coordinate token
+    tk = cfg.tokenizer
+    enc = model.encode_image(golden_image(g0, 0))
+    model.load_encoded_image(enc)
+    orig = model._pick
+    seq = iter([tk.start_ground_points_id, tk.coord_id, tk.coord_id, tk.end_ground_id, tk.answer_id])
+    model._pick = lambda logits, *a, **k: torch.tensor([next(seq)], dtype=torch.int32, device=logits.device)
+    try:
+        pos, text, grounding = model._generate_reasoning(torch.tensor([[1, 381, 2, 11, 3, tk.thinking_id]]), enc.pos, {"temperature": 0, "max_tokens": 8})
+    finally:
+        model._pick = orig
+    assert [int(t) for t in text.split()] == [tk.start_ground_points_id, tk.coord_id, tk.coord_id, tk.end_ground_id]
+    assert len(grounding) == 1 and len(grounding[0]["points"]) == 1 and all(0.0 <= c < 1.0 for c in grounding[0]["points"][0])
+
+
 # ------------------------------------------------------------------ batched string API + HF wrapper
 def test_batch_generate_strings_ragged_equals_sequential(tiny):
     """batch_generate / batch_query / batch_caption (the names BASELINE.json uses) with questions of

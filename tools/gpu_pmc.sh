@@ -13,7 +13,7 @@ for run in ("a","b"):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0,0.0]))
     for row in csv.DictReader(open(fs[0])):
         k = row["Kernel_Name"]
-        if "gemm_bf16" not in k and "attn_prefill" not in k: continue
+        if "gemm_bf16" not in k and "gemm_w4" not in k and "attn_prefill" not in k: continue
         key = k[:60] + " grid=" + row.get("Grid_Size","?")
         c = agg[key][row["Counter_Name"]]; c[0]+=1; c[1]+=float(row["Counter_Value"])
     out = open(f"gpurun_out/pmc/summary_{run}.txt","w")

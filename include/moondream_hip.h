@@ -378,6 +378,32 @@ md_status md_text_forward(const md_text_model* m, const void* x, void* hidden, i
                           int32_t q_len, const int32_t* pos0, const md_kv_cache* kv,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* LoRA "variant" side path (reference: lora.py:54-79 -> text.py:31-32,55-56 and layers.py:129-146 with lora != None).
+ * delta(x) = (x A^T) B^T with A [r][k] and B [n][r] packed as bias-free md_linear (r zero-padded to 64); a pair with
+ * a.w == NULL is absent.  Per block, in the reference's order and with its bf16 roundings:
+ *   qkv  = bf16(qkv(l_in) + delta_qkv(l_in))
+ *   attn = bf16(proj(att) + delta_proj(l_in))        -- sic: the reference feeds the BLOCK INPUT to this pair (text.py:55)
+ *   h    = gelu(bf16(fc1(l_in) + delta_fc1(l_in)));  mlp = bf16(fc2(h) + delta_fc2(h))
+ *   x    = bf16(bf16(x + attn) + mlp) */
+typedef struct {
+  md_linear a, b;
+} md_lora_pair;
+typedef struct {
+  md_lora_pair qkv, proj, fc1, fc2;
+} md_text_block_lora;
+
+/* md_text_forward with the side path: lora = host array of n_layers entries (NULL: plain md_text_forward).
+ * Runs the unfused kernels (separate qkv / fc1, stand-alone GELU and adds). */
+size_t md_text_lora_workspace_bytes(const md_text_model* m, int32_t batch, int32_t q_len);
+md_status md_text_forward_lora(const md_text_model* m, const md_text_block_lora* lora, const void* x, void* hidden,
+                               int32_t batch, int32_t q_len, const int32_t* pos0, const md_kv_cache* kv,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[r, :cols] = bf16(a[r, :cols] + b[r, :cols]);  out = gelu_tanh(a)  (bf16 rows, cols % 8 == 0). */
+md_status md_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t rows,
+                      int32_t cols, void* stream);
+md_status md_gelu_bf16(const void* a, int64_t lda, void* out, int64_t ldo, int32_t rows, int32_t cols, void* stream);
+
 size_t md_lm_head_workspace_bytes(const md_text_model* m, int32_t batch);
 
 /* lm_head on the LAST token of each sequence (reference: text.py:163-167):

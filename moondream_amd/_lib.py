@@ -82,6 +82,14 @@ class MdTextModel(C.Structure):
     ]
 
 
+class MdLoraPair(C.Structure):
+    _fields_ = [("a", MdLinear), ("b", MdLinear)]
+
+
+class MdTextBlockLora(C.Structure):
+    _fields_ = [("qkv", MdLoraPair), ("proj", MdLoraPair), ("fc1", MdLoraPair), ("fc2", MdLoraPair)]
+
+
 class MdKvCache(C.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("layer_stride", c_int64), ("batch_stride", c_int64), ("ctx", c_int32)]
 
@@ -131,6 +139,11 @@ SIGNATURES = {
     "md_text_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32, c_int32]),
     "md_text_forward": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_int32, c_int32, c_void_p, P(MdKvCache),
                                   c_void_p, c_size_t, c_void_p]),
+    "md_text_lora_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32, c_int32]),
+    "md_text_forward_lora": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, P(MdKvCache),
+                                       c_void_p, c_size_t, c_void_p]),
+    "md_add_bf16": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "md_gelu_bf16": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "md_lm_head_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32]),
     "md_lm_head": (C.c_int, [P(MdTextModel), c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "md_decode_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32]),

@@ -408,6 +408,98 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
   return MD_OK;
 }
 
+// ------------------------------------------------------------- LoRA side path
+namespace {
+struct LoraWs {
+  void *h, *qkv, *att, *ff, *t, *d1, *d2, *pos_kv;
+  size_t total;
+};
+LoraWs lora_layout(const md_text_model* m, int batch, int q_len, void* base) {
+  const size_t M = (size_t)batch * q_len, hd = m->dim / m->n_heads;
+  Arena a{(char*)base, 0};
+  LoraWs w;
+  w.h = a.take(M * m->blocks[0].qkv.k_pad * 2);
+  w.qkv = a.take(M * (m->n_heads + 2 * m->n_kv_heads) * hd * 2);
+  w.att = a.take(M * m->blocks[0].proj.k_pad * 2);
+  w.ff = a.take(M * m->blocks[0].fc1.n_pad * 2);
+  w.t = a.take(M * 256 * 2);  // x A^T, rank zero-padded (<= 256)
+  w.d1 = a.take(M * m->dim * 2);
+  w.d2 = a.take(M * m->dim * 2);
+  w.pos_kv = a.take((size_t)batch * 4);
+  w.total = a.off;
+  return w;
+}
+// c = bf16(c + (x A^T) B^T), in place on c [M][ldc]; absent pair: nothing
+md_status lora_add(const md_lora_pair& lp, const void* x, int64_t ldx, void* t, void* c, int64_t ldc, int M, hipStream_t s) {
+  if (lp.a.w == nullptr) return MD_OK;
+  if (lp.a.n_pad > 256 || lp.b.k_pad != lp.a.n_pad) return MD_ERR_UNSUPPORTED;
+  MD_TRY(gemm(x, ldx, lp.a, t, lp.a.n_pad, M, MD_EPI_BIAS, nullptr, 0, 0, 1, s));   // pad columns written as zeros
+  return gemm(t, lp.a.n_pad, lp.b, c, ldc, M, MD_EPI_RESIDUAL, c, ldc, 0, 0, s);
+}
+}  // namespace
+
+extern "C" size_t md_text_lora_workspace_bytes(const md_text_model* m, int32_t batch, int32_t q_len) {
+  if (!m || !m->blocks || batch <= 0 || q_len <= 0) return 0;
+  return lora_layout(m, batch, q_len, nullptr).total;
+}
+
+extern "C" md_status md_text_forward_lora(const md_text_model* m, const md_text_block_lora* lora, const void* x_in, void* hidden,
+                                          int32_t batch, int32_t q_len, const int32_t* pos0, const md_kv_cache* kv,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (lora == nullptr) return md_text_forward(m, x_in, hidden, batch, q_len, pos0, kv, workspace, workspace_bytes, stream);
+  MD_CHECK_ARG(m && x_in && hidden && pos0 && kv && kv->k && kv->v && workspace && m->blocks);
+  MD_CHECK_ARG(batch > 0 && q_len > 0 && m->dim % m->n_heads == 0);
+  const int hd = m->dim / m->n_heads;
+  if (hd != 64) return MD_ERR_UNSUPPORTED;
+  const LoraWs w = lora_layout(m, batch, q_len, workspace);
+  if (workspace_bytes < w.total) return MD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->dim, M = batch * q_len;
+  const int qkv_w = (m->n_heads + 2 * m->n_kv_heads) * hd;
+  const int Dp = m->blocks[0].qkv.k_pad;
+  MD_CHECK_ARG(Dp == D && m->blocks[0].proj.k_pad == D && m->blocks[0].fc1.k_pad == D);  // no K padding on this path
+  bf16_t* x = (bf16_t*)hidden;
+  if (x_in != hidden && hipMemcpyAsync(hidden, x_in, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return MD_ERR_LAUNCH;
+  int32_t* kv_len = (int32_t*)w.pos_kv;
+  hipLaunchKernelGGL(kv_len_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pos0, kv_len, q_len, batch);
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const md_text_block& b = m->blocks[l];
+    const md_text_block_lora& lo = lora[l];
+    bf16_t* kl = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
+    bf16_t* vl = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
+    const int64_t ffld = b.fc1.n_pad;
+    MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad && b.fc1.n == b.fc1.n_pad);
+    MD_TRY(md_layernorm_bf16(x, D, w.h, D, &b.ln, M, D, 1e-5f, s));                                     // text.py:145
+    MD_TRY(gemm(w.h, D, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));                      // text.py:30
+    MD_TRY(lora_add(lo.qkv, w.h, D, w.t, w.qkv, qkv_w, M, s));                                          // text.py:31-32
+    MD_TRY(md_rope_kv_write(w.qkv, qkv_w, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch, q_len, m->n_heads,
+                            m->n_kv_heads, hd, m->rot_dim, s));
+    if (q_len == 1) {
+      MD_TRY(md_attention_decode(w.qkv, qkv_w, w.att, D, kl, vl, kv->batch_stride, kv->ctx, kv_len, batch, m->n_heads,
+                                 m->n_kv_heads, hd, scale, s));
+    } else {
+      md_attn_args a;
+      a.q = w.qkv; a.q_bs = (int64_t)q_len * qkv_w; a.q_ts = qkv_w; a.q_hs = hd;
+      a.k = kl; a.v = vl; a.k_bs = a.v_bs = kv->batch_stride; a.k_ts = a.v_ts = hd; a.k_hs = a.v_hs = (int64_t)kv->ctx * hd;
+      a.o = w.att; a.o_bs = (int64_t)q_len * D; a.o_ts = D; a.o_hs = hd;
+      a.batch = batch; a.n_heads = m->n_heads; a.n_kv_heads = m->n_kv_heads; a.head_dim = hd; a.q_len = q_len;
+      a.kv_len_all = 0; a.q_pos0 = pos0; a.kv_len = kv_len; a.prefix_len = m->prefix_len; a.scale = scale;
+      MD_TRY(md_attention_prefill(&a, s));
+    }
+    MD_TRY(gemm(w.att, D, b.proj, w.d1, D, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));                        // text.py:53
+    MD_TRY(lora_add(lo.proj, w.h, D, w.t, w.d1, D, M, s));                                               // text.py:55: x = l_in
+    MD_TRY(gemm(w.h, D, b.fc1, w.ff, ffld, M, MD_EPI_BIAS, nullptr, 0, 0, 1, s));                        // layers.py:130
+    MD_TRY(lora_add(lo.fc1, w.h, D, w.t, w.ff, ffld, M, s));                                             // layers.py:131-133
+    MD_TRY(md_gelu_bf16(w.ff, ffld, w.ff, ffld, M, (int32_t)ffld, s));                                   // layers.py:137
+    MD_TRY(gemm(w.ff, ffld, b.fc2, w.d2, D, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));                       // layers.py:139
+    MD_TRY(lora_add(lo.fc2, w.ff, ffld, w.t, w.d2, D, M, s));                                            // layers.py:140-142
+    MD_TRY(md_add_bf16(x, D, w.d1, D, x, D, M, D, s));                                                   // text.py:158
+    MD_TRY(md_add_bf16(x, D, w.d2, D, x, D, M, D, s));
+  }
+  return MD_OK;
+}
+
 extern "C" size_t md_lm_head_workspace_bytes(const md_text_model* m, int32_t batch) {
   if (!m || batch <= 0) return 0;
   return align_up((size_t)batch * m->lm_head.k_pad * 2);

@@ -4,6 +4,8 @@
 // arithmetic in fp32 with exactly one rounding to bf16 per reference op.
 #include "md_common.hpp"
 
+#include <algorithm>
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -289,6 +291,34 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(bf16_t* __restrict__ qkv, 
 }
 
 // ---------------------------------------------------------------------------
+// Row-wise bf16 helpers of the LoRA side path: out = bf16(a + b) (the reference's bf16 tensor adds,
+// layers.py:132-143, text.py:31-32,55-56,158) and out = gelu_tanh(a) as a stand-alone op.
+// rows x cols with leading dimensions; cols % 8 == 0.
+template <int OP>  // 0: add, 1: gelu
+__global__ __launch_bounds__(256) void rowwise_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b,
+                                                      int64_t ldb, bf16_t* __restrict__ out, int64_t ldo, int rows, int cols) {
+  const int cpr = cols >> 3;
+  const int64_t total = (int64_t)rows * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+    const u32x4 x = *(const u32x4*)(a + (int64_t)r * lda + c);
+    u32x4 o;
+    if constexpr (OP == 0) {
+      const u32x4 y = *(const u32x4*)(b + (int64_t)r * ldb + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(lo_bf(x[e]) + lo_bf(y[e]), hi_bf(x[e]) + hi_bf(y[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const md_f32x2 g = gelu_tanh_f32x2(md_f32x2{lo_bf(x[e]), hi_bf(x[e])});
+        o[e] = pack_bf16x2(g[0], g[1]);
+      }
+    }
+    *(u32x4*)(out + (int64_t)r * ldo + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
                                                     const bf16_t* __restrict__ table, int64_t ldt,
                                                     bf16_t* __restrict__ out, int64_t ldo, int dim) {
@@ -492,6 +522,23 @@ extern "C" md_status md_rope_kv_write(void* qkv, int64_t ld, const float* freqs,
   hipLaunchKernelGGL(rope_kv_kernel, dim3(batch * q_len), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)qkv, ld, freqs, pos0, (bf16_t*)k_slab, (bf16_t*)v_slab,
                      slab_batch_stride, ctx, q_len, n_heads, n_kv_heads, head_dim, rot_dim);
+  return md_launch_status();
+}
+
+extern "C" md_status md_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
+                                 int32_t rows, int32_t cols, void* stream) {
+  MD_CHECK_ARG(a && b && out && rows > 0 && cols > 0 && cols % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0);
+  const int64_t total = (int64_t)rows * (cols / 8);
+  hipLaunchKernelGGL(rowwise_kernel<0>, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, rows, cols);
+  return md_launch_status();
+}
+
+extern "C" md_status md_gelu_bf16(const void* a, int64_t lda, void* out, int64_t ldo, int32_t rows, int32_t cols, void* stream) {
+  MD_CHECK_ARG(a && out && rows > 0 && cols > 0 && cols % 8 == 0 && lda % 8 == 0 && ldo % 8 == 0);
+  const int64_t total = (int64_t)rows * (cols / 8);
+  hipLaunchKernelGGL(rowwise_kernel<1>, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, lda, (const bf16_t*)nullptr, (int64_t)0, (bf16_t*)out, ldo, rows, cols);
   return md_launch_status();
 }
 

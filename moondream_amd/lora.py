@@ -1,0 +1,82 @@
+"""LoRA "variants" (reference: moondream/torch/lora.py).
+
+A variant is a checkpoint of low-rank pairs for the decoder's four linears per block.  The
+reference downloads it from api.moondream.ai into the Hugging Face cache and renames / nests its
+keys (lora.py:12-79).  This build has no network path: a variant is either REGISTERED in process
+(``MoondreamModel.register_variant(id, nested_or_flat_dict)``) or read from the same cache file the
+reference would have written, ``<cache>/md_variants/<id>/final.pt`` -- if it is not there, the call
+fails instead of downloading.
+
+Nested layout consumed by the model (what the reference's ``variant_state_dict`` returns):
+``lora["text"]["blocks"][str(i)]["attn"]["qkv" | "proj"]["A" | "B"]`` and
+``...["mlp"]["fc1" | "fc2"]["A" | "B"]`` with A [r, in] and B [out, r]
+(text.py:31-32,55-56; layers.py:129-146).
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Dict, Optional
+
+import torch
+
+RENAME_RULES = [  # reference: lora.py:63-69
+    ("text_model.transformer.h", "text.blocks"),
+    (".mixer", ".attn"),
+    (".out_proj", ".proj"),
+    (".Wqkv", ".qkv"),
+    (".parametrizations.weight.0", ""),
+]
+
+
+def variant_cache_dir() -> Path:
+    """reference: lora.py:12-21."""
+    hub = os.environ.get("HF_HUB_CACHE")
+    if hub is not None:
+        return Path(hub) / "md_variants"
+    home = os.environ.get("HF_HOME")
+    if home is not None:
+        return Path(home) / "hub" / "md_variants"
+    return Path("~/.cache/huggingface/hub").expanduser() / "md_variants"
+
+
+def cached_variant_path(variant_id: str) -> Path:
+    """reference: lora.py:24-41 without the download: the file must already be in the cache."""
+    dest = variant_cache_dir() / variant_id / "final.pt"
+    if not dest.exists():
+        raise FileNotFoundError(
+            f"LoRA variant '{variant_id}' is not registered and not in the cache ({dest}); this build does not download "
+            "variants -- place the file there or call MoondreamModel.register_variant()"
+        )
+    return dest
+
+
+def nest(flat: Dict[str, torch.Tensor]) -> dict:
+    """reference: lora.py:43-51."""
+    tree: dict = {}
+    for k, v in flat.items():
+        parts = k.split(".")
+        d = tree
+        for p in parts[:-1]:
+            d = d.setdefault(p, {})
+        d[parts[-1]] = v
+    return tree
+
+
+def rename_and_nest(state_dict: Dict[str, torch.Tensor]) -> dict:
+    """reference: lora.py:61-79."""
+    out = {}
+    for key, tensor in state_dict.items():
+        for old, new in RENAME_RULES:
+            if old in key:
+                key = key.replace(old, new)
+        out[key] = tensor
+    return nest(out)
+
+
+def variant_state_dict(variant_id: Optional[str], device="cpu") -> Optional[dict]:
+    """reference: lora.py:54-79."""
+    if variant_id is None:
+        return None
+    sd = torch.load(cached_variant_path(variant_id), map_location=device, weights_only=True)
+    return rename_and_nest(sd)

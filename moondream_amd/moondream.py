@@ -28,7 +28,8 @@ from PIL import Image
 from . import _lib
 from .config import MoondreamConfig
 from .image_crops import overlap_crop_image, reconstruct_from_crops
-from .weights import PackedModel
+from .lora import variant_state_dict
+from .weights import PackedLora, PackedModel
 
 BF16 = torch.bfloat16
 
@@ -121,6 +122,7 @@ class MoondreamModel:
         self.collect_timing = False
         self.last_phase_ms: Dict[str, float] = {}
         self._region_tables = None
+        self._variants: Dict[str, PackedLora] = {}
         if setup_caches:
             self._setup_caches(max_batch)
 
@@ -185,6 +187,20 @@ class MoondreamModel:
 
         return cls(config or get_config("2b"), load_state_dict_file(weights_file), **kwargs)
 
+    def register_variant(self, variant_id: str, lora: dict):
+        """Make a LoRA variant available to ``settings={"variant": variant_id}`` without the network: ``lora`` is the
+        nested dict the reference's ``variant_state_dict`` returns (lora.py:54-79)."""
+        self._variants[variant_id] = PackedLora(self.config, lora, self._device)
+
+    def _lora(self, settings: Optional[dict]) -> Optional[PackedLora]:
+        """The packed variant named by ``settings["variant"]`` (reference: moondream.py:241-245,455-459), or None."""
+        vid = (settings or {}).get("variant")
+        if vid is None:
+            return None
+        if vid not in self._variants:
+            self._variants[vid] = PackedLora(self.config, variant_state_dict(vid, device="cpu"), self._device)
+        return self._variants[vid]
+
     def compile(self):
         """The reference rebinds the seam to torch.compile'd functions here
         (moondream.py:194-204).  The seam is already native; ``compile`` turns on
@@ -244,7 +260,7 @@ class MoondreamModel:
         return st
 
     def _text_forward(self, x: torch.Tensor, pos0: Union[int, Sequence[int]], slot0: int = 0, causal: bool = False,
-                      pos_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      pos_dev: Optional[torch.Tensor] = None, lora: Optional[PackedLora] = None) -> torch.Tensor:
         """x [B,T,D] embeddings -> hidden [B,T,D]; K,V written at pos0[b]..pos0[b]+T-1.
         ``pos0`` is host data (one int for the whole batch or one per sequence): the slab has
         max_context slots per head and the kernels do not bounds-check, so the check is here
@@ -269,9 +285,20 @@ class MoondreamModel:
         self._ensure_batch(slot0 + b)
         x = x.contiguous()
         hidden = torch.empty_like(x)
+        kv = self._kv_struct(slot0)
+        if lora is not None:  # LoRA side path: unfused kernels + low-rank pairs (text.py:31-32,55-56; layers.py:129-146)
+            need = self.lib.md_text_lora_workspace_bytes(C.byref(text), b, t)
+            ws = self._workspace(need)
+            _lib.check(
+                self.lib.md_text_forward_lora(
+                    C.byref(text), lora.ptr(), x.data_ptr(), hidden.data_ptr(), b, t, pos0.data_ptr(), C.byref(kv),
+                    ws.data_ptr(), ws.numel(), self._stream(),
+                ),
+                "md_text_forward_lora",
+            )
+            return hidden
         need = self.lib.md_text_workspace_bytes(C.byref(text), b, t)
         ws = self._workspace(need)
-        kv = self._kv_struct(slot0)
         _lib.check(
             self.lib.md_text_forward(
                 C.byref(text), x.data_ptr(), hidden.data_ptr(), b, t, pos0.data_ptr(), C.byref(kv),
@@ -298,9 +325,7 @@ class MoondreamModel:
 
     def _prefill(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, lora=None):
         """reference: moondream.py:174-181.  x [1,T,D]; pos_ids int64 [T] consecutive."""
-        if lora is not None:
-            raise NotImplementedError("LoRA variants are not on the native path")
-        return self._text_forward(x.to(self._device), int(pos_ids[0]), 0)
+        return self._text_forward(x.to(self._device), int(pos_ids[0]), 0, lora=lora)
 
     def _decode_one_tok(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, lora=None):
         """reference: moondream.py:183-192.  x [1,1,D] -> (logits [1,V], hidden [1,1,D])."""
@@ -395,12 +420,12 @@ class MoondreamModel:
     def _run_vision_encoder(self, image: Image.Image) -> torch.Tensor:
         return self._run_vision_encoder_batch([image])[0]
 
-    def _prefill_images(self, img_emb: torch.Tensor, slot0: int = 0) -> int:
+    def _prefill_images(self, img_emb: torch.Tensor, slot0: int = 0, lora: Optional[PackedLora] = None) -> int:
         """[B,729,D] -> image prefix in the KV slabs of slots [slot0, slot0+B); returns pos (730)."""
         b = img_emb.shape[0]
         bos = self._embed(torch.full((b, 1), self.config.tokenizer.bos_id, dtype=torch.int32))
         x = torch.cat([bos, img_emb], dim=1)
-        self._text_forward(x, 0, slot0)
+        self._text_forward(x, 0, slot0, lora=lora)
         return x.shape[1]
 
     def encode_image(self, image: Union[Image.Image, EncodedImage], settings: Optional[dict] = None) -> EncodedImage:
@@ -409,11 +434,10 @@ class MoondreamModel:
             return image
         if not isinstance(image, Image.Image):
             raise ValueError("image must be a PIL Image or EncodedImage")
-        if settings is not None and settings.get("variant") is not None:
-            raise NotImplementedError("LoRA variants are not on the native path")
+        lora = self._lora(settings)  # the image prefix depends on the variant (moondream.py:241-257)
         with torch.inference_mode():
             self._ensure_batch(1)
-            pos = self._prefill_images(self._run_vision_encoder(image)[None], 0)
+            pos = self._prefill_images(self._run_vision_encoder(image)[None], 0, lora)
             caches = [
                 (self._kv_k[l, 0:1, :, :pos, :].clone(), self._kv_v[l, 0:1, :, :pos, :].clone())
                 for l in range(self.config.text.n_layers)
@@ -465,17 +489,19 @@ class MoondreamModel:
         return nxt
 
     # ---------------------------------------------------------- batched engine
-    def _prefill_prompts(self, prompts: Sequence[Sequence[int]], pos: int, slot0: int = 0, prompt_embs=None):
+    def _prefill_prompts(self, prompts: Sequence[Sequence[int]], pos: int, slot0: int = 0, prompt_embs=None,
+                         lora: Optional[PackedLora] = None):
         """Prefill B equal-length prompts at position ``pos``; returns (logits [B,V], hidden [B,T,D], pos+T).
         reference: moondream.py:280-321 (per sequence)."""
         b = len(prompts)
         ids = torch.tensor(prompts, dtype=torch.int32)
         x = self._embed(ids) if prompt_embs is None else prompt_embs
-        hidden = self._text_forward(x, pos, slot0)
+        hidden = self._text_forward(x, pos, slot0, lora=lora)
         return self._lm_head(hidden), hidden, pos + ids.shape[1]
 
     def _decode_greedy(self, first: torch.Tensor, pos: Union[int, Sequence[int]], max_tokens: int, suppress_id: int,
-                       slot0: int = 0, eos_id: Optional[int] = None, check_every: int = 16) -> torch.Tensor:
+                       slot0: int = 0, eos_id: Optional[int] = None, check_every: int = 16,
+                       lora: Optional[PackedLora] = None) -> torch.Tensor:
         """Device-resident greedy loop: returns int32 [steps+1, B] (row 0 = ``first``).
         reference: the generator of moondream.py:471-530 without its per-token host sync.
         ``pos`` is the position of the next token, one int or one per sequence (sequences whose
@@ -510,6 +536,20 @@ class MoondreamModel:
             return eos_id is not None and bool((hist[: upto + 1] == eos_id).any(dim=0).all())
 
         steps = 0
+        if lora is not None:
+            # LoRA variant: the fused device-resident step has no side path; same loop from its pieces
+            # (embed -> decoder with the low-rank pairs -> lm_head -> suppress + argmax), still without a host sync per token
+            pos_t, pos_h = pos_base.clone(), list(pos_list)
+            while steps < max_tokens:
+                emb = self._embed(hist[steps].reshape(b, 1))
+                h = self._text_forward(emb, pos_h, slot0, pos_dev=pos_t, lora=lora)
+                hist[steps + 1] = self._pick(self._lm_head(h), 0.0, 0.0, suppress_id)
+                pos_t.add_(1)
+                pos_h = [p + 1 for p in pos_h]
+                steps += 1
+                if check_every and steps % check_every == 0 and all_done(steps):
+                    break
+            return hist[: steps + 1]
         if not self.use_graphs:
             pos_t = pos_base.clone()
             while steps < max_tokens:
@@ -573,7 +613,7 @@ class MoondreamModel:
             out.append(tok)
         return out
 
-    def _prepare_sequences(self, images, prompts: Sequence[Sequence[int]], mark=None):
+    def _prepare_sequences(self, images, prompts: Sequence[Sequence[int]], mark=None, lora: Optional[PackedLora] = None):
         """Everything before the first generated token, for B (image, prompt-ids) pairs: sequences are
         placed in KV slots in order of prompt length (stable), so that every group of equal-length
         prompts occupies a contiguous slot range; raw images are encoded together and prefilled
@@ -603,7 +643,7 @@ class MoondreamModel:
                 k = j
                 while k + 1 < len(raw_idx) and raw_idx[k + 1] == raw_idx[k] + 1:
                     k += 1
-                pos = self._prefill_images(img_emb[j : k + 1], raw_idx[j])
+                pos = self._prefill_images(img_emb[j : k + 1], raw_idx[j], lora)
                 j = k + 1
             mark("image_prefill")
         for i, im in enumerate(images):
@@ -620,7 +660,7 @@ class MoondreamModel:
             g1 = g0
             while g1 < b and len(prompts[g1]) == len(prompts[g0]):
                 g1 += 1
-            logits, hidden, p1 = self._prefill_prompts(prompts[g0:g1], pos, g0)
+            logits, hidden, p1 = self._prefill_prompts(prompts[g0:g1], pos, g0, lora=lora)
             first[g0:g1] = self._pick(logits, 0.0, 0.0)
             hidden_last[g0:g1] = hidden[:, -1, :]
             next_pos[g0:g1] = [p1] * (g1 - g0)
@@ -635,6 +675,7 @@ class MoondreamModel:
         max_tokens: int = DEFAULT_MAX_TOKENS,
         eos_id: Optional[int] = None,
         ignore_eos: bool = False,
+        variant: Optional[str] = None,
     ) -> List[List[int]]:
         """Greedy token ids for B (image, prompt-ids) pairs, decoded in lockstep.
 
@@ -656,12 +697,13 @@ class MoondreamModel:
                 e.record(torch.cuda.current_stream(self._device))
                 marks.append((name, e))
 
+        lora = self._lora({"variant": variant})
         with torch.inference_mode():
-            order, first, _, next_pos = self._prepare_sequences(list(images), prompts, mark)
+            order, first, _, next_pos = self._prepare_sequences(list(images), prompts, mark, lora)
             b = len(order)
             stop = None if ignore_eos else eos
             hist = self._decode_greedy(first, next_pos if len(set(next_pos)) > 1 else next_pos[0], max_tokens,
-                                       tk.answer_id, 0, stop)
+                                       tk.answer_id, 0, stop, lora=lora)
             mark("decode")
             cols = hist.t().tolist()
             results: List[Optional[List[int]]] = [None] * b
@@ -733,7 +775,7 @@ class MoondreamModel:
         if length not in tpl:
             raise ValueError(f"Model does not support caption length '{length}'.")
         mt = (settings or {}).get("max_tokens", DEFAULT_MAX_TOKENS)
-        ids = self.batch_generate_ids(images, [tpl[length]] * len(images), mt)
+        ids = self.batch_generate_ids(images, [tpl[length]] * len(images), mt, variant=(settings or {}).get("variant"))
         return [self.tokenizer.decode(s) for s in ids]
 
     def batch_query(self, images, questions: Sequence[str], settings: Optional[dict] = None) -> List[str]:
@@ -745,7 +787,7 @@ class MoondreamModel:
             list(tpl["prefix"]) + list(self.tokenizer.encode(q).ids) + list(tpl["suffix"]) + list(tpl["suffix"])
             for q in questions
         ]
-        ids = self.batch_generate_ids(images, prompts, mt)
+        ids = self.batch_generate_ids(images, prompts, mt, variant=(settings or {}).get("variant"))
         return [self.tokenizer.decode(s) for s in ids]
 
     def batch_generate(self, images, prompts: Optional[Sequence[str]] = None, settings: Optional[dict] = None) -> List[str]:
@@ -769,7 +811,7 @@ class MoondreamModel:
                 emb[ids.to(self._device) == self.config.tokenizer.coord_id] = enc["coords"]
                 if enc["sizes"] is not None:
                     emb[ids.to(self._device) == self.config.tokenizer.size_id] = enc["sizes"]
-            hidden = self._text_forward(emb, pos, 0, causal=causal)
+            hidden = self._text_forward(emb, pos, 0, causal=causal, lora=lora if isinstance(lora, PackedLora) else None)
             logits = self._lm_head(hidden)
             nxt = self._pick(logits, temperature, top_p)
         return logits, hidden, nxt.reshape(1, 1), pos + ids.shape[1]
@@ -782,14 +824,13 @@ class MoondreamModel:
         max_tokens = settings.get("max_tokens", DEFAULT_MAX_TOKENS)
         temperature = settings.get("temperature", DEFAULT_TEMPERATURE)
         top_p = settings.get("top_p", DEFAULT_TOP_P)
-        if settings.get("variant") is not None:
-            raise NotImplementedError("LoRA variants are not on the native path")
+        lora = self._lora(settings)
         eos = eos_id if eos_id is not None else self.config.tokenizer.eos_id
         # decode steps attend to keys [0, pos] only, which both masks allow: the mask matters for the prompt
-        _, _, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask, causal=causal)
+        _, _, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask, lora=lora, causal=causal)
 
         def token_source():
-            if temperature == 0:
+            if temperature == 0 and lora is None:
                 done = 0
                 first = nxt.reshape(1).to(torch.int32)
                 cur_pos = pos
@@ -814,7 +855,7 @@ class MoondreamModel:
                         return
                     with torch.inference_mode():
                         emb = self._embed(tok.reshape(1, 1))
-                        hidden = self._text_forward(emb, cur_pos, 0)
+                        hidden = self._text_forward(emb, cur_pos, 0, lora=lora)
                         logits = self._lm_head(hidden)
                         cur_pos += 1
                         tok = self._pick(logits, temperature, top_p, self.config.tokenizer.answer_id)  # moondream.py:517
@@ -862,7 +903,7 @@ class MoondreamModel:
             raise NotImplementedError("Model does not support captioning.")
         if length not in tpl:
             raise ValueError(f"Model does not support caption length '{length}'.")
-        enc = self.encode_image(image)
+        enc = self.encode_image(image, settings)
         self.load_encoded_image(enc)
         prompt = torch.tensor([tpl[length]])
         gen = self._generate_answer(prompt, enc.pos, settings)
@@ -880,7 +921,7 @@ class MoondreamModel:
         if spatial_refs and image is None:
             raise ValueError("spatial_refs can only be used with an image.")
         if image is not None:
-            enc = self.encode_image(image)
+            enc = self.encode_image(image, settings)
             self.load_encoded_image(enc)
             pos, head, causal = enc.pos, list(tpl["prefix"]), False
         else:
@@ -916,10 +957,9 @@ class MoondreamModel:
         max_tokens = settings.get("max_tokens", DEFAULT_MAX_TOKENS)
         temperature = settings.get("temperature", DEFAULT_TEMPERATURE)
         top_p = settings.get("top_p", DEFAULT_TOP_P)
-        if settings.get("variant") is not None:
-            raise NotImplementedError("LoRA variants are not on the native path")
+        lora = self._lora(settings)
         tk = self.config.tokenizer
-        _, hidden, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask, causal=causal)
+        _, hidden, nxt, pos = self._prefill_prompt(prompt_tokens, pos, temperature, top_p, spatial_refs, attn_mask, lora=lora, causal=causal)
         last_hidden = hidden[:, -1:, :].reshape(1, -1)
         text_chunks: List[List[int]] = [[]]
         grounding_chunks: List[List[float]] = [[]]
@@ -940,7 +980,7 @@ class MoondreamModel:
                     grounding_chunks[-1].append((bins[0, 0].to(torch.int64) / n_bins).item())
                 else:
                     emb = self._embed(torch.tensor([[tok]]))
-                h = self._text_forward(emb.reshape(1, 1, -1), pos, 0)
+                h = self._text_forward(emb.reshape(1, 1, -1), pos, 0, lora=lora)
                 logits = self._lm_head(h)
                 logits[:, suppress] = float("-inf")  # moondream.py:397-398
                 pos += 1
@@ -1076,7 +1116,7 @@ class MoondreamModel:
         return self._lin(feats, enc)
 
     def _points_loop(self, hidden: torch.Tensor, first: torch.Tensor, pos: Sequence[int], slot0: int, include_size: bool,
-                     max_objects: int) -> List[List[dict]]:
+                     max_objects: int, lora: Optional[PackedLora] = None) -> List[List[dict]]:
         """The loop of moondream.py:653-733 for B sequences in lockstep.  hidden [B, D] = last prompt
         position, first int32 [B] = the token after the prompt, pos[b] = next position."""
         b = hidden.shape[0]
@@ -1094,7 +1134,7 @@ class MoondreamModel:
 
         def step(emb):
             nonlocal pos_host, hidden
-            h = self._text_forward(emb.reshape(b, 1, -1), pos_host, slot0, pos_dev=pos_dev)
+            h = self._text_forward(emb.reshape(b, 1, -1), pos_host, slot0, pos_dev=pos_dev, lora=lora)
             pos_host = [p + 1 for p in pos_host]
             pos_dev.add_(1)
             hidden = h.reshape(b, -1)
@@ -1147,13 +1187,12 @@ class MoondreamModel:
         if tpl is None:
             raise NotImplementedError(f"Model does not support {kind}.")
         self._region()
-        if settings is not None and settings.get("variant") is not None:
-            raise NotImplementedError("LoRA variants are not on the native path")
+        lora = self._lora(settings)  # moondream.py:757-761
         max_objects = (settings or {}).get("max_objects", DEFAULT_MAX_OBJECTS)
         prompts = [list(tpl["prefix"]) + list(self.tokenizer.encode(" " + o).ids) + list(tpl["suffix"]) for o in objects]
         with torch.inference_mode():
-            order, first, hidden, next_pos = self._prepare_sequences(list(images), prompts)
-            res = self._points_loop(hidden, first, next_pos, 0, include_size, max_objects)
+            order, first, hidden, next_pos = self._prepare_sequences(list(images), prompts, None, lora)
+            res = self._points_loop(hidden, first, next_pos, 0, include_size, max_objects, lora)
         out = [None] * len(order)
         for slot, src in enumerate(order):
             out[src] = res[slot]

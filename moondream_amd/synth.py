@@ -222,3 +222,22 @@ def synthetic_vqa_prompt(config: MoondreamConfig, index: int, seed: int = 0, n_q
     hi = min(50000, config.text.vocab_size)
     q = rng.integers(10, hi, n_question).tolist()
     return list(tpl["prefix"]) + q + list(tpl["suffix"]) + list(tpl["suffix"])
+
+
+def synthetic_lora(config: MoondreamConfig, seed: int = 0, rank: int = 8, device="cpu", dtype=torch.bfloat16) -> dict:
+    """A seeded LoRA "variant" in the nested layout the reference's ``variant_state_dict`` returns
+    (lora.py:54-79): per decoder block A [rank, in] / B [out, rank] for attn.qkv, attn.proj, mlp.fc1, mlp.fc2.
+    Scales are large enough to move the logits (a wrong or missing side path changes the generated ids)."""
+    t = config.text
+    blocks = {}
+    for i in range(t.n_layers):
+        def pair(name, out_f, in_f, gain):
+            a = _tensor(f"lora.{i}.{name}.A", (rank, in_f), 1.0 / math.sqrt(in_f), seed, device, dtype)
+            b = _tensor(f"lora.{i}.{name}.B", (out_f, rank), gain / math.sqrt(rank), seed, device, dtype)
+            return {"A": a, "B": b}
+
+        blocks[str(i)] = {
+            "attn": {"qkv": pair("qkv", t.qkv_dim, t.dim, 0.5), "proj": pair("proj", t.dim, t.dim, 0.5)},
+            "mlp": {"fc1": pair("fc1", t.ff_dim, t.dim, 0.5), "fc2": pair("fc2", t.dim, t.ff_dim, 0.25)},
+        }
+    return {"text": {"blocks": blocks}}

@@ -175,6 +175,32 @@ def load_state_dict_file(weights_file: str) -> Dict[str, torch.Tensor]:
     return remap_legacy_keys(norm)
 
 
+class PackedLora:
+    """A LoRA variant packed for md_text_forward_lora: per block an md_text_block_lora of bias-free (A, B) pairs,
+    A [r, in] and B [out, r] zero-padded to 64-multiples like every other linear (reference layout: lora.py:54-79)."""
+
+    def __init__(self, config: MoondreamConfig, lora: dict, device):
+        t = config.text
+        self._keep: List[PackedLinear] = []
+        self.blocks = (_lib.MdTextBlockLora * t.n_layers)()
+        tree = lora.get("text", {}).get("blocks", {})
+        for i in range(t.n_layers):
+            layer = tree.get(str(i), {})
+            for group, names in (("attn", ("qkv", "proj")), ("mlp", ("fc1", "fc2"))):
+                for name in names:
+                    pair = layer.get(group, {}).get(name)
+                    if pair is None:
+                        continue
+                    a = PackedLinear(pair["A"], None, device)
+                    b = PackedLinear(pair["B"], None, device)
+                    assert a.n_pad <= 256 and b.k_pad == a.n_pad, "LoRA rank must be <= 256"
+                    self._keep += [a, b]
+                    setattr(self.blocks[i], name, _lib.MdLoraPair(a.struct(), b.struct()))
+
+    def ptr(self):
+        return C.cast(self.blocks, C.c_void_p)
+
+
 class PackedModel:
     """All weights resident on one device + the md_vit_model / md_text_model
     structs (kept alive here; the library only borrows the pointers)."""

@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [0.5b] [2b] [bench64] [reftime]
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [lora] [0.5b] [2b] [bench64] [reftime]
 """
 from __future__ import annotations
 
@@ -673,6 +673,70 @@ def gen_reasoning(name="tiny_reasoning", cfg_name="tiny", seed=1, n_cases=2, max
     print(f"[{name}] wrote {path}", flush=True)
 
 
+def gen_lora(name="tiny_lora", cfg_name="tiny", seed=1, rank=8, n_cases=2, max_tokens=12, min_margin=0.75):
+    """LoRA variant side path: the reference's caption() with settings["variant"] set, the download replaced by a
+    seeded synthetic variant (lora.py:54-79 -> text.py:31-32,55-56, layers.py:129-146; the image prefill uses the
+    variant too, moondream.py:241-257).  Records ids / margins with and without the variant."""
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    lora = synth.synthetic_lora(cfg, seed=seed, rank=rank)
+    ref_md.variant_state_dict = lambda variant_id, device=None: (lora if variant_id == "synthetic" else None)
+    caption_ids = cfg.tokenizer.templates["caption"]["normal"]
+    out = {"seed": np.int64(seed), "cfg": np.array(cfg_name), "rank": np.int64(rank), "max_tokens": np.int64(max_tokens)}
+
+    def run(image, variant):
+        from PIL import Image
+
+        rec = {"decode_logits": []}
+        orig_decode, orig_lm_head = model._decode_one_tok, ref_md.lm_head
+
+        def decode_tap(x, mask, pos_ids, lr):
+            assert (lr is not None) == (variant is not None)
+            logits, hidden = orig_decode(x, mask, pos_ids, lr)
+            rec["decode_logits"].append(logits[0].clone())
+            return logits, hidden
+
+        def lm_head_tap(h, w):
+            o = orig_lm_head(h, w)
+            rec.setdefault("prompt_logits", o[0].clone())
+            return o
+
+        model._decode_one_tok, ref_md.lm_head = decode_tap, lm_head_tap
+        try:
+            text = model.caption(Image.fromarray(image, "RGB"), settings={"temperature": 0, "max_tokens": max_tokens, "variant": variant})["caption"]
+        finally:
+            model._decode_one_tok, ref_md.lm_head = orig_decode, orig_lm_head
+        steps = [rec["prompt_logits"]]
+        for lg in rec["decode_logits"]:
+            lg = lg.clone()
+            lg[cfg.tokenizer.answer_id] = float("-inf")
+            steps.append(lg)
+        margins = [float((lambda t: t[0] - t[1])(torch.topk(lg.float(), 2).values)) for lg in steps]
+        return [int(t) for t in text.split()], margins
+
+    kept, src = 0, -1
+    while kept < n_cases:
+        src += 1
+        assert src < 200
+        image = synth.synthetic_image_array(src, seed, (378, 378))
+        toks, margins = run(image, "synthetic")
+        base, _ = run(image, None)
+        if min(margins) < min_margin or toks == base:
+            print(f"[{name}] skip image {src}: min margin {min(margins):.3f}, differs from base: {toks != base}", flush=True)
+            continue
+        out[f"case{kept}.image_index"] = np.int64(src)
+        out[f"case{kept}.tokens"] = np.array(toks)
+        out[f"case{kept}.base_tokens"] = np.array(base)
+        out[f"case{kept}.margins"] = np.array(margins, dtype=np.float32)
+        print(f"[{name}] case{kept}: image {src}: variant {toks} | base {base} (min margin {min(margins):.3f})", flush=True)
+        kept += 1
+    out["n_cases"] = np.int64(kept)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -688,6 +752,8 @@ def main():
         gen_textonly()
     if "0.5b" in which:
         gen_model_case("md05b_seed1", "0.5b", 1, [(378, 378)], 32, False, n_images=2, min_margin=0.5)
+    if "lora" in which:
+        gen_lora()
     if "reasoning" in which:
         gen_reasoning()
     if "sampling" in which:

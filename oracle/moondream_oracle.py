@@ -100,12 +100,22 @@ def gelu_tanh(x: torch.Tensor):
     return _r(0.5 * xf * (1.0 + torch.tanh(inner)))
 
 
-def mlp(x, sd, prefix, fast=False):
-    """fc1 -> gelu(tanh) -> fc2 without the LoRA branch.  reference:
-    layers.py:129-146."""
+def lora_delta(x, pair, fast=False):
+    """(x A^T) B^T as two bf16 linears.  reference: layers.py:132,141, text.py:32,55."""
+    return linear(linear(x, pair["A"], None, fast), pair["B"], None, fast)
+
+
+def mlp(x, sd, prefix, fast=False, lora=None):
+    """fc1 -> gelu(tanh) -> fc2; with ``lora`` ({"fc1": {A, B}, "fc2": {A, B}}) each linear's output gets its
+    low-rank delta added as a bf16 tensor add BEFORE the next op.  reference: layers.py:129-146."""
     h = linear(x, sd[prefix + ".fc1.weight"], sd[prefix + ".fc1.bias"], fast)
+    if lora is not None:
+        h = add_bf16(h, lora_delta(x, lora["fc1"], fast))
     h = gelu_tanh(h)
-    return linear(h, sd[prefix + ".fc2.weight"], sd[prefix + ".fc2.bias"], fast)
+    y = linear(h, sd[prefix + ".fc2.weight"], sd[prefix + ".fc2.bias"], fast)
+    if lora is not None:
+        y = add_bf16(y, lora_delta(h, lora["fc2"], fast))
+    return y
 
 
 def softmax_attention(q, k, v, allowed: Optional[torch.Tensor], scale: float, fast: bool = False):
@@ -335,12 +345,14 @@ class OracleKV:
         return OracleKV([a.clone() for a in self.k], [a.clone() for a in self.v])
 
 
-def text_attention(x, sd, prefix, cfg, layer, kv: OracleKV, pos: torch.Tensor, cos, sin, allowed, fast=False):
+def text_attention(x, sd, prefix, cfg, layer, kv: OracleKV, pos: torch.Tensor, cos, sin, allowed, fast=False, lora=None):
     """reference: text.py:16-60.  x [T, D]."""
     t = cfg.text
     T = x.shape[0]
     hd = t.head_dim
     qkv = linear(x, sd[prefix + ".qkv.weight"], sd[prefix + ".qkv.bias"], fast)
+    if lora is not None:
+        qkv = add_bf16(qkv, lora_delta(x, lora["qkv"], fast))  # text.py:31-32
     qd, kd = t.n_heads * hd, t.n_kv_heads * hd
     q = qkv[:, :qd].reshape(T, t.n_heads, hd).permute(1, 0, 2)
     k = qkv[:, qd : qd + kd].reshape(T, t.n_kv_heads, hd).permute(1, 0, 2)
@@ -358,10 +370,13 @@ def text_attention(x, sd, prefix, cfg, layer, kv: OracleKV, pos: torch.Tensor, c
         kk, vv = kk.repeat_interleave(rep, 0), vv.repeat_interleave(rep, 0)
     o = softmax_attention(q, kk, vv, allowed[:, :n_kv], 1.0 / math.sqrt(hd), fast)
     o = o.permute(1, 0, 2).reshape(T, qd)
-    return linear(o, sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"], fast)
+    out = linear(o, sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"], fast)
+    if lora is not None:
+        out = add_bf16(out, lora_delta(x, lora["proj"], fast))  # text.py:55: the pair is fed the BLOCK INPUT x, not `o`
+    return out
 
 
-def text_decoder(x, sd, cfg, kv: OracleKV, pos: torch.Tensor, cos, sin, tap=None, fast=False, prefix=None):
+def text_decoder(x, sd, cfg, kv: OracleKV, pos: torch.Tensor, cos, sin, tap=None, fast=False, prefix=None, lora=None):
     """Parallel attention + MLP off ONE LayerNorm, then two left-to-right bf16
     adds.  reference: text.py:128-160.  x [T, D] -> [T, D]; writes kv.
     ``prefix`` overrides the bidirectional prefix length (0 = the plain causal
@@ -371,8 +386,9 @@ def text_decoder(x, sd, cfg, kv: OracleKV, pos: torch.Tensor, cos, sin, tap=None
     for i in range(t.n_layers):
         p = f"text.blocks.{i}"
         h = layer_norm(x, sd[p + ".ln.weight"], sd[p + ".ln.bias"])
-        a = text_attention(h, sd, p + ".attn", cfg, i, kv, pos, cos, sin, allowed, fast)
-        m = mlp(h, sd, p + ".mlp", fast)
+        ll = None if lora is None else lora["text"]["blocks"][str(i)]  # text.py:137-140
+        a = text_attention(h, sd, p + ".attn", cfg, i, kv, pos, cos, sin, allowed, fast, None if ll is None else ll["attn"])
+        m = mlp(h, sd, p + ".mlp", fast, None if ll is None else ll["mlp"])
         x = add_bf16(add_bf16(x, a), m)
         if tap is not None and i in (0, t.n_layers - 1):
             tap[f"text.block{i}"] = x
@@ -432,6 +448,7 @@ class Oracle:
         self.cfg = cfg
         self.sd = {k: v.detach().to("cpu") for k, v in state_dict.items()}
         self.fast = fast
+        self.lora = None  # nested LoRA dict (lora.py:54-79) applied by every decoder call below when set
         self.cos, self.sin = rope_table(cfg.text.rot_dim // 2, cfg.text.max_context)
 
     def embed(self, ids) -> torch.Tensor:
@@ -444,20 +461,20 @@ class Oracle:
         x = torch.cat([self.embed([self.cfg.tokenizer.bos_id]), img], dim=0)
         kv = OracleKV.empty(self.cfg)
         pos = torch.arange(x.shape[0])
-        text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast)
+        text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast, lora=self.lora)
         return x.shape[0], kv
 
     def prefill_prompt(self, prompt_ids, pos0: int, kv: OracleKV, tap=None, prompt_emb=None, prefix=None):
         """reference: moondream.py:280-321 (greedy branch)."""
         x = self.embed(prompt_ids) if prompt_emb is None else prompt_emb
         pos = torch.arange(pos0, pos0 + x.shape[0])
-        h = text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast, prefix)
+        h = text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast, prefix, lora=self.lora)
         logits = lm_head(h[-1], self.sd, self.fast)
         return logits, h, pos0 + x.shape[0]
 
     def decode_token(self, emb: torch.Tensor, pos: int, kv: OracleKV, prefix=None):
         """reference: moondream.py:183-192.  emb [1, D]."""
-        h = text_decoder(emb, self.sd, self.cfg, kv, torch.tensor([pos]), self.cos, self.sin, None, self.fast, prefix)
+        h = text_decoder(emb, self.sd, self.cfg, kv, torch.tensor([pos]), self.cos, self.sin, None, self.fast, prefix, lora=self.lora)
         return lm_head(h[-1], self.sd, self.fast), h
 
     @staticmethod

@@ -365,6 +365,48 @@ def test_reasoning_query_vs_reference(tiny, golden_dir):
     assert len(grounding) == 1 and len(grounding[0]["points"]) == 1 and all(0.0 <= c < 1.0 for c in grounding[0]["points"][0])
 
 
+def test_lora_variant_vs_reference(tiny, golden_dir):
+    """settings={"variant": id}: ids equal the reference's run with the same (seeded) LoRA variant, through caption(),
+    the batched engine and detect(); an unknown variant fails loudly instead of downloading."""
+    g0, cfg, sd, model = tiny
+    g = load_golden(golden_dir, "tiny_lora.npz")
+    model.register_variant("synthetic", synth.synthetic_lora(cfg, seed=int(g["seed"]), rank=int(g["rank"]), device="cuda"))
+    images = []
+    for i in range(int(g["n_cases"])):
+        img = Image.fromarray(synth.synthetic_image_array(int(g[f"case{i}.image_index"]), int(g["seed"]), (378, 378)), "RGB")
+        images.append(img)
+        want = g[f"case{i}.tokens"].tolist()
+        st = {"temperature": 0, "max_tokens": len(want), "variant": "synthetic"}
+        assert [int(t) for t in model.caption(img, settings=st)["caption"].split()] == want
+        base = model.caption(img, settings={"temperature": 0, "max_tokens": len(want)})["caption"]
+        assert [int(t) for t in base.split()] == g[f"case{i}.base_tokens"].tolist()
+    prompt = cfg.tokenizer.templates["caption"]["normal"]
+    n = len(g["case0.tokens"])
+    got = model.batch_generate_ids(images, [prompt] * len(images), max_tokens=n, variant="synthetic")
+    assert got == [g[f"case{i}.tokens"].tolist() for i in range(len(images))]
+    objs = model.detect(images[0], "7 8", settings={"max_objects": 1, "variant": "synthetic"})["objects"]
+    assert len(objs) <= 1
+    with pytest.raises(FileNotFoundError):
+        model.caption(images[0], settings={"variant": "no-such-variant-anywhere"})
+
+
+def test_rowwise_add_and_gelu_kernels():
+    from moondream_amd import _lib
+    import ctypes as C
+
+    lib = _lib.load()
+    a = torch.randn(77, 704, generator=torch.Generator().manual_seed(1)).to(BF16).cuda()
+    b = torch.randn(77, 704, generator=torch.Generator().manual_seed(2)).to(BF16).cuda()
+    out = torch.empty_like(a)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.md_add_bf16(a.data_ptr(), 704, b.data_ptr(), 704, out.data_ptr(), 704, 77, 704, st))
+    torch.cuda.synchronize()
+    assert torch.equal(out, a + b)
+    _lib.check(lib.md_gelu_bf16(a.data_ptr(), 704, out.data_ptr(), 704, 77, 704, st))
+    torch.cuda.synchronize()
+    compare("gelu", out, torch.nn.functional.gelu(a.float(), approximate="tanh").to(BF16), 3e-3, 2e-2)
+
+
 # ------------------------------------------------------------------ batched string API + HF wrapper
 def test_batch_generate_strings_ragged_equals_sequential(tiny):
     """batch_generate / batch_query / batch_caption (the names BASELINE.json uses) with questions of

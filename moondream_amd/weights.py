@@ -152,10 +152,48 @@ def remap_legacy_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
+def dequantize_int4(packed: torch.Tensor, scale: torch.Tensor, zero_point: torch.Tensor, out_features: int) -> torch.Tensor:
+    """The reference's 4-bit checkpoint format back to a bf16 [out, in] weight (layers.py:38-44): ``packed`` is
+    uint8 [out*in/256, 128]; the high nibbles are the first half of the group rows, the low nibbles the second
+    half; every 128-wide group row has one ``scale`` and one ``zero_point``; the arithmetic runs in place on a bf16
+    tensor (subtract, round, multiply, round) so the result is bit-identical to the reference's dequantize_tensor."""
+    step = packed.shape[0]
+    w = torch.empty(2 * step, packed.shape[1], dtype=BF16, device=packed.device)
+    w[:step] = (packed & 0xF0) >> 4
+    w[step:] = packed & 0x0F
+    w.sub_(zero_point).mul_(scale)
+    if w.numel() % out_features:
+        raise ValueError(f"int4 weight of {w.numel()} elements does not divide into {out_features} rows")
+    return w.reshape(out_features, -1)
+
+
+def dequantize_int4_entries(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Replace every ``<p>.weight.packed / .scale / .zero_point`` triple (the reference's QuantizedLinear parameters,
+    layers.py:57-74; text blocks' qkv/proj/fc1/fc2 when config.text.group_size is set, text.py:178, the region
+    coordinate/size encoders and decoders when config.region.group_size is set, moondream.py:95) by the bf16
+    ``<p>.weight`` the kernels consume.  The reference then re-quantises that tensor for torchao's int4 GEMM
+    (layers.py:100); this framework runs it as bf16 -- 4x the weight bytes, none of the second rounding."""
+    packed = [k for k in sd if k.endswith(".weight.packed")]
+    if not packed:
+        return sd
+    out = dict(sd)
+    for k in packed:
+        p = k[: -len(".weight.packed")]
+        bias = sd.get(p + ".bias")
+        if bias is None:
+            raise KeyError(f"{p}.bias is needed to recover the shape of the int4 weight {k}")
+        out[p + ".weight"] = dequantize_int4(
+            sd[k], sd[p + ".weight.scale"], sd[p + ".weight.zero_point"], bias.shape[0])
+        for suffix in (".weight.packed", ".weight.scale", ".weight.zero_point"):
+            del out[p + suffix]
+    return out
+
+
 def load_state_dict_file(weights_file: str) -> Dict[str, torch.Tensor]:
     """Read a checkpoint the way the reference's ``load_weights_into_model`` does
     (weights.py:112-171): ``.safetensors`` or a torch ``.pt`` state dict, in the
-    module-tree key layout (optionally prefixed ``model.``) or the older
+    module-tree key layout (optionally prefixed ``model.``; 4-bit QuantizedLinear
+    triples are dequantised to bf16, see dequantize_int4_entries) or the older
     ``vision_encoder.* / text_model.* / region_model.*`` layout (optionally with
     torch.compile's ``._orig_mod`` infix).  Returns module-tree keys; tensors
     stay on the CPU (``PackedModel`` moves and packs them)."""
@@ -172,7 +210,7 @@ def load_state_dict_file(weights_file: str) -> Dict[str, torch.Tensor]:
         if k.startswith("model."):
             k = k[len("model."):]
         norm[k] = v
-    return remap_legacy_keys(norm)
+    return dequantize_int4_entries(remap_legacy_keys(norm))
 
 
 class PackedLora:
@@ -208,7 +246,7 @@ class PackedModel:
     def __init__(self, config: MoondreamConfig, state_dict: Dict[str, torch.Tensor], device):
         self.config = config
         self.device = torch.device(device)
-        sd = remap_legacy_keys(state_dict)
+        sd = dequantize_int4_entries(remap_legacy_keys(state_dict))
         self.sd_keys = set(sd)
         v, t = config.vision, config.text
         dev = self.device

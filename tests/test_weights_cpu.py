@@ -77,3 +77,60 @@ def test_checkpoint_layouts_and_containers(tmp_path):
     p3 = os.path.join(tmp_path, "c.pt")
     torch.save(legacy, p3)
     _same(load_state_dict_file(p3), sd)
+
+
+def _quantize_int4(w, group=128):
+    """Test-side packer: the inverse of the checkpoint format dequantize_int4 reads (reference layers.py:38-44)."""
+    out_f, in_f = w.shape
+    rows = w.float().reshape(-1, group)
+    lo, hi = rows.min(1, keepdim=True).values, rows.max(1, keepdim=True).values
+    scale = ((hi - lo) / 15).clamp_min(1e-8)
+    zero = (-lo / scale)
+    q = torch.clamp(torch.round(rows / scale + zero), 0, 15).to(torch.uint8)
+    step = q.shape[0] // 2
+    packed = (q[:step] << 4) | q[step:]
+    return packed, scale, zero
+
+
+def test_int4_checkpoint_is_dequantised_like_the_reference(tmp_path):
+    import pytest
+    from safetensors.torch import save_file
+
+    from moondream_amd.weights import dequantize_int4
+
+    cfg = get_config("tiny")
+    sd = {k: v.contiguous() for k, v in synth.synthetic_state_dict(cfg, seed=5).items()}
+    q_names = [f"text.blocks.{i}.{n}" for i in range(cfg.text.n_layers)
+               for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")]
+    q_names += ["region.coord_encoder", "region.size_decoder.fc1"]
+    qsd, expect = dict(sd), dict(sd)
+    for n in q_names:
+        w = sd[n + ".weight"]
+        if w.numel() % 256:
+            continue
+        packed, scale, zero = _quantize_int4(w)
+        del qsd[n + ".weight"]
+        qsd[n + ".weight.packed"], qsd[n + ".weight.scale"], qsd[n + ".weight.zero_point"] = packed, scale, zero
+        expect[n + ".weight"] = dequantize_int4(packed, scale, zero, w.shape[0])
+        # 4-bit round trip of a smooth weight: within one quantisation step
+        assert (expect[n + ".weight"].float() - w.float()).abs().max() <= scale.max() * 1.01 + 1e-2
+    assert any(k.endswith(".weight.packed") for k in qsd)
+    path = os.path.join(tmp_path, "q.safetensors")
+    save_file({k: v.contiguous() for k, v in qsd.items()}, path)
+    _same(load_state_dict_file(path), expect)
+
+    # bit-exact against the reference's own dequantize_tensor where the reference tree is present
+    if not os.path.isdir("/root/reference/moondream/torch"):
+        pytest.skip("reference tree not on this machine")
+    # (layers.py imports torchao, absent here: evaluate just that function's source, in place)
+    src = open("/root/reference/moondream/torch/layers.py").read()
+    start = src.index("def dequantize_tensor")
+    end = src.index("\n\n\n", start)
+    ns = {"torch": torch}
+    exec(compile(src[start:end], "reference:layers.py", "exec"), ns)
+    g = torch.Generator().manual_seed(0)
+    packed = torch.randint(0, 256, (96, 128), dtype=torch.uint8, generator=g)
+    scale = torch.rand(192, 1, generator=g) * 0.02 + 1e-3
+    zero = torch.rand(192, 1, generator=g) * 15
+    ref = ns["dequantize_tensor"](packed, scale, zero, (48, 512))
+    assert torch.equal(ref, dequantize_int4(packed, scale, zero, 48))

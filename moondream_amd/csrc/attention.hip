@@ -587,7 +587,15 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
 // decode: one query row per (sequence, head)
 // ---------------------------------------------------------------------------
 // 8 lanes cover one 128-byte key/value row (8 x 16 B); a wave covers 8 rows per
-// load instruction, the 4 waves of the workgroup interleave rows mod 32.
+// load instruction.  Keys are partitioned into 128 classes (key index mod 128); class
+// 32 u + r is accumulated on its own (fp32, ascending key order), the four classes of a
+// residue r are combined as (u0 + u1) + (u2 + u3) and the 32 residues summed in
+// ascending order.  That order is the DEFINITION of the result, so the two launch
+// shapes below produce the same bits:
+//   NW = 4   (large batches): thread group (wave, g) owns residue 8 wave + g and its
+//            four classes -- four independent load streams per thread;
+//   NW = 16  (few sequences): 16 waves, thread group owns ONE class -- a quarter of the
+//            dependent iterations, for the latency-bound single-sequence decode step.
 // Pass 1 streams K (scores -> LDS, running max), pass 2 streams V.
 constexpr int DEC_MAX_CTX = 2048;
 
@@ -596,17 +604,21 @@ constexpr int DEC_MAX_CTX = 2048;
 // rotated k and v at slot pos = kv_len - 1 of the slab (moondream.py:74-78) and treats
 // that newest key from LDS -- one launch instead of rope_kv_kernel + attention, same
 // arithmetic (bf16-rounded rotated values), MHA only.
-template <bool FUSED>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq,
-                                                          bf16_t* __restrict__ o, int64_t ldo,
-                                                          bf16_t* __restrict__ kslab,
-                                                          bf16_t* __restrict__ vslab,
-                                                          int64_t slab_bs, int ctx, const int32_t* kv_len_p,
-                                                          int n_heads, int kv_group, float scale_log2,
-                                                          const float* __restrict__ freqs, int rot) {
+template <bool FUSED, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                              bf16_t* __restrict__ o, int64_t ldo,
+                                                              bf16_t* __restrict__ kslab,
+                                                              bf16_t* __restrict__ vslab,
+                                                              int64_t slab_bs, int ctx, const int32_t* kv_len_p,
+                                                              int n_heads, int kv_group, float scale_log2,
+                                                              const float* __restrict__ freqs, int rot) {
+  static_assert(NW == 4 || NW == 16, "waves per workgroup");
+  constexpr int CPT = 16 / NW;            // classes per thread group
+  constexpr int NU = (NW == 16) ? 4 : 1;  // class quarters that live in different waves
+  constexpr int UNR = (NW == 16) ? 4 : 2; // 128-key rounds whose loads are issued together
   __shared__ float sc[DEC_MAX_CTX];
-  __shared__ float red[4][8][64 + 1];
-  __shared__ float red_m[4], red_l[4];
+  __shared__ float red[NU][32][64 + 1];   // [class quarter][residue][feature | sum of p]
+  __shared__ float red_m[NW];
   __shared__ __attribute__((aligned(16))) bf16_t newrow[3][64];  // FUSED: rotated q, rotated k, v of the new token
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -616,6 +628,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   const int pos = kv_len - 1;
   bf16_t* kb = kslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
   bf16_t* vb = vslab + (int64_t)b * slab_bs + (int64_t)hk * ctx * 64;
+  // residue and first class of this thread group
+  const int res = (NW == 16) ? ((wave & 3) * 8 + g) : (wave * 8 + g);
+  const int u0 = (NW == 16) ? (wave >> 2) : 0;
 
   if constexpr (FUSED) {
     // row layout: [q heads | k heads | v heads], 64 features per head
@@ -632,7 +647,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     } else if (tid >= 64 && tid < 64 + 2 * (64 - rot)) {  // pass-through features of q and k
       const int t2 = tid - 64, which = t2 / (64 - rot), i = rot + t2 % (64 - rot);
       newrow[which][i] = row[(which ? (n_heads + h) : h) * 64 + i];
-    } else if (tid >= 192) {  // v
+    } else if (tid >= 192 && tid < 256) {  // v
       const int i = tid - 192;
       newrow[2][i] = row[(2 * n_heads + h) * 64 + i];
     }
@@ -651,55 +666,108 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
   }
 
+  // key of (round i, class slot u): 128 i + 32 (u0 + u) + res; rows past kv_len replay the last row, masked below
   // ---- pass 1: scores --------------------------------------------------------
   float mx = -INFINITY;
-  for (int j = wave * 8 + g; j < kv_len; j += 32) {
-    // (FUSED: the newest key is not yet visible in global memory to this CU: take it from LDS)
-    const u32x4 kq = (FUSED && j == pos) ? *(const u32x4*)(&newrow[1][c * 8]) : *(const u32x4*)(kb + (int64_t)j * 64 + c * 8);
-    float s = 0.f;
+  for (int i0 = 0; i0 * 128 < kv_len; i0 += UNR) {
+    u32x4 kq[UNR][CPT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s += qv[2 * e] * lo_bf(kq[e]) + qv[2 * e + 1] * hi_bf(kq[e]);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (c == 0) sc[j] = s;
-    mx = fmaxf(mx, s);
+    for (int r = 0; r < UNR; ++r)
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
+        kq[r][u] = *(const u32x4*)(kb + (int64_t)min(j, pos) * 64 + c * 8);
+      }
+#pragma unroll
+    for (int r = 0; r < UNR; ++r)
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
+        // (FUSED: the newest key is not yet visible in global memory to this CU: take it from LDS)
+        const u32x4 kk = (FUSED && j == pos) ? *(const u32x4*)(&newrow[1][c * 8]) : kq[r][u];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += qv[2 * e] * lo_bf(kk[e]) + qv[2 * e + 1] * hi_bf(kk[e]);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (j < kv_len) {
+          if (c == 0) sc[j] = s;
+          mx = fmaxf(mx, s);
+        }
+      }
   }
   mx = wave_max(mx);
   if (lane == 0) red_m[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+  mx = red_m[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red_m[w]);
 
   // ---- pass 2: probabilities and P.V ----------------------------------------
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float l = 0.f;
-  for (int j = wave * 8 + g; j < kv_len; j += 32) {
-    const float pj = __builtin_amdgcn_exp2f(sc[j] - mx);
-    l += pj;
-    const float pr = bf2f(f2bf(pj));  // probabilities enter the second contraction as bf16
-    const u32x4 vq = (FUSED && j == pos) ? *(const u32x4*)(&newrow[2][c * 8]) : *(const u32x4*)(vb + (int64_t)j * 64 + c * 8);
+  float acc[CPT][8], l[CPT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc[2 * e] += pr * lo_bf(vq[e]);
-      acc[2 * e + 1] += pr * hi_bf(vq[e]);
-    }
+  for (int u = 0; u < CPT; ++u) {
+    l[u] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[u][e] = 0.f;
   }
-  // every lane of a row group added the same p: count it once (lanes c == 0)
-  l = (c == 0) ? l : 0.f;
-  l = wave_sum(l);
-  if (lane == 0) red_l[wave] = l;
+  for (int i0 = 0; i0 * 128 < kv_len; i0 += UNR) {
+    u32x4 vq[UNR][CPT];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[wave][g][c * 8 + e] = acc[e];
+    for (int r = 0; r < UNR; ++r)
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
+        vq[r][u] = *(const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 8);
+      }
+#pragma unroll
+    for (int r = 0; r < UNR; ++r)
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
+        const u32x4 vv = (FUSED && j == pos) ? *(const u32x4*)(&newrow[2][c * 8]) : vq[r][u];
+        const float pj = (j < kv_len) ? __builtin_amdgcn_exp2f(sc[min(j, pos)] - mx) : 0.f;
+        l[u] += pj;
+        const float pr = bf2f(f2bf(pj));  // probabilities enter the second contraction as bf16
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[u][2 * e] += pr * lo_bf(vv[e]);
+          acc[u][2 * e + 1] += pr * hi_bf(vv[e]);
+        }
+      }
+  }
+  if constexpr (NW == 4) {
+    // the four classes of this residue are in registers: (u0 + u1) + (u2 + u3)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[0][res][c * 8 + e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    if (c == 0) red[0][res][64] = (l[0] + l[1]) + (l[2] + l[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[u0][res][c * 8 + e] = acc[0][e];
+    if (c == 0) red[u0][res][64] = l[0];
+  }
   __syncthreads();
   if (tid < 64) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int gg = 0; gg < 8; ++gg) s += red[w][gg][tid];
-    const float lt = red_l[0] + red_l[1] + red_l[2] + red_l[3];
+    float s = 0.f, lt = 0.f;
+    for (int r = 0; r < 32; ++r) {
+      if constexpr (NW == 4) {
+        s += red[0][r][tid];
+        lt += red[0][r][64];
+      } else {
+        s += (red[0][r][tid] + red[1][r][tid]) + (red[2][r][tid] + red[3][r][tid]);
+        lt += (red[0][r][64] + red[1][r][64]) + (red[2][r][64] + red[3][r][64]);
+      }
+    }
     o[(int64_t)b * ldo + h * 64 + tid] = f2bf(lt > 0.f ? s / lt : 0.f);
   }
+}
+
+// waves per workgroup of the decode kernel: a function of the launch size only (same bits either way)
+int decode_attn_waves(int batch, int n_heads) {
+  static const int forced = [] { const char* e = getenv("MD_ATTN_DECODE_NW"); return e ? atoi(e) : 0; }();
+  if (forced == 4 || forced == 16) return forced;
+  return ((long)batch * n_heads <= 512) ? 16 : 4;
 }
 
 }  // namespace
@@ -769,10 +837,16 @@ extern "C" md_status md_attention_decode(const void* q, int64_t ldq, void* o, in
   MD_CHECK_ARG(q && o && k_slab && v_slab && kv_len);
   MD_CHECK_ARG(head_dim == 64 && ctx <= DEC_MAX_CTX && batch > 0 && n_heads % n_kv_heads == 0);
   MD_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && ldq >= n_heads * 64 && ldo >= n_heads * 64);
-  hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
-                     slab_batch_stride, ctx, kv_len, n_heads, n_heads / n_kv_heads,
-                     scale * 1.4426950408889634f, (const float*)nullptr, 0);
+  if (decode_attn_waves(batch, n_heads) == 16)
+    hipLaunchKernelGGL((attn_decode_kernel<false, 16>), dim3(n_heads, batch), dim3(1024), 0, (hipStream_t)stream,
+                       (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                       slab_batch_stride, ctx, kv_len, n_heads, n_heads / n_kv_heads,
+                       scale * 1.4426950408889634f, (const float*)nullptr, 0);
+  else
+    hipLaunchKernelGGL((attn_decode_kernel<false, 4>), dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                       slab_batch_stride, ctx, kv_len, n_heads, n_heads / n_kv_heads,
+                       scale * 1.4426950408889634f, (const float*)nullptr, 0);
   return md_launch_status();
 }
 
@@ -785,8 +859,13 @@ extern "C" md_status md_attention_decode_rope(const void* qkv, int64_t ld, void*
   MD_CHECK_ARG(head_dim == 64 && ctx <= DEC_MAX_CTX && batch > 0 && n_heads > 0);
   MD_CHECK_ARG(rot_dim % 2 == 0 && rot_dim > 0 && rot_dim <= 64 && ld % 8 == 0 && ldo % 8 == 0);
   MD_CHECK_ARG(ld >= 3 * n_heads * 64 && ldo >= n_heads * 64);
-  hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
-                     slab_batch_stride, ctx, kv_len, n_heads, 1, scale * 1.4426950408889634f, freqs, rot_dim);
+  if (decode_attn_waves(batch, n_heads) == 16)
+    hipLaunchKernelGGL((attn_decode_kernel<true, 16>), dim3(n_heads, batch), dim3(1024), 0, (hipStream_t)stream,
+                       (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                       slab_batch_stride, ctx, kv_len, n_heads, 1, scale * 1.4426950408889634f, freqs, rot_dim);
+  else
+    hipLaunchKernelGGL((attn_decode_kernel<true, 4>), dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                       slab_batch_stride, ctx, kv_len, n_heads, 1, scale * 1.4426950408889634f, freqs, rot_dim);
   return md_launch_status();
 }

@@ -330,16 +330,17 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
 }
 
 // greedy argmax, ties -> lowest index; optionally bumps pos[b]
-__global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t ld,
+__global__ __launch_bounds__(1024) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t ld,
                                                      int vocab, int suppress, int32_t* __restrict__ next,
                                                      int32_t* __restrict__ pos_inc) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
+  __shared__ float sv[16];
+  __shared__ int si[16];
   const int b = blockIdx.x;
   const bf16_t* lr = logits + (int64_t)b * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int ch = threadIdx.x; ch < (vocab >> 3); ch += 256) {
+  // 16 waves per row: the single-sequence decode step waits on this kernel's dependent-load chain
+  for (int ch = threadIdx.x; ch < (vocab >> 3); ch += 1024) {
     const u32x4 q = *(const u32x4*)(lr + ch * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
         best = sv[w];
         bi = si[w];
@@ -553,7 +554,7 @@ extern "C" md_status md_embed_tokens(const int32_t* ids, const void* table, int6
 // internal (api.hip): argmax that also advances pos
 md_status md_argmax_advance(const void* logits, int64_t ld, int32_t batch, int32_t vocab,
                             int32_t suppress_id, int32_t* next, int32_t* pos, hipStream_t stream) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(batch), dim3(256), 0, stream, (const bf16_t*)logits, ld, vocab,
+  hipLaunchKernelGGL(argmax_kernel, dim3(batch), dim3(1024), 0, stream, (const bf16_t*)logits, ld, vocab,
                      suppress_id, next, pos);
   return md_launch_status();
 }

@@ -457,6 +457,41 @@ def test_decode_attention_with_fused_rope_equals_two_kernels(lib):
     assert torch.equal(qb, qkv)  # the fused kernel leaves the activation untouched
 
 
+def test_decode_attention_launch_shapes_agree_bitwise(lib):
+    """The decode kernel runs 16 waves per (sequence, head) for small launches and 4 for large ones; the class-
+    partitioned accumulation order makes both the same function: a sequence's output row is bit-identical
+    whether it is decoded alone or inside a large batch (fused-rope form too)."""
+    h, hd, ctx, rot = 4, 64, 2048, 32
+    small, big = 5, 160  # 20 and 640 (sequence, head) pairs: either side of the launch-shape switch
+    lens_small = torch.tensor([736, 1, 2048, 129, 915], dtype=torch.int32, device="cuda")
+    reps = big // small
+    qkv = randn(small, 3 * h * hd, seed=70)
+    k, v = randn(small, h, ctx, hd, seed=71), randn(small, h, ctx, hd, seed=72)
+    freqs = rope_table(rot, ctx).cuda()
+
+    def run(n_rep, fused):
+        q_, k_, v_ = qkv.repeat(n_rep, 1), k.repeat(n_rep, 1, 1, 1), v.repeat(n_rep, 1, 1, 1)
+        lens = lens_small.repeat(n_rep)
+        o = torch.zeros(small * n_rep, h * hd, dtype=BF16, device="cuda")
+        if fused:
+            _lib.check(lib.md_attention_decode_rope(q_.data_ptr(), q_.stride(0), o.data_ptr(), h * hd, freqs.data_ptr(),
+                                                    k_.data_ptr(), v_.data_ptr(), h * ctx * hd, ctx, lens.data_ptr(),
+                                                    small * n_rep, h, hd, rot, 0.125, stream()))
+        else:
+            _lib.check(lib.md_attention_decode(q_.data_ptr(), q_.stride(0), o.data_ptr(), h * hd, k_.data_ptr(), v_.data_ptr(),
+                                               h * ctx * hd, ctx, lens.data_ptr(), small * n_rep, h, h, hd, 0.125, stream()))
+        torch.cuda.synchronize()
+        return o, k_, v_
+
+    for fused in (False, True):
+        o1, k1, v1 = run(1, fused)
+        o2, k2, v2 = run(reps, fused)
+        assert torch.isfinite(o1.float()).all()
+        for r in range(reps):
+            assert torch.equal(o2[r * small:(r + 1) * small], o1), (fused, r)
+        assert torch.equal(k2[:small], k1) and torch.equal(v2[:small], v1)
+
+
 def test_rope_kv_write(lib):
     from oracle.moondream_oracle import apply_rope, rope_table as o_rope_table
 

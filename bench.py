@@ -366,7 +366,10 @@ def main():
                         f"(2 crops each, both encoded), {len(prompt)}-token prompt, {T} greedy decode tokens, "
                         f"seeded synthetic weights",
             "batch_per_gpu": B, "decode_tokens": T, "parallelism": f"dp{world}",
-            "step_overlap": "none" if args.no_pipeline else "decode(step i) || encode(step i+1) on two HIP streams",
+            # two HIP streams; their kernels do not run concurrently on the GPU (profiles/r01_overlap_probe.txt): what
+            # is hidden is the host's tiling / launch / D2H time of step i+1 behind the decode kernels of step i
+            "host_latency_hiding": "none" if args.no_pipeline else "step i+1's host tiling + encode launches are issued on a second "
+                                   "HIP stream while step i decodes (no GPU-side overlap: the GPU is saturated)",
         },
         "roofline": {
             "bound": "mfma",

@@ -690,12 +690,17 @@ int decode_slices(int n_store, int k_pad) {
 
 // Tile choice: every CU works through ceil(tiles / 256) tiles, a tile costs its area
 // over the config's measured efficiency (256x256 alternating schedule = 1; 256x128
-// ~0.78; 128x128 ~0.62 -- profiles/r01_gemm_alternating_sweep*.txt).  A function of
-// (M, N) only, so a given layer always runs the same kernel -- and every config
+// ~0.78; 128x128 ~0.62 -- profiles/r01_gemm_alternating_sweep*.txt).  A function of the shape
+// (M, N, K) only, so a given layer always runs the same kernel -- and every config
 // accumulates K in the same order (sequential 16-wide MFMA steps), so results do
 // not depend on it.
-int pick_tile(int M, int n_store) {
+int pick_tile(int M, int n_store, int K) {
   if (knobs().tile >= 0) return knobs().tile;  // experiments / tests: force a tile config
+  // single-image regime: a layer that makes at most 128 tiles of 128 x 128 leaves half the chip idle and
+  // runs at the latency of its K loop -- the 64 x 64 tiles with the 4-deep ring and DMA helper waves
+  // (the decode-regime config) quadruple the workgroups and hide the load latency
+  // (tools/sweep_gemm_b1.py: text fc2 at 730 rows 81 -> 61 us, ViT fc2 50 -> 30 us)
+  if (M > 64 && K >= 1024 && (long)((M + 127) / 128) * ((n_store + 127) / 128) <= 128) return 16;
   const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 128};
   const double eff[3] = {1.0, 0.70, 0.55};
   int best = 2;
@@ -747,7 +752,7 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.partial_ld = k.partial_slice_stride = 0;
   k.nt = knobs().nt;  // decode regime: non-temporal weight stream (kernel-level +2..10 %, nothing end to end)
   hipStream_t s = (hipStream_t)stream;
-  int tile = pick_tile(k.M, k.n_store);
+  int tile = pick_tile(k.M, k.n_store, k.K);
   k.slices = 1;
   k.slabs = nullptr;
   k.tickets = nullptr;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 1
+#define MD_ABI_VERSION 2 /* 2: md_text_model.fp8 (trailing, optional) */
 
 typedef int md_status;
 enum {
@@ -132,6 +132,29 @@ md_status md_reduce_residual_layernorm(void* x, int64_t ldx, const float* partia
                                        const void* bias_b, int64_t ld_partial, int64_t slice_stride,
                                        void* y, int64_t ldy, const md_layernorm* ln, int32_t rows,
                                        int32_t dim, float eps, void* stream);
+
+/* ---- FP8 weights for the decode regime (opt-in numerical mode; BASELINE configs[4]) -------------------------------
+ * w: OCP e4m3fn bytes in MFMA-fragment order: block (nb, kb) of 32 channels x 32 features is 1 KiB at
+ * ((nb * k_pad / 32 + kb) * 1024); inside it lane l (0..63) owns 16 bytes: channel 32 nb + (l & 31), bytes 0..7 =
+ * features 32 kb + 8 (l >> 5) + j, bytes 8..15 = features 32 kb + 16 + 8 (l >> 5) + j.  scale: fp32 [n_pad],
+ * weight[n][k] ~= scale[n] * fp8[n][k].  b: bf16 [n_pad] or NULL.  n_pad % 64 == 0, k_pad % 128 == 0, zero padded.
+ * The same op as md_gemm_bf16 at m <= 64 (F.linear of text.py:30,53, layers.py:130,139, text.py:166 at q_len 1):
+ * bf16 activations, exact fp8 -> bf16 products, fp32 accumulation, epilogue(scale * acc + bias) with the bf16
+ * kernels' rounding points.  MD_EPI_BIAS / MD_EPI_GELU (GELU on columns >= gelu_from_col). */
+typedef struct {
+  const void* w;
+  const float* scale;
+  const void* b;
+  int32_t n, k, n_pad, k_pad;
+} md_linear_fp8;
+md_status md_gemm_fp8w(const void* a, int64_t lda, const md_linear_fp8* lin, void* c, int64_t ldc, int32_t m,
+                       int32_t epilogue, int32_t store_pad_cols, int32_t gelu_from_col, void* stream);
+/* K-slice partial products of two layers in one launch, the fp8 form of md_gemm_partial_f32_pair (already scaled,
+ * no bias); md_gemm_fp8w_partial_slices(lin) slices each. */
+int32_t md_gemm_fp8w_partial_slices(const md_linear_fp8* lin);
+md_status md_gemm_fp8w_partial_f32_pair(const void* a0, int64_t lda0, const md_linear_fp8* lin0, float* partial0,
+                                        const void* a1, int64_t lda1, const md_linear_fp8* lin1, float* partial1,
+                                        int32_t m, int64_t ld_partial, int64_t slice_stride, void* stream);
 
 /* Measurement / test hook, not needed by the product path: overrides one of the GEMM dispatch
  * knobs at run time (the same knobs are read once from MD_GEMM_* / MD_DECODE_* environment
@@ -349,6 +372,17 @@ typedef struct {
   md_linear qkv_fc1;
 } md_text_block;
 
+/* Optional FP8 copies of the decoder's weight stream: used by md_text_forward / md_lm_head / md_decode_step for
+ * launches of <= 64 rows (the decode regime) when md_text_model.fp8 is set; prefill always runs the bf16 weights.
+ * A member with w == NULL falls back to bf16 for that layer. */
+typedef struct {
+  md_linear_fp8 qkv_fc1, proj, fc2;
+} md_text_block_fp8;
+typedef struct {
+  const md_text_block_fp8* blocks; /* host array of n_layers */
+  md_linear_fp8 lm_head;
+} md_text_fp8;
+
 typedef struct {
   int32_t dim, n_heads, n_kv_heads, n_layers, ff_dim, vocab, max_context, prefix_len, rot_dim;
   const md_text_block* blocks; /* host array of n_layers */
@@ -356,6 +390,7 @@ typedef struct {
   md_linear lm_head;
   const void* wte;       /* bf16 [vocab][dim] */
   const float* freqs;    /* fp32 [max_context][rot_dim/2][2] */
+  const md_text_fp8* fp8; /* NULL: bf16 weights everywhere (the reference's precision) */
 } md_text_model;
 
 /* KV slabs: layer l's keys at k + l*layer_stride, element (b,h,p,d) at

@@ -16,9 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
+ABI_VERSION = 2  # include/moondream_hip.h MD_ABI_VERSION
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
 MD_CROPS_U8_HWC, MD_CROPS_BF16_CHW = 0, 1
 
@@ -73,12 +74,25 @@ class MdTextBlock(C.Structure):
                 ("qkv_fc1", MdLinear)]
 
 
+class MdLinearFp8(C.Structure):
+    _fields_ = [("w", c_void_p), ("scale", c_void_p), ("b", c_void_p), ("n", c_int32), ("k", c_int32),
+                ("n_pad", c_int32), ("k_pad", c_int32)]
+
+
+class MdTextBlockFp8(C.Structure):
+    _fields_ = [("qkv_fc1", MdLinearFp8), ("proj", MdLinearFp8), ("fc2", MdLinearFp8)]
+
+
+class MdTextFp8(C.Structure):
+    _fields_ = [("blocks", C.POINTER(MdTextBlockFp8)), ("lm_head", MdLinearFp8)]
+
+
 class MdTextModel(C.Structure):
     _fields_ = [
         ("dim", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("n_layers", c_int32),
         ("ff_dim", c_int32), ("vocab", c_int32), ("max_context", c_int32), ("prefix_len", c_int32),
         ("rot_dim", c_int32), ("blocks", C.POINTER(MdTextBlock)), ("post_ln", MdLayerNorm),
-        ("lm_head", MdLinear), ("wte", c_void_p), ("freqs", c_void_p),
+        ("lm_head", MdLinear), ("wte", c_void_p), ("freqs", c_void_p), ("fp8", C.POINTER(MdTextFp8)),
     ]
 
 
@@ -107,6 +121,10 @@ SIGNATURES = {
                                            c_int32, c_int64, c_int64, c_void_p]),
     "md_reduce_residual_layernorm": (C.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                                c_int64, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_float, c_void_p]),
+    "md_gemm_fp8w": (C.c_int, [c_void_p, c_int64, P(MdLinearFp8), c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "md_gemm_fp8w_partial_slices": (c_int32, [P(MdLinearFp8)]),
+    "md_gemm_fp8w_partial_f32_pair": (C.c_int, [c_void_p, c_int64, P(MdLinearFp8), c_void_p, c_void_p, c_int64, P(MdLinearFp8),
+                                                c_void_p, c_int32, c_int64, c_int64, c_void_p]),
     "md_gemm_set_tuning": (C.c_int, [C.c_char_p, c_int32]),
     "md_profile_gemm": (None, [c_int32]),
     "md_profile_gemm_read": (C.c_int, [c_int32, P(C.c_double), P(C.c_double), P(c_int64)]),
@@ -251,7 +269,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
         fn.restype = res
         fn.argtypes = args
-    if lib.md_abi_version() != 1:
+    if lib.md_abi_version() != ABI_VERSION:
         raise MoondreamHipError("libmoondream_hip.so ABI version mismatch")
     _LIB = lib
     return lib

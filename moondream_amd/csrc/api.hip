@@ -31,12 +31,6 @@ struct Arena {
   }
 };
 
-#define MD_TRY(expr)               \
-  do {                             \
-    md_status _s = (expr);         \
-    if (_s != MD_OK) return _s;    \
-  } while (0)
-
 md_status gemm(const void* a, int64_t lda, const md_linear& lin, void* c, int64_t ldc, int m, int epi,
                const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s,
                void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
@@ -337,7 +331,12 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     const bool fused = b.qkv_fc1.w != nullptr;
     const int64_t qld = fused ? b.qkv_fc1.n_pad : qkv_w;  // leading dimension of the qkv activation
     const int64_t ffld = fused ? b.qkv_fc1.n_pad : b.fc1.n_pad;
-    if (fused) {
+    // decode regime with FP8 weight copies attached (opt-in): the same three launches over half the bytes
+    const md_text_block_fp8* f8 = (m->fp8 && m->fp8->blocks && tail_fused && fused) ? &m->fp8->blocks[l] : nullptr;
+    if (f8 && f8->qkv_fc1.w) {
+      MD_CHECK_ARG(f8->qkv_fc1.n_pad == b.qkv_fc1.n_pad && qkv_w % 64 == 0);
+      MD_TRY(md_gemm_fp8w(w.h, Dp, &f8->qkv_fc1, w.qkv, qld, M, MD_EPI_GELU, 1, qkv_w, s));
+    } else if (fused) {
       // one GEMM for both consumers of l_in: [qkv | gelu(fc1)]   (text.py:30 and layers.py:130-138)
       MD_CHECK_ARG(b.qkv_fc1.n_pad == qkv_w + b.fc1.n_pad && qkv_w % 64 == 0);
       md_gemm_args g;
@@ -393,11 +392,21 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     if (tail_fused) {
       // decode regime: both linears leave fp32 K-slice partials; ONE tail kernel sums them, applies
       // bias / residual with the same roundings and writes the next block's ln(x)
-      MD_TRY(md_gemm_partial_f32_pair(w.att, Dp, &b.proj, w.part_a, w.ff, ffld, &b.fc2, w.part_b, M, w.part_ld,
-                                      w.part_stride, s));
+      const bool f8_tail = f8 && f8->proj.w && f8->fc2.w;
+      int sl_a = md_gemm_partial_slices(&b.proj), sl_b = md_gemm_partial_slices(&b.fc2);
+      if (f8_tail) {
+        MD_CHECK_ARG(md_gemm_fp8w_partial_slices(&f8->proj) <= sl_a && md_gemm_fp8w_partial_slices(&f8->fc2) <= sl_b);  // workspace is sized for the bf16 split
+        sl_a = md_gemm_fp8w_partial_slices(&f8->proj);
+        sl_b = md_gemm_fp8w_partial_slices(&f8->fc2);
+        MD_TRY(md_gemm_fp8w_partial_f32_pair(w.att, Dp, &f8->proj, w.part_a, w.ff, ffld, &f8->fc2, w.part_b, M, w.part_ld,
+                                             w.part_stride, s));
+      } else {
+        MD_TRY(md_gemm_partial_f32_pair(w.att, Dp, &b.proj, w.part_a, w.ff, ffld, &b.fc2, w.part_b, M, w.part_ld,
+                                        w.part_stride, s));
+      }
       const bool last = (l + 1 == m->n_layers);
-      MD_TRY(md_reduce_residual_layernorm(x, D, w.part_a, md_gemm_partial_slices(&b.proj), b.proj.b, w.part_b,
-                                          md_gemm_partial_slices(&b.fc2), b.fc2.b, w.part_ld, w.part_stride,
+      MD_TRY(md_reduce_residual_layernorm(x, D, w.part_a, sl_a, b.proj.b, w.part_b,
+                                          sl_b, b.fc2.b, w.part_ld, w.part_stride,
                                           last ? nullptr : w.h, Dp, last ? nullptr : &m->blocks[l + 1].ln, M, D,
                                           1e-5f, s));
     } else {
@@ -517,6 +526,8 @@ extern "C" md_status md_lm_head(const md_text_model* m, const void* hidden, int3
   const int Dp = m->lm_head.k_pad;
   MD_TRY(zero_if_padded(workspace, batch, Dp, D, s));
   MD_TRY(md_layernorm_bf16(last, (int64_t)q_len * D, workspace, Dp, &m->post_ln, batch, D, 1e-5f, s));
+  if (m->fp8 && m->fp8->lm_head.w && batch <= 64)
+    return md_gemm_fp8w(workspace, Dp, &m->fp8->lm_head, logits, ld_logits, batch, MD_EPI_BIAS, 0, 0, s);
   return gemm(workspace, Dp, m->lm_head, logits, ld_logits, batch, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
 }
 

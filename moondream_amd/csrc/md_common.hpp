@@ -89,6 +89,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     if (!(cond)) return MD_ERR_INVALID_ARG; \
   } while (0)
 
+#define MD_TRY(expr)               \
+  do {                             \
+    md_status _s = (expr);         \
+    if (_s != MD_OK) return _s;    \
+  } while (0)
+
 static inline md_status md_launch_status() {
   return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_LAUNCH;
 }

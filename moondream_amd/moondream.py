@@ -201,6 +201,17 @@ class MoondreamModel:
             self._variants[vid] = PackedLora(self.config, variant_state_dict(vid, device="cpu"), self._device)
         return self._variants[vid]
 
+    def enable_fp8_decode(self, on: bool = True):
+        """Opt-in numerical mode (BASELINE configs[4]): decode steps (launches of <= 64 rows) stream FP8 e4m3fn copies
+        of the decoder weights -- half the bytes of the bandwidth-bound decode step -- with bf16 activations and fp32
+        accumulation; prefill, the vision path and the KV cache stay bf16.  Outputs are judged by tolerance against
+        the bf16 path (tests/test_model_gpu.py), not bit parity; off by default."""
+        if on:
+            self.w.enable_fp8_decode()
+        else:
+            self.w.disable_fp8_decode()
+        self._graphs.clear()  # captured decode steps baked the other launches in
+
     def compile(self):
         """The reference rebinds the seam to torch.compile'd functions here
         (moondream.py:194-204).  The seam is already native; ``compile`` turns on

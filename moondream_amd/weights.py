@@ -92,6 +92,37 @@ class FusedLinear:
                              self.nb_pad, self.k_pad)
 
 
+FP8_MAX = 448.0  # largest finite OCP e4m3fn value
+
+
+class PackedLinearFp8:
+    """An already packed bf16 linear (``w`` [n_pad][k_pad], zero padded; ``b`` bf16 [n_pad] or None) quantised
+    to OCP e4m3fn with one fp32 scale per output channel (max |w| -> 448) and laid out in the MFMA-fragment
+    order md_linear_fp8 documents (include/moondream_hip.h): an opt-in copy for the decode regime's weight
+    stream; the bf16 original stays in place for every other launch."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], n: int, k: int):
+        assert w.dim() == 2 and w.shape[0] % 64 == 0
+        self.n, self.k, self.n_pad = n, k, w.shape[0]
+        self.k_pad = _round_up(w.shape[1], 128)
+        wf = torch.zeros(self.n_pad, self.k_pad, dtype=torch.float32, device=w.device)
+        wf[:, : w.shape[1]] = w.float()
+        amax = wf.abs().amax(dim=1)
+        self.scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax)).contiguous()
+        q = (wf / self.scale[:, None]).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+        self.q = q  # row-major [n_pad][k_pad]: what the layer computes with is  q.float() * scale[:, None]
+        frag = q.view(torch.uint8).view(self.n_pad // 32, 32, self.k_pad // 32, 2, 2, 8)
+        self.w = frag.permute(0, 2, 4, 1, 3, 5).contiguous()  # [nb][kb][hi][row][step][j]
+        self.b = b
+
+    def dequantized(self) -> torch.Tensor:
+        return self.q.float() * self.scale[:, None]
+
+    def struct(self) -> _lib.MdLinearFp8:
+        return _lib.MdLinearFp8(self.w.data_ptr(), self.scale.data_ptr(), self.b.data_ptr() if self.b is not None else None,
+                                self.n, self.k, self.n_pad, self.k_pad)
+
+
 class PackedLayerNorm:
     def __init__(self, w: torch.Tensor, b: torch.Tensor, device):
         self.w = w.to(device=device, dtype=BF16).contiguous()
@@ -288,6 +319,7 @@ class PackedModel:
 
         # ---------------- text
         self.text_blocks = (_lib.MdTextBlock * t.n_layers)()
+        self._text_packed: List[dict] = []  # per block: the packed bf16 linears, for enable_fp8_decode
         for i in range(t.n_layers):
             p = f"text.blocks.{i}"
             blk = self.text_blocks[i]
@@ -299,10 +331,12 @@ class PackedModel:
                 self._keep.append(fused)
                 blk.qkv, blk.fc1, blk.qkv_fc1 = fused.struct_a(), fused.struct_b(), fused.struct()
             else:
+                fused = None
                 blk.qkv = lin(p + ".attn.qkv").struct()
                 blk.fc1 = lin(p + ".mlp.fc1").struct()
-            blk.proj = lin(p + ".attn.proj").struct()
-            blk.fc2 = lin(p + ".mlp.fc2").struct()
+            proj, fc2 = lin(p + ".attn.proj"), lin(p + ".mlp.fc2")
+            blk.proj, blk.fc2 = proj.struct(), fc2.struct()
+            self._text_packed.append({"qkv_fc1": fused, "proj": proj, "fc2": fc2})
         self.text_post_ln = ln("text.post_ln")
         self.lm_head = lin("text.lm_head")
         self.wte = sd["text.wte"].to(device=dev, dtype=BF16).contiguous()
@@ -326,6 +360,38 @@ class PackedModel:
                 "coord_features": sd["region.coord_features"].to(device=dev, dtype=BF16).contiguous(),
                 "size_features": sd["region.size_features"].to(device=dev, dtype=BF16).contiguous(),
             }
+
+    def enable_fp8_decode(self) -> None:
+        """Attach FP8 (e4m3fn, per-channel scale) copies of the decoder's weight stream -- fused qkv|fc1, proj,
+        fc2 of every block and lm_head -- to md_text_model.fp8: launches of <= 64 rows (decode steps) then read half
+        the weight bytes; prefill keeps the bf16 weights.  An opt-in numerical mode (BASELINE configs[4]); the
+        default path stays at the reference's precision.  Call before capturing hipGraphs."""
+        if getattr(self, "_fp8", None) is not None:
+            return
+        t = self.config.text
+        keep: List[PackedLinearFp8] = []
+
+        def q8(p, n, k):
+            f = PackedLinearFp8(p.w, p.b, n, k)
+            keep.append(f)
+            return f.struct()
+
+        blocks = (_lib.MdTextBlockFp8 * t.n_layers)()
+        for i, pk in enumerate(self._text_packed):
+            if pk["qkv_fc1"] is None:
+                raise ValueError("fp8 decode needs the fused qkv|fc1 packing (qkv_dim % 64 == 0)")
+            blocks[i].qkv_fc1 = q8(pk["qkv_fc1"], pk["qkv_fc1"].n, pk["qkv_fc1"].k)
+            blocks[i].proj = q8(pk["proj"], pk["proj"].n, pk["proj"].k)
+            blocks[i].fc2 = q8(pk["fc2"], pk["fc2"].n, pk["fc2"].k)
+        head = q8(self.lm_head, self.lm_head.n, self.lm_head.k)
+        self._fp8_blocks = blocks
+        self._fp8 = _lib.MdTextFp8(C.cast(blocks, C.POINTER(_lib.MdTextBlockFp8)), head)
+        self._fp8_keep = keep
+        self.text.fp8 = C.pointer(self._fp8)
+
+    def disable_fp8_decode(self) -> None:
+        self.text.fp8 = C.POINTER(_lib.MdTextFp8)()
+        self._fp8 = None
 
     def param_bytes(self) -> int:
         total = 0

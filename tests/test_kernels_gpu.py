@@ -243,6 +243,77 @@ def test_gemm_decode_regime(lib, m, k, n, epi):
     compare(f"skinny(no scratch) m{m} {k}x{n}", c1, ref, 3e-3, 2e-2)
 
 
+@pytest.mark.parametrize("m", [1, 7, 32, 33, 64])
+@pytest.mark.parametrize("k,n,epi,gelu_from", [(2048, 6144 + 8192, 1, 6144), (2048, 51200, 0, 0), (704, 256, 0, 0), (256, 1024, 1, 0)])
+def test_gemm_fp8_weights_decode_regime(lib, m, k, n, epi, gelu_from):
+    """md_gemm_fp8w: exact products of bf16 activations with the e4m3 weights (the quantisation is the only
+    approximation), so it is compared tightly with a torch evaluation over the DEQUANTISED weights; rows do
+    not depend on how many rows are in flight; the quantisation error itself is reported against the bf16 layer."""
+    from moondream_amd.weights import PackedLinearFp8
+
+    a, w, b = randn(m, k, seed=80), randn(n, k, scale=1 / math.sqrt(k), seed=81), randn(n, scale=0.1, seed=82)
+    lin = PackedLinear(w, b, "cuda")
+    q = PackedLinearFp8(lin.w, lin.b, n, k)
+    assert q.k_pad % 128 == 0 and q.w.numel() == q.n_pad * q.k_pad
+    A = pad_k(a, lin.k_pad)
+
+    def run(rows):
+        c = torch.full((rows, q.n_pad), float("nan"), dtype=BF16, device="cuda")
+        st = q.struct()
+        _lib.check(lib.md_gemm_fp8w(A.data_ptr(), A.stride(0), C.byref(st), c.data_ptr(), c.stride(0), rows, epi, 1, gelu_from, stream()))
+        torch.cuda.synchronize()
+        return c
+
+    c = run(m)
+    deq = q.dequantized()[:n, :k]
+    ref = (a.float() @ deq.t() + b.float()).to(BF16)
+    if epi == 1:
+        g = torch.nn.functional.gelu(ref.float(), approximate="tanh").to(BF16)
+        ref = torch.cat([ref[:, :gelu_from], g[:, gelu_from:]], 1)
+    compare(f"fp8w m{m} {k}x{n} epi{epi}", c[:, :n], ref, 3e-3, 2e-2)
+    assert float(c[:, n:].float().abs().max() if q.n_pad > n else 0.0) == 0.0  # pad columns: zero weights, zero bias
+    if m > 1:
+        assert torch.equal(run(1), c[:1])
+    # what the quantisation costs against the bf16 layer (per-channel scale, 3 mantissa bits): a few per cent
+    full = ref_linear(a, w, b)
+    if epi == 1:
+        gfull = torch.nn.functional.gelu(full.float(), approximate="tanh").to(BF16)
+        full = torch.cat([full[:, :gelu_from], gfull[:, gelu_from:]], 1)
+    compare(f"fp8w vs bf16 layer m{m} {k}x{n}", c[:, :n], full, 6e-2)
+
+
+@pytest.mark.parametrize("m,dim,ka,kb", [(64, 2048, 2048, 8192), (5, 1024, 1024, 4096), (33, 256, 256, 704)])
+def test_fp8_partial_pair_feeds_the_block_tail(lib, m, dim, ka, kb):
+    """md_gemm_fp8w_partial_f32_pair: scaled K-slice partials whose sum is the fp32 product with the dequantised
+    weights; md_reduce_residual_layernorm consumes them unchanged; row-subset invariant."""
+    from moondream_amd.weights import PackedLinearFp8
+
+    a1, w1, b1 = randn(m, ka, seed=90), randn(dim, ka, scale=1 / math.sqrt(ka), seed=91), randn(dim, scale=0.1, seed=92)
+    a2, w2, b2 = randn(m, kb, seed=93), randn(dim, kb, scale=1 / math.sqrt(kb), seed=94), randn(dim, scale=0.1, seed=95)
+    la, lb = PackedLinear(w1, b1, "cuda"), PackedLinear(w2, b2, "cuda")
+    qa, qb = PackedLinearFp8(la.w, la.b, dim, ka), PackedLinearFp8(lb.w, lb.b, dim, kb)
+    sa, sb = qa.struct(), qb.struct()
+    na, nb = lib.md_gemm_fp8w_partial_slices(C.byref(sa)), lib.md_gemm_fp8w_partial_slices(C.byref(sb))
+    assert 1 <= na <= 8 and 1 <= nb <= 8
+
+    def run(rows):
+        pa = torch.full((na, rows, dim), float("nan"), dtype=torch.float32, device="cuda")
+        pb = torch.full((nb, rows, dim), float("nan"), dtype=torch.float32, device="cuda")
+        A1, A2 = pad_k(a1[:rows], la.k_pad), pad_k(a2[:rows], lb.k_pad)
+        _lib.check(lib.md_gemm_fp8w_partial_f32_pair(A1.data_ptr(), A1.stride(0), C.byref(sa), pa.data_ptr(), A2.data_ptr(), A2.stride(0),
+                                                     C.byref(sb), pb.data_ptr(), rows, dim, rows * dim, stream()))
+        torch.cuda.synchronize()
+        return pa, pb
+
+    pa, pb = run(m)
+    assert torch.isfinite(pa).all() and torch.isfinite(pb).all()
+    compare("fp8 partials a", pa.sum(0).to(BF16), (a1.float() @ qa.dequantized()[:dim, :ka].t()).to(BF16), 3e-3, 2e-2)
+    compare("fp8 partials b", pb.sum(0).to(BF16), (a2.float() @ qb.dequantized()[:dim, :kb].t()).to(BF16), 3e-3, 2e-2)
+    if m > 1:
+        p1a, p1b = run(1)
+        assert torch.equal(p1a, pa[:, :1]) and torch.equal(p1b, pb[:, :1])
+
+
 @pytest.mark.parametrize("m,dim,ka,kb", [(64, 2048, 2048, 8192), (5, 1024, 1024, 4096), (1, 144, 144, 576), (33, 256, 256, 704)])
 def test_block_tail_partials_then_reduce_residual_layernorm(lib, m, dim, ka, kb):
     """Decode-regime block tail: md_gemm_partial_f32 x 2 + md_reduce_residual_layernorm against the

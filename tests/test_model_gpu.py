@@ -496,6 +496,57 @@ def test_hf_wrapper_answer_question_and_batch_answer(tiny):
         hf._unsupported_exception()
 
 
+def fp8_decode_report(model, images, prompts, ids_bf16, ref_margins, label):
+    """Run the same generation with FP8 decode weights; the first decode step's logits (identical image prefix in the
+    KV cache, identical input token) must stay within tolerance of the bf16 logits, and token streams may only leave the bf16 stream at
+    a decision whose reference margin is small against the measured logit error."""
+    n_tok = len(ids_bf16[0])
+    enc = model.encode_image(images[0])
+    model.load_encoded_image(enc)
+    logits_b, _, pos = model._prefill_prompts([prompts[0]], enc.pos, 0)
+    emb = model._embed(torch.tensor([[int(ids_bf16[0][0])]]))
+    step_b, _ = model._decode_one_tok(emb, None, torch.tensor([pos], dtype=torch.long), None)
+    model.enable_fp8_decode(True)
+    try:
+        model.load_encoded_image(enc)
+        _, _, pos8 = model._prefill_prompts([prompts[0]], enc.pos, 0)  # <= 64 rows: this launch streams the fp8 weights too
+        step_8, _ = model._decode_one_tok(emb, None, torch.tensor([pos8], dtype=torch.long), None)
+        ids_fp8 = model.batch_generate_ids(images, prompts, max_tokens=n_tok, ignore_eos=True)
+    finally:
+        model.enable_fp8_decode(False)
+    again = model.batch_generate_ids(images[:2], prompts[:2], max_tokens=n_tok, ignore_eos=True)
+    assert again == [list(x) for x in ids_bf16[:2]]  # switching the mode off restores the bf16 path exactly
+    lb, l8 = step_b[0].float().cpu(), step_8[0].float().cpu()
+    err = float((l8 - lb).abs().max())
+    rel = float((l8 - lb).pow(2).mean().sqrt() / lb.pow(2).mean().sqrt())
+    same = sum(list(a) == list(b) for a, b in zip(ids_fp8, ids_bf16))
+    prefix = []
+    worst_margin = 0.0
+    for si, (a, b) in enumerate(zip(ids_fp8, ids_bf16)):
+        k = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(b))
+        prefix.append(k)
+        if k < len(b) and ref_margins is not None:
+            worst_margin = max(worst_margin, float(ref_margins[si][k]))
+    print(f"fp8 decode [{label}]: first-step logits rel-RMS {rel:.4f}, max abs err {err:.3f}; {same}/{len(ids_bf16)} sequences "
+          f"identical to bf16, mean matching prefix {sum(prefix) / len(prefix):.1f}/{n_tok} tokens, largest reference margin at a "
+          f"first divergence {worst_margin:.3f}")
+    assert all(0 <= t < model.config.text.vocab_size for seq in ids_fp8 for t in seq)
+    assert rel <= 0.12, rel
+    if ref_margins is not None:
+        # a stream may leave the bf16 stream only where the decision was closer than a few times the logit error
+        assert worst_margin <= max(4.0 * err, 1.0), (worst_margin, err)
+
+
+def test_fp8_decode_mode_tiny(tiny):
+    g, cfg, sd, model = tiny
+    n_img = len(g["image_index"])
+    images = [golden_image(g, i) for i in range(n_img)]
+    prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(n_img)]
+    n = len(g["img0.cap.tokens"])
+    ids = model.batch_generate_ids(images, prompts, max_tokens=n, ignore_eos=True)
+    fp8_decode_report(model, images, prompts, ids, None, "tiny")
+
+
 @pytest.mark.parametrize("name,cfg_name", [("md05b_seed1.npz", "0.5b"), ("md2b_seed1.npz", "2b")])
 def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     """BASELINE.json configs at full size: greedy ids bit-exact against the
@@ -557,3 +608,6 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
         for i in g["image_index"].tolist():  # the wide-margin images of md2b_seed1 are among the 64: exact
             assert got64[i] == gb["tokens"][i].tolist(), i
         assert exact >= 4  # most of the 64 have at least one decision inside bf16 noise (margins recorded in the fixture)
+    # opt-in FP8 weight stream for the decode steps of the same configuration (BASELINE configs[4]): a different
+    # numerical mode, judged by tolerance against the bf16 path -- never by bit parity
+    fp8_decode_report(model, imgs64, [pr] * 64, got64, gb["margins"], "2b B=64")

@@ -134,3 +134,31 @@ def test_int4_checkpoint_is_dequantised_like_the_reference(tmp_path):
     zero = torch.rand(192, 1, generator=g) * 15
     ref = ns["dequantize_tensor"](packed, scale, zero, (48, 512))
     assert torch.equal(ref, dequantize_int4(packed, scale, zero, 48))
+
+
+def test_fp8_fragment_layout_and_scales():
+    """PackedLinearFp8: per-channel scale maps max |w| to 448, the fragment-ordered bytes are the row-major e4m3
+    bytes permuted as include/moondream_hip.h documents (md_linear_fp8), padding is zero."""
+    from moondream_amd.weights import PackedLinear, PackedLinearFp8
+
+    g = torch.Generator().manual_seed(3)
+    n, k = 96, 200
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16)
+    w[5] = 0  # an all-zero channel keeps scale 1
+    lin = PackedLinear(w, torch.zeros(n), "cpu")
+    q = PackedLinearFp8(lin.w, lin.b, n, k)
+    assert (q.n_pad, q.k_pad) == (128, 256) and q.scale.shape == (128,)
+    amax = lin.w.float().abs().amax(1)
+    assert torch.allclose(q.scale[amax > 0], amax[amax > 0] / 448.0) and float(q.scale[5]) == 1.0
+    rows = q.q.view(torch.uint8)
+    frag = q.w.reshape(-1)
+    for (ch, feat) in [(0, 0), (31, 7), (32, 8), (77, 199), (95, 31), (64, 48), (127, 255), (3, 130)]:
+        nb, r, kb, rem = ch // 32, ch % 32, feat // 32, feat % 32
+        step, hi, j = rem // 16, (rem % 16) // 8, rem % 8
+        lane = hi * 32 + r
+        off = ((nb * (q.k_pad // 32) + kb) * 64 + lane) * 16 + step * 8 + j
+        assert int(frag[off]) == int(rows[ch, feat]), (ch, feat)
+    assert int(rows[n:].max()) == 0 and int(rows[:, k:].max()) == 0
+    # quantisation error: half an e4m3 ulp relative to the channel maximum's binade
+    err = (q.dequantized()[:n, :k] - w.float()).abs()
+    assert float((err / amax[:n, None].clamp_min(1e-30)).max()) <= 2.0 ** -4 + 1e-6

@@ -622,14 +622,7 @@ md_status launch_cfg(const GemmK& k, hipStream_t stream) {
   constexpr int lds = (PP == 3) ? ring + epi : (ring > epi ? ring : epi);
   static_assert(lds <= 163840, "LDS budget");
   auto fn = gemm_bf16_kernel<BM, BN, WM, WN, EPI, SPLITK, STAGES, BKT, PP, XW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      (void)hipGetLastError();
-      return MD_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  MD_TRY(md_ensure_dynamic_lds((const void*)fn, lds));
   GemmK kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.n_store + BN - 1) / BN;
@@ -903,14 +896,7 @@ extern "C" md_status md_gemm_partial_f32_pair(const void* a0, int64_t lda0, cons
   const int NT = helpers ? 256 : 128;
   auto fn = helpers ? gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
                     : gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[helpers]) {
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      (void)hipGetLastError();
-      return MD_ERR_LAUNCH;
-    }
-    attr_set[helpers] = true;
-  }
+  MD_TRY(md_ensure_dynamic_lds((const void*)fn, lds));
   ProfScope prof;
   if (prof.begin(2.0 * ((double)lin0->n * lin0->k + (double)lin1->n * lin1->k), s) != MD_OK) return MD_ERR_LAUNCH;
   const int gx = std::max(pair.g[0].tiles_m * pair.g[0].tiles_n, pair.g[1].tiles_m * pair.g[1].tiles_n);

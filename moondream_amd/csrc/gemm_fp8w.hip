@@ -53,13 +53,16 @@ constexpr int A_STAGE = 64 * A_ROW;
 constexpr int NS = 3;
 constexpr int EPI_PARTIAL = 3;
 
-// 8 fp8 (two dwords) -> one bf16x8 MFMA operand
+// 8 fp8 (two dwords) -> one bf16x8 MFMA operand: v_cvt_scalef32_pk_bf16_fp8 converts a pair per instruction
+// (scale 1.0; e4m3 -> bf16 is exact)
+typedef __bf16 md_bf16pair __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t lo, uint32_t hi) {
-  const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false);
-  const auto b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-  const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false);
-  const auto d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
-  const u32x4 r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), pack_bf16x2(c[0], c[1]), pack_bf16x2(d[0], d[1])};
+  const md_bf16pair a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)lo, 1.0f, false);
+  const md_bf16pair b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)lo, 1.0f, true);
+  const md_bf16pair c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)hi, 1.0f, false);
+  const md_bf16pair d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)hi, 1.0f, true);
+  const u32x4 r = {__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c),
+                   __builtin_bit_cast(uint32_t, d)};
   return __builtin_bit_cast(bf16x8, r);
 }
 
@@ -113,12 +116,26 @@ __device__ __forceinline__ void fp8w_body(const Fp8K& p, char* smem) {
     constexpr int PFW = 8;
     const int rs = nsteps * (STEP_K * 2) + 16;  // row stride: rotates 4 banks per row
     const int ppr = nsteps * 16;               // 16-byte pieces per row
-    for (int q = tid; q < p.M * ppr; q += 256) {
-      const int r = q / ppr, pc = q - r * ppr;
-      const int k = step0 * STEP_K + pc * 8;
-      u32x4 v = zero4;
-      if (k < p.Ka) v = *(const u32x4*)(p.A + (int64_t)r * p.lda + k);
-      *(u32x4*)(smem + r * rs + pc * 16) = v;
+    // 8 independent loads per thread before the first store: one L2 round trip for up to 8 rows of K = 2048
+    const int total = p.M * ppr;
+    for (int q0 = tid; q0 < total; q0 += 256 * 8) {
+      u32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = min(q0 + 256 * u, total - 1);
+        const int r = q / ppr, pc = q - r * ppr;
+        const int k = step0 * STEP_K + pc * 8;
+        const u32x4 x = *(const u32x4*)(p.A + (int64_t)r * p.lda + (k < p.Ka ? k : 0));
+        v[u] = (k < p.Ka) ? x : zero4;  // columns past the activation's zero padding
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + 256 * u;
+        if (q < total) {
+          const int r = q / ppr, pc = q - r * ppr;
+          *(u32x4*)(smem + r * rs + pc * 16) = v[u];
+        }
+      }
     }
     u32x4 wreg[PFW][2];
 #pragma unroll
@@ -284,7 +301,7 @@ extern "C" int32_t md_gemm_fp8w_partial_slices(const md_linear_fp8* lin) {
   if (!lin || lin->n <= 0 || lin->k_pad <= 0) return 0;
   const int tiles = (lin->n + 63) / 64, steps = lin->k_pad / STEP_K;
   int s = 256 / std::max(1, tiles);
-  s = std::max(1, std::min(s, std::min(8, steps)));
+  s = std::max(1, std::min(s, std::min(8, steps / 8)));  // at least 8 steps (one prefetch window) per slice
   const int per = (steps + s - 1) / s;
   return (steps + per - 1) / per;
 }

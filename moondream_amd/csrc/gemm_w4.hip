@@ -445,14 +445,7 @@ int g_w4_variant = 0;  // measurement hook (md_gemm_set_tuning "w4_variant"): 16
 template <int EPI, int ABL = 0>
 md_status launch(const GemmK& k, hipStream_t stream) {
   auto fn = gemm_w4_kernel<EPI, ABL>;
-  static bool attr_set = false;  // per process: the library serves the process's current device
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      (void)hipGetLastError();
-      return MD_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  MD_TRY(md_ensure_dynamic_lds((const void*)fn, LDS_BYTES));
   GemmK kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.n_store + BN - 1) / BN;

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../../include/moondream_hip.h"
 
 typedef uint16_t bf16_t;  // raw bf16 bits everywhere; arithmetic is fp32
@@ -94,6 +97,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     md_status _s = (expr);         \
     if (_s != MD_OK) return _s;    \
   } while (0)
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute belongs to the function ON the
+// current device, so a process that drives several GPUs needs it on each of them.
+inline md_status md_ensure_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, uint64_t> done;  // kernel -> bit per device ordinal
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MD_ERR_LAUNCH;
+  const uint64_t bit = 1ull << (dev & 63);
+  std::lock_guard<std::mutex> g(mu);
+  uint64_t& bits = done[fn];
+  if (bits & bit) return MD_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return MD_ERR_LAUNCH;
+  }
+  bits |= bit;
+  return MD_OK;
+}
 
 static inline md_status md_launch_status() {
   return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_LAUNCH;

@@ -315,14 +315,7 @@ extern "C" md_status md_sample_top_p(const void* logits, int64_t ld, int32_t bat
   MD_CHECK_ARG(logits && uniforms && next && batch > 0 && vocab > 0 && ld >= vocab && temperature > 0.f);
   MD_CHECK_ARG(probs_out == nullptr || ld_probs >= vocab);
   constexpr int lds = HIST_BINS * 4 + 16 * 4 + SAMPLE_THREADS * 4 + 16 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)sample_top_p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      (void)hipGetLastError();
-      return MD_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  MD_TRY(md_ensure_dynamic_lds((const void*)sample_top_p_kernel, lds));
   hipLaunchKernelGGL(sample_top_p_kernel, dim3(batch), dim3(SAMPLE_THREADS), lds, (hipStream_t)stream, (const bf16_t*)logits, ld,
                      vocab, suppress_id, temperature, top_p, uniforms, next, (bf16_t*)probs_out, ld_probs);
   return md_launch_status();

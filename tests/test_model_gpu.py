@@ -501,6 +501,8 @@ def fp8_decode_report(model, images, prompts, ids_bf16, ref_margins, label):
     KV cache, identical input token) must stay within tolerance of the bf16 logits, and token streams may only leave the bf16 stream at
     a decision whose reference margin is small against the measured logit error."""
     n_tok = len(ids_bf16[0])
+    base = model.batch_generate_ids(images, prompts, max_tokens=n_tok, ignore_eos=True)
+    assert base == [list(x) for x in ids_bf16]
     enc = model.encode_image(images[0])
     model.load_encoded_image(enc)
     logits_b, _, pos = model._prefill_prompts([prompts[0]], enc.pos, 0)
@@ -514,8 +516,8 @@ def fp8_decode_report(model, images, prompts, ids_bf16, ref_margins, label):
         ids_fp8 = model.batch_generate_ids(images, prompts, max_tokens=n_tok, ignore_eos=True)
     finally:
         model.enable_fp8_decode(False)
-    again = model.batch_generate_ids(images[:2], prompts[:2], max_tokens=n_tok, ignore_eos=True)
-    assert again == [list(x) for x in ids_bf16[:2]]  # switching the mode off restores the bf16 path exactly
+    again = model.batch_generate_ids(images, prompts, max_tokens=n_tok, ignore_eos=True)
+    assert again == base  # switching the mode off restores the bf16 path exactly
     lb, l8 = step_b[0].float().cpu(), step_8[0].float().cpu()
     err = float((l8 - lb).abs().max())
     rel = float((l8 - lb).pow(2).mean().sqrt() / lb.pow(2).mean().sqrt())

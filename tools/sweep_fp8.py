@@ -20,17 +20,29 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def timeit(fn, iters=30, warm=5):
+def timeit(fn, iters=24, warm=3, reps=5):
+    """Microseconds per launch with the launches replayed from a hipGraph: a 10 us kernel launched through
+    ctypes from Python is otherwise timed at the host's issue rate, not the GPU's."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(iters):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(reps):
+        g.replay()
     e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters * 1e3
+    return s.elapsed_time(e) / (iters * reps) * 1e3
 
 
 # a ring of distinct weight copies larger than the 256 MB Infinity Cache, so every launch streams from HBM
@@ -65,3 +77,37 @@ for m in (1, 8, 64):
         print(f"m={m:2d} {label:8s} k={k} n={n}: bf16 {tb:6.1f}us ({n * k * 2 / tb / 1e6:5.2f} TB/s)  fp8 {t8:6.1f}us ({n * k / t8 / 1e6:5.2f} TB/s)  x{tb / t8:4.2f}", flush=True)
         del lins, q8
         torch.cuda.empty_cache()
+
+
+# the block tail's two K-sliced layers in one launch: proj (2048 -> 2048) + fc2 (8192 -> 2048)
+for m in (1, 8, 64):
+    dim = 2048
+    a1 = (torch.randn(m, 2048, device="cuda") * 0.5).to(BF16)
+    a2 = (torch.randn(m, 8192, device="cuda") * 0.5).to(BF16)
+    nring = 8
+    pj = [PackedLinear((torch.randn(dim, 2048, device="cuda") / 45).to(BF16), torch.zeros(dim, dtype=BF16), "cuda") for _ in range(nring)]
+    f2 = [PackedLinear((torch.randn(dim, 8192, device="cuda") / 90).to(BF16), torch.zeros(dim, dtype=BF16), "cuda") for _ in range(nring)]
+    pj8 = [PackedLinearFp8(l.w, l.b, dim, 2048) for l in pj]
+    f28 = [PackedLinearFp8(l.w, l.b, dim, 8192) for l in f2]
+    pa = torch.empty(8, m, dim, dtype=torch.float32, device="cuda")
+    pb = torch.empty(8, m, dim, dtype=torch.float32, device="cuda")
+    state = {"i": 0}
+
+    def run_bf16():
+        i = state["i"] % nring; state["i"] += 1
+        sa, sb = pj[i].struct(), f2[i].struct()
+        _lib.check(lib.md_gemm_partial_f32_pair(a1.data_ptr(), a1.stride(0), C.byref(sa), pa.data_ptr(), a2.data_ptr(), a2.stride(0),
+                                                C.byref(sb), pb.data_ptr(), m, dim, m * dim, stream()))
+
+    def run_fp8():
+        i = state["i"] % nring; state["i"] += 1
+        sa, sb = pj8[i].struct(), f28[i].struct()
+        _lib.check(lib.md_gemm_fp8w_partial_f32_pair(a1.data_ptr(), a1.stride(0), C.byref(sa), pa.data_ptr(), a2.data_ptr(), a2.stride(0),
+                                                     C.byref(sb), pb.data_ptr(), m, dim, m * dim, stream()))
+
+    tb, t8 = [], []
+    for _ in range(3):
+        tb.append(timeit(run_bf16)); t8.append(timeit(run_fp8))
+    tb, t8 = statistics.median(tb), statistics.median(t8)
+    by = dim * (2048 + 8192)
+    print(f"m={m:2d} proj+fc2 partial pair: bf16 {tb:6.1f}us ({by * 2 / tb / 1e6:5.2f} TB/s)  fp8 {t8:6.1f}us ({by / t8 / 1e6:5.2f} TB/s)  x{tb / t8:4.2f}", flush=True)

@@ -29,4 +29,5 @@ struct GemmK {
 // gemm_w4.hip: the 256x256 tile kernel with one wave per SIMD (4 waves x 128x128), persistent.
 // epi = MD_EPI_*.  Fills tiles_m / tiles_n itself.
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream);
+int md_gemm_w4_residual_max_cols();   // widest residual layer the four-wave kernel takes (its bias vector lives in LDS)
 void md_gemm_w4_set_variant(int v);  // measurement hook: schedule / ablation variant of the bias-epilogue kernel

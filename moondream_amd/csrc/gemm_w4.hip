@@ -47,9 +47,11 @@ constexpr int ROW_BYTES = BKT * 2;             // 64-byte rows: 4 chunks of 16 b
 constexpr int A_BYTES = BM * ROW_BYTES;        // 16 KiB
 constexpr int STAGE = (BM + BN) * ROW_BYTES;   // 32 KiB
 constexpr int RING = 4 * STAGE;                // 128 KiB: the pair of slices being multiplied + the pair being written
-constexpr int XPOSE_BYTES = 32 * 128;          // 32 rows x 64 bf16: the epilogue's transposition tile
-constexpr int SCRATCH_PER_WAVE = XPOSE_BYTES + 256;  // + the wave's 128 bias values
-constexpr int LDS_BYTES = RING + 4 * SCRATCH_PER_WAVE;
+// next to the ring: the layer's whole bias vector (28 KiB), or -- residual layers, whose epilogue transposes through
+// LDS -- four 4 KiB transposition tiles and a bias vector of up to 6144 columns
+constexpr int XPOSE_BYTES = 32 * 128;          // 32 rows x 64 bf16
+constexpr int LDS_BYTES = RING + 14336 * 2;
+template <int EPI> constexpr int bias_max_cols() { return EPI == MD_EPI_RESIDUAL ? (LDS_BYTES - RING - 4 * XPOSE_BYTES) / 2 : (LDS_BYTES - RING) / 2; }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -336,7 +338,20 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   };
 
   // ---- tile loop ------------------------------------------------------------------------------
-  const uint32_t tile_lds = lds_base + RING + wave * SCRATCH_PER_WAVE;
+  // The layer's bias vector goes to LDS once per launch: a global load inside the epilogue would have to wait for
+  // every older operand load of the running stream (loads return in order), i.e. drain the prefetch once per tile.
+  const uint32_t tile_lds = lds_base + RING + wave * XPOSE_BYTES;  // residual epilogue only
+  const uint32_t bias_lds = lds_base + RING + (EPI == MD_EPI_RESIDUAL ? 4 * XPOSE_BYTES : 0);
+  const bool bias_in_lds = p.n_pad <= bias_max_cols<EPI>();
+  if (bias_in_lds) {
+    for (int c = tid * 4; c < p.n_pad; c += 256 * 4) {
+      u32x2 bw = {0u, 0u};
+      if (p.bias != nullptr) bw = *(const u32x2*)(p.bias + c);
+      ds_write_b64_asm(bias_lds + c * 2, bw);
+    }
+    wait_lgkm<0>();
+    __syncthreads();
+  }
   for (int vtile = blockIdx.x; vtile < nwg; vtile += gridDim.x) {
     // the accumulators are (re)defined by the first K step of every tile: nothing is carried from
     // one tile to the next in them
@@ -347,18 +362,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
 
     // ---- epilogue of tile vtile (the next tile's first slices are already in the ring / in flight)
     // block X = 4 i + j, register r: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)   within the wave's quarter
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
     int m0c, n0c;
     tile_origin(vtile, m0c, n0c);
     const int wm0 = m0c + wm * 128, wn0 = n0c + wn * 128;
-    // the wave's 128 bias values go to LDS once per tile and are re-read per pass (broadcast ds_read_b64)
-    const uint32_t bias_lds = tile_lds + XPOSE_BYTES;
-    if (lane < 32) {
-      const int n = wn0 + 4 * lane;
-      u32x2 bw = {0u, 0u};
-      if (p.bias != nullptr && n < p.n_pad) bw = *(const u32x2*)(p.bias + n);
-      ds_write_b64_asm(bias_lds + lane * 8, bw);
-    }
+    if constexpr (EPI == MD_EPI_RESIDUAL) {
+    // Residual layers keep the LDS transposition: their second operand is read in whole 128-byte row pieces (the
+    // register-only path below reads / writes 32-byte pieces, which costs these short-K, narrow-N layers 5 % --
+    // profiles/r02_gemm_w4_epilogue_variants.txt).
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
     // eight passes of 32 rows x 64 columns (row block i, column half jp): bias add + ONE bf16 rounding on the
     // accumulator layout, transposition through the wave's 4 KiB LDS tile, then GELU / residual and the global
     // stores on whole 16-byte row pieces.  Piece q of this lane: row (q*64 + lane) >> 3, chunk (q*64 + lane) & 7.
@@ -380,10 +391,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     MD_PIN();
     static_for<0, 8>([&](auto pc) {
       constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
-      u32x2 bias_w[2][4];
+      u32x2 bias_p[2][4];
       static_for<0, 8>([&](auto jq) {
         constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
-        ds_read_b64_u32<(32 * (2 * jp + jj) + 8 * q) * 2>(bias_w[jj][q], bias_lds + hi * 8);
+        ds_read_b64_u32<(32 * (2 * jp + jj) + 8 * q) * 2>(bias_p[jj][q], bias_lds + (wn0 + 4 * hi) * 2);
       });
       if constexpr (EPI == MD_EPI_RESIDUAL && PASS + 1 < 8) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
       wait_lgkm<0>();
@@ -391,8 +402,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       static_for<0, 8>([&](auto jq) {
         constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4, base = 16 * (4 * i + 2 * jp + jj) + 4 * q;
         u32x2 w;
-        w[0] = pack_bf16x2(acc_read<base + 0>() + lo_bf(bias_w[jj][q][0]), acc_read<base + 1>() + hi_bf(bias_w[jj][q][0]));
-        w[1] = pack_bf16x2(acc_read<base + 2>() + lo_bf(bias_w[jj][q][1]), acc_read<base + 3>() + hi_bf(bias_w[jj][q][1]));
+        w[0] = pack_bf16x2(acc_read<base + 0>() + lo_bf(bias_p[jj][q][0]), acc_read<base + 1>() + hi_bf(bias_p[jj][q][0]));
+        w[1] = pack_bf16x2(acc_read<base + 2>() + lo_bf(bias_p[jj][q][1]), acc_read<base + 3>() + hi_bf(bias_p[jj][q][1]));
         constexpr int ch = 4 * jj + q;
         ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, w);
       });
@@ -431,6 +442,84 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       }
       MD_PIN();
     });
+    } else {
+    // this lane's 16 bias quads (column 32 j + 8 q + 4 hi .. + 3), once per tile
+    u32x2 bias_w[4][4];
+    if (bias_in_lds) {
+      static_for<0, 16>([&](auto jq) {
+        constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
+        ds_read_b64_u32<(32 * j + 8 * q) * 2>(bias_w[j][q], bias_lds + (wn0 + 4 * hi) * 2);
+      });
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = wn0 + 32 * j + 8 * q + 4 * hi;
+          bias_w[j][q] = u32x2{0u, 0u};
+          if (p.bias != nullptr && n < p.n_pad) bias_w[j][q] = *(const u32x2*)(p.bias + n);
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
+    // Eight passes of 32 rows x 64 columns (row block i, column half jp).  Bias add + ONE bf16 rounding happen on the
+    // accumulator layout (a lane: one row, quads of 4 consecutive columns; the two lane halves hold the two quads of an
+    // 8-column group).  Two v_permlane32_swap per pair of groups hand every lane a full 16-byte row piece -- lanes
+    // 0-31 the even group, lanes 32-63 the odd one, adjacent in memory -- so GELU / residual and the global stores
+    // work on 16-byte pieces with no trip through LDS: piece t of a pass: row l31, columns 64 jp + 32 jj + 16 t + 8 hi.
+    auto load_residual = [&](int pass, u32x4 (&rv)[4]) {
+      const int i = pass >> 1, jp = pass & 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = wm0 + 32 * i + l31, n = wn0 + 64 * jp + 16 * q + 8 * hi;
+        rv[q] = u32x4{0, 0, 0, 0};
+        if (m < p.M && n < p.n_store) {
+          const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
+          rv[q] = *(const u32x4*)(p.R + rrow * p.ldr + n);
+        }
+      }
+    };
+    u32x4 rres[2][4];
+    if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
+    wait_lgkm<0>();
+    MD_PIN();
+    static_for<0, 8>([&](auto pc) {
+      constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
+      if constexpr (EPI == MD_EPI_RESIDUAL && PASS + 1 < 8) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
+      static_for<0, 4>([&](auto tc) {
+        // piece t: groups q = 2 (t & 1) and q + 1 of column block j = 2 jp + (t >> 1)
+        constexpr int T = decltype(tc)::value, j = 2 * jp + (T >> 1), q0 = 2 * (T & 1);
+        constexpr int base0 = 16 * (4 * i + j) + 4 * q0, base1 = base0 + 4;
+        const uint32_t a0 = pack_bf16x2(acc_read<base0 + 0>() + lo_bf(bias_w[j][q0][0]), acc_read<base0 + 1>() + hi_bf(bias_w[j][q0][0]));
+        const uint32_t a1 = pack_bf16x2(acc_read<base0 + 2>() + lo_bf(bias_w[j][q0][1]), acc_read<base0 + 3>() + hi_bf(bias_w[j][q0][1]));
+        const uint32_t b0 = pack_bf16x2(acc_read<base1 + 0>() + lo_bf(bias_w[j][q0 + 1][0]), acc_read<base1 + 1>() + hi_bf(bias_w[j][q0 + 1][0]));
+        const uint32_t b1 = pack_bf16x2(acc_read<base1 + 2>() + lo_bf(bias_w[j][q0 + 1][1]), acc_read<base1 + 3>() + hi_bf(bias_w[j][q0 + 1][1]));
+        // swap(x, y): x' = {x of lanes 0-31, y of lanes 0-31}, y' = {x of lanes 32-63, y of lanes 32-63}
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        const int m = wm0 + 32 * i + l31, n = wn0 + 32 * j + 8 * (q0 + hi);
+        if (m < p.M && n < p.n_store) {
+          if constexpr (EPI == MD_EPI_GELU) {
+            if (n >= p.gelu_from) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const md_f32x2 ge = gelu_tanh_f32x2(md_f32x2{lo_bf(v[e]), hi_bf(v[e])});
+                v[e] = pack_bf16x2(ge[0], ge[1]);
+              }
+            }
+          } else if constexpr (EPI == MD_EPI_RESIDUAL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][T][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][T][e]) + hi_bf(v[e]));
+          }
+          if constexpr (ABL & 128) __builtin_nontemporal_store(v, (u32x4*)(p.C + (int64_t)m * p.ldc + n));
+          else if constexpr (!(ABL & 16)) *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+          else keep_alive(v);
+        }
+      });
+      MD_PIN();
+    });
+    }
     if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
     // registers the epilogue does not have to carry); its first pair was published by the last barrier above
@@ -462,6 +551,8 @@ md_status launch(const GemmK& k, hipStream_t stream) {
 
 }  // namespace
 
+int md_gemm_w4_residual_max_cols() { return bias_max_cols<MD_EPI_RESIDUAL>(); }
+
 void md_gemm_w4_set_variant(int v) { g_w4_variant = v; }
 
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
@@ -469,6 +560,9 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   // 32-bit byte offsets into A and W
   if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32))
     return MD_ERR_UNSUPPORTED;
+  // the residual epilogue takes its bias from the LDS-resident vector only (md_gemm_bf16 sends wider residual
+  // layers to the eight-wave kernel)
+  if (epi == MD_EPI_RESIDUAL && k.n_pad > md_gemm_w4_residual_max_cols()) return MD_ERR_UNSUPPORTED;
 #ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
   if (epi == MD_EPI_BIAS && g_w4_variant != 0) {
     switch (g_w4_variant) {

@@ -388,22 +388,23 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     };
     u32x4 rres[2][4];
     if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
+    // this lane's 16 bias quads, once per tile (not per pass: one LDS round trip less on every pass)
+    u32x2 bias_r[4][4];
+    static_for<0, 16>([&](auto jq) {
+      constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
+      ds_read_b64_u32<(32 * j + 8 * q) * 2>(bias_r[j][q], bias_lds + (wn0 + 4 * hi) * 2);
+    });
+    wait_lgkm<0>();
     MD_PIN();
     static_for<0, 8>([&](auto pc) {
       constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
-      u32x2 bias_p[2][4];
-      static_for<0, 8>([&](auto jq) {
-        constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
-        ds_read_b64_u32<(32 * (2 * jp + jj) + 8 * q) * 2>(bias_p[jj][q], bias_lds + (wn0 + 4 * hi) * 2);
-      });
       if constexpr (EPI == MD_EPI_RESIDUAL && PASS + 1 < 8) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
-      wait_lgkm<0>();
       MD_PIN();
       static_for<0, 8>([&](auto jq) {
         constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4, base = 16 * (4 * i + 2 * jp + jj) + 4 * q;
         u32x2 w;
-        w[0] = pack_bf16x2(acc_read<base + 0>() + lo_bf(bias_p[jj][q][0]), acc_read<base + 1>() + hi_bf(bias_p[jj][q][0]));
-        w[1] = pack_bf16x2(acc_read<base + 2>() + lo_bf(bias_p[jj][q][1]), acc_read<base + 3>() + hi_bf(bias_p[jj][q][1]));
+        w[0] = pack_bf16x2(acc_read<base + 0>() + lo_bf(bias_r[2 * jp + jj][q][0]), acc_read<base + 1>() + hi_bf(bias_r[2 * jp + jj][q][0]));
+        w[1] = pack_bf16x2(acc_read<base + 2>() + lo_bf(bias_r[2 * jp + jj][q][1]), acc_read<base + 3>() + hi_bf(bias_r[2 * jp + jj][q][1]));
         constexpr int ch = 4 * jj + q;
         ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, w);
       });

@@ -259,12 +259,13 @@ def load() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MD_HIP_LIB") or LIB_PATH  # MD_HIP_LIB: another build of the SAME ABI, for same-box A/B runs (tools/ab_lib.sh)
+    if not os.path.exists(path):
         raise MoondreamHipError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the Moondream hot path)"
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
         fn.restype = res

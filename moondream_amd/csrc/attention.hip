@@ -615,7 +615,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
   static_assert(NW == 4 || NW == 16, "waves per workgroup");
   constexpr int CPT = 16 / NW;            // classes per thread group
   constexpr int NU = (NW == 16) ? 4 : 1;  // class quarters that live in different waves
-  constexpr int UNR = (NW == 16) ? 4 : 2; // 128-key rounds whose loads are issued together
+  constexpr int UNR = (NW == 16) ? 8 : 2; // 128-key rounds whose loads are issued together
+  constexpr int VPRE = (NW == 16) ? 8 : 0; // NW = 16: the V rows of the first VPRE rounds are requested WITH the K rows (one memory round trip for a
+                                           // context of up to 1024 keys instead of two: the single-sequence step is latency-bound)
   __shared__ float sc[DEC_MAX_CTX];
   __shared__ float red[NU][32][64 + 1];   // [class quarter][residue][feature | sum of p]
   __shared__ float red_m[NW];
@@ -669,6 +671,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
   // key of (round i, class slot u): 128 i + 32 (u0 + u) + res; rows past kv_len replay the last row, masked below
   // ---- pass 1: scores --------------------------------------------------------
   float mx = -INFINITY;
+  u32x4 vpre[VPRE > 0 ? VPRE : 1];
   for (int i0 = 0; i0 * 128 < kv_len; i0 += UNR) {
     u32x4 kq[UNR][CPT];
 #pragma unroll
@@ -678,6 +681,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
         const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
         kq[r][u] = *(const u32x4*)(kb + (int64_t)min(j, pos) * 64 + c * 8);
       }
+    if constexpr (VPRE > 0) {
+      if (i0 == 0) {
+#pragma unroll
+        for (int r = 0; r < VPRE; ++r) {
+          const int j = 128 * r + 32 * u0 + res;
+          vpre[r] = *(const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 8);
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < UNR; ++r)
 #pragma unroll
@@ -714,13 +726,19 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
   }
   for (int i0 = 0; i0 * 128 < kv_len; i0 += UNR) {
     u32x4 vq[UNR][CPT];
+    if (VPRE > 0 && i0 == 0) {
+      static_assert(VPRE == 0 || (VPRE == UNR && CPT == 1), "prefetched V rows cover exactly the first batch");
 #pragma unroll
-    for (int r = 0; r < UNR; ++r)
+      for (int r = 0; r < UNR; ++r) vq[r][0] = vpre[VPRE > 0 ? r : 0];
+    } else {
 #pragma unroll
-      for (int u = 0; u < CPT; ++u) {
-        const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
-        vq[r][u] = *(const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 8);
-      }
+      for (int r = 0; r < UNR; ++r)
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
+          vq[r][u] = *(const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 8);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < UNR; ++r)
 #pragma unroll

@@ -8,3 +8,4 @@ grep -E "fp8 decode|bench64 parity" gpurun_out/tests_all.log | head
 t0=$(date +%s)
 timeout 420 python bench.py > gpurun_out/bench_full.log 2>&1
 echo "bench rc=$? wall=$(( $(date +%s) - t0 ))s"; tail -1 gpurun_out/bench_full.log | cut -c1-4000
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3

@@ -402,7 +402,9 @@ def main():
         result["vit_encoder"] = {
             "bound": "mfma", "achieved": vit_flops / (phase_ms["vision"] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
             "frac": vit_flops / (phase_ms["vision"] * 1e-3) / 1e12 / 2500.0,
-            "note": "all kernels of the vision phase, 2 crops/image (666.45 GFLOP each) + projector (51.98 GFLOP/image)",
+            "note": "all kernels of the vision phase (H2D of the crops, patchify, 27 blocks incl. attention and layer norms, stitch, "
+                    "projector), 2 crops/image (666.45 GFLOP each) + projector (51.98 GFLOP/image); the host-side tiling the eager "
+                    "step waits for first is phase_ms.host_tiling (hidden behind the previous step's decode in the timed region)",
         }
 
     # p50 single-image caption latency (B=1), outside the timed region

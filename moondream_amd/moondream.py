@@ -365,7 +365,7 @@ class MoondreamModel:
         oc = overlap_crop_image(arr, max_crops=v.max_crops, overlap_margin=v.overlap_margin)
         return oc["crops"], tuple(oc["tiling"])
 
-    def _run_vision_encoder_batch(self, images: Sequence[Image.Image]) -> torch.Tensor:
+    def _run_vision_encoder_batch(self, images: Sequence[Image.Image], mark=None) -> torch.Tensor:
         """images -> [B,729,D] projected embeddings (reference: moondream.py:206-228, per image).
 
         Host tiling (PIL, reference image_crops.py:58-167) runs on a thread pool and is
@@ -380,6 +380,8 @@ class MoondreamModel:
         feat_parts = []
         for i0 in range(0, n_img, per_chunk):
             part = [f.result() for f in futures[i0 : i0 + per_chunk]]
+            if mark is not None and i0 == 0:
+                mark("host_tiling")  # phase timing: the GPU has nothing of this batch to run before the first crops exist
             cropped.extend(part)
             host = np.concatenate([c for c, _ in part], axis=0)
             dev_crops = torch.from_numpy(host).to(self._device, non_blocking=True)
@@ -646,7 +648,7 @@ class MoondreamModel:
         mark("start")
         pos = None
         if raw_idx:
-            img_emb = self._run_vision_encoder_batch([images[i] for i in raw_idx])
+            img_emb = self._run_vision_encoder_batch([images[i] for i in raw_idx], mark)
             mark("vision")
             # every run of consecutive raw images is prefilled straight into its own slots
             j = 0

@@ -20,5 +20,5 @@ for run in ("a","b"):
     for k, cs in agg.items():
         line = k + " :: " + "  ".join(f"{n}={v[1]/v[0]:.3e}" for n, v in sorted(cs.items()))
         print(line); out.write(line+"\n")
-find gpurun_out/pmc -name "*.csv" -size +5M -delete
 PY
+find gpurun_out/pmc -name "*.csv" -size +5M -delete

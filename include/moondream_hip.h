@@ -447,6 +447,25 @@ md_status md_lm_head(const md_text_model* m, const void* hidden, int32_t batch, 
                      void* logits, int64_t ld_logits, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* Single-sequence decode as ONE persistent kernel (csrc/decode_b1.hip): all decoder blocks of one token inside one
+ * launch of one workgroup per CU, grid barriers instead of kernel boundaries (the body of _decode_one_tok,
+ * moondream.py:183-192 -> text.py:128-160, at batch 1).  x_in / hidden: bf16 [dim]; kv: the sequence's slot
+ * (k / v pointing at its batch entry); sync_state: >= 16 KiB of device memory owned by the caller, ZERO before first
+ * use and written by nothing else (barrier counters carry over from launch to launch; word 704 is raised if a
+ * barrier ever timed out).  fp32 matrix-vector products and per-slice softmax maxima: the same tolerance against the
+ * reference as the batched kernels, not bit-identical to them.  Needs the fused qkv|fc1 packing and n_kv_heads ==
+ * n_heads, head_dim 64. */
+size_t md_decode_b1_workspace_bytes(const md_text_model* m);
+md_status md_decode_b1_layers(const md_text_model* m, const void* x_in, void* hidden, const int32_t* pos,
+                              const md_kv_cache* kv, void* workspace, size_t workspace_bytes, void* sync_state,
+                              void* stream);
+/* md_decode_step for ONE sequence on that kernel: embed -> md_decode_b1_layers -> lm_head -> suppress -> argmax;
+ * pos[0] += 1.  Workspace: md_decode_step_b1_workspace_bytes(m). */
+size_t md_decode_step_b1_workspace_bytes(const md_text_model* m);
+md_status md_decode_step_b1(const md_text_model* m, const int32_t* token, int32_t* next, int32_t* pos,
+                            const md_kv_cache* kv, int32_t suppress_id, void* logits, int64_t ld_logits,
+                            void* workspace, size_t workspace_bytes, void* sync_state, void* stream);
+
 /* One greedy decode step for the whole batch, device-resident (the body of the
  * reference's generator loop, moondream.py:512-530, without its per-token host
  * sync): embed tokens[b] -> decoder at pos[b] -> lm_head -> suppress

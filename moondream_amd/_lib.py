@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "decode_b1.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
 ABI_VERSION = 2  # include/moondream_hip.h MD_ABI_VERSION
@@ -164,6 +164,11 @@ SIGNATURES = {
     "md_gelu_bf16": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "md_lm_head_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32]),
     "md_lm_head": (C.c_int, [P(MdTextModel), c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "md_decode_b1_workspace_bytes": (c_size_t, [P(MdTextModel)]),
+    "md_decode_b1_layers": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_void_p, P(MdKvCache), c_void_p, c_size_t, c_void_p, c_void_p]),
+    "md_decode_step_b1_workspace_bytes": (c_size_t, [P(MdTextModel)]),
+    "md_decode_step_b1": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_void_p, P(MdKvCache), c_int32, c_void_p, c_int64,
+                                    c_void_p, c_size_t, c_void_p, c_void_p]),
     "md_decode_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32]),
     "md_decode_step": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_void_p, c_int32, P(MdKvCache), c_int32,
                                  c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),

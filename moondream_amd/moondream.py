@@ -123,6 +123,10 @@ class MoondreamModel:
         self.last_phase_ms: Dict[str, float] = {}
         self._region_tables = None
         self._variants: Dict[str, PackedLora] = {}
+        # batch-1 greedy decode on the persistent single-sequence kernel (md_decode_step_b1): one launch per token for
+        # all decoder blocks; False = the batched kernels at one row (bit-identical to a row of a batch)
+        self.single_sequence_kernel = True
+        self._b1_sync = None  # barrier state of that kernel: zeroed once, then owned by it
         if setup_caches:
             self._setup_caches(max_batch)
 
@@ -536,7 +540,25 @@ class MoondreamModel:
         kv = self._kv_struct(slot0)
         pos_base = torch.tensor(pos_list, dtype=torch.int32, device=self._device)
 
+        b1 = (b == 1 and self.single_sequence_kernel and lora is None and not bool(self.w.text.fp8)
+              and t.n_heads == t.n_kv_heads and t.qkv_dim % 64 == 0)
+        if b1:
+            if self._b1_sync is None:
+                self._b1_sync = torch.zeros(4096, dtype=torch.int32, device=self._device)
+            need = max(need, self.lib.md_decode_step_b1_workspace_bytes(C.byref(self.w.text)))
+            ws = self._workspace(need, 2)
+
         def one_step(tok_in, tok_out, pos_buf):
+            if b1:
+                _lib.check(
+                    self.lib.md_decode_step_b1(
+                        C.byref(self.w.text), tok_in.data_ptr(), tok_out.data_ptr(), pos_buf.data_ptr(), C.byref(kv),
+                        suppress_id, logits.data_ptr(), t.vocab_size, ws.data_ptr(), ws.numel(), self._b1_sync.data_ptr(),
+                        self._stream(),
+                    ),
+                    "md_decode_step_b1",
+                )
+                return
             _lib.check(
                 self.lib.md_decode_step(
                     C.byref(self.w.text), tok_in.data_ptr(), tok_out.data_ptr(), pos_buf.data_ptr(), b, C.byref(kv),
@@ -579,7 +601,7 @@ class MoondreamModel:
             # a graph is replayed only on the stream (context) it was captured for: the pipelined engine's
             # decode stream and the default stream each keep their own captures
             key = ("decode", b, slot0, n, suppress_id, ws.data_ptr(), self._kv_k.data_ptr(), logits.data_ptr(),
-                   torch.cuda.current_stream(self._device).cuda_stream)
+                   torch.cuda.current_stream(self._device).cuda_stream, b1)
             entry = self._graphs.get(key)
             if entry is None:
                 buf = torch.zeros(n + 1, b, dtype=torch.int32, device=self._device)

@@ -496,6 +496,42 @@ def test_hf_wrapper_answer_question_and_batch_answer(tiny):
         hf._unsupported_exception()
 
 
+def test_single_sequence_kernel_tracks_batched_kernels(tiny):
+    """Batch-1 decode on the persistent kernel (md_decode_step_b1: every decoder block of a token in one launch, grid
+    barriers, fp32 matrix-vector products) against the batched kernels at one row: same ids on the wide-margin
+    goldens (== the reference's), teacher-forced logits within bf16 noise, K/V rows of the new tokens equal within
+    tolerance, and no barrier ever timed out."""
+    g, cfg, sd, model = tiny
+    try:
+        for idx in range(len(g["image_index"])):
+            img, prompt = golden_image(g, idx), g[f"img{idx}.cap.prompt"].tolist()
+            ref = g[f"img{idx}.cap.tokens"].tolist()
+            model.single_sequence_kernel = False
+            a = model.batch_generate_ids([img], [prompt], max_tokens=len(ref), ignore_eos=True)[0]
+            ka = model._kv_k[:, 0].clone()
+            model.single_sequence_kernel = True
+            b = model.batch_generate_ids([img], [prompt], max_tokens=len(ref), ignore_eos=True)[0]
+            kb = model._kv_k[:, 0].clone()
+            assert a == ref and b == ref, (idx, a, b, ref)
+            n_pos = 730 + len(prompt) + len(ref) - 1
+            compare(f"K rows img{idx}", kb[:, :, 730:n_pos], ka[:, :, 730:n_pos], 1e-2)
+        assert int(model._b1_sync[64 * 11]) == 0, "a grid barrier timed out"
+        # one teacher-forced step: logits of both paths
+        enc = model.encode_image(golden_image(g, 0))
+        outs = []
+        for flag in (False, True):
+            model.single_sequence_kernel = flag
+            model.load_encoded_image(enc)
+            first = torch.tensor([int(g["img0.cap.tokens"][0])], dtype=torch.int32, device="cuda")
+            _, _, pos = model._prefill_prompts([g["img0.cap.prompt"].tolist()], enc.pos, 0)
+            model._decode_greedy(first, pos, 1, cfg.tokenizer.answer_id, 0, None)
+            outs.append(model._logits_buf[0].float().cpu().clone())
+        err = float((outs[0] - outs[1]).abs().max())
+        assert err <= 0.25, err
+    finally:
+        model.single_sequence_kernel = True
+
+
 def fp8_decode_report(model, images, prompts, ids_bf16, ref_margins, label):
     """Run the same generation with FP8 decode weights; the first decode step's logits (identical image prefix in the
     KV cache, identical input token) must stay within tolerance of the bf16 logits, and token streams may only leave the bf16 stream at

@@ -558,21 +558,18 @@ extern "C" md_status md_decode_step(const md_text_model* m, const int32_t* token
 
 extern "C" size_t md_decode_step_b1_workspace_bytes(const md_text_model* m) {
   if (!m || !m->blocks) return 0;
-  return align_up((size_t)m->dim * 2) + md_lm_head_workspace_bytes(m, 1) + align_up(md_decode_b1_workspace_bytes(m));
+  return align_up(md_decode_b1_workspace_bytes(m));
 }
+
+// decode_b1.hip: embedding lookup, every decoder block, final layer norm, lm_head, suppression, argmax and pos += 1 in ONE launch
+md_status md_decode_b1_step(const md_text_model* m, const int32_t* token, int32_t* next, int32_t* pos, const md_kv_cache* kv,
+                            int32_t suppress_id, void* logits, void* workspace, size_t workspace_bytes, void* sync_state,
+                            hipStream_t s);
 
 extern "C" md_status md_decode_step_b1(const md_text_model* m, const int32_t* token, int32_t* next, int32_t* pos,
                                        const md_kv_cache* kv, int32_t suppress_id, void* logits, int64_t ld_logits,
                                        void* workspace, size_t workspace_bytes, void* sync_state, void* stream) {
-  MD_CHECK_ARG(m && token && next && pos && kv && logits && workspace && sync_state);
+  MD_CHECK_ARG(m && token && next && pos && kv && logits && workspace && sync_state && ld_logits >= m->vocab);
   if (workspace_bytes < md_decode_step_b1_workspace_bytes(m)) return MD_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  Arena a{(char*)workspace, 0};
-  void* x = a.take((size_t)m->dim * 2);
-  void* lmws = a.take(md_lm_head_workspace_bytes(m, 1));
-  void* lws = a.take(md_decode_b1_workspace_bytes(m));
-  MD_TRY(md_embed_tokens(token, m->wte, m->dim, x, m->dim, 1, m->dim, s));
-  MD_TRY(md_decode_b1_layers(m, x, x, pos, kv, lws, md_decode_b1_workspace_bytes(m), sync_state, s));
-  MD_TRY(md_lm_head(m, x, 1, 1, logits, ld_logits, lmws, md_lm_head_workspace_bytes(m, 1), s));
-  return md_argmax_advance(logits, ld_logits, 1, m->vocab, suppress_id, next, pos, s);
+  return md_decode_b1_step(m, token, next, pos, kv, suppress_id, logits, workspace, workspace_bytes, sync_state, (hipStream_t)stream);
 }

@@ -30,7 +30,7 @@ namespace {
 
 constexpr int B1_MAX_LAYERS = 32;
 constexpr int B1_SLICES = 8;        // key slices per head
-constexpr int B1_PART = 66;         // floats per attention partial: max, sum, out[64]
+constexpr int B1_PART = 68;         // floats per attention partial: max, sum, two pad words, out[64] (16-byte aligned)
 constexpr unsigned B1_SPIN_LIMIT = 4000000u;
 
 struct B1Layer {
@@ -46,7 +46,15 @@ struct B1Args {
   bf16_t* vslab;
   int64_t layer_stride;
   const int32_t* pos;
-  bf16_t* x[2];      // residual stream, ping-pong; x[0] holds the input embedding
+  const bf16_t* x_first;  // the first block's input (nullptr: row token[0] of wte)
+  bf16_t* x[2];           // residual stream between blocks, ping-pong
+  bf16_t* x_last;         // the last block's output (nullptr: x[n_layers & 1])
+  // whole decode step (lm_w != nullptr): embedding lookup in front, final layer norm + lm_head + greedy choice behind
+  const int32_t* token;
+  const bf16_t *wte, *post_ln_w, *post_ln_b, *lm_w, *lm_b;
+  int ld_lm, vocab, suppress;
+  bf16_t* logits;
+  int32_t *next, *pos_out;
   bf16_t* act;       // [qkv_w + ff]: the fused linear's output row
   float* part;       // [n_heads][B1_SLICES][B1_PART]
   unsigned* sync;    // [0] epoch, [64 (1 + xcd)] per-XCD arrivals, [64 * 9] top-level arrivals, [64 * 10] flag, [64 * 11] error
@@ -60,6 +68,14 @@ __device__ __forceinline__ uint32_t ld_coh32(const void* p) {
 __device__ __forceinline__ uint64_t ld_coh64(const void* p) {
   return __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// 16-byte form: a buffer load with the sc1 bit (what the agent-scope atomic loads above compile to), tracked by the
+// compiler's wait counters like any other load
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ld_coh128(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
 __device__ __forceinline__ void st_coh32(void* p, uint32_t v) {
   __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -71,37 +87,40 @@ struct GridBarrier {
   unsigned* sync;
   unsigned base;
   unsigned count = 0;
-  __device__ void arrive_and_wait() {
+  unsigned target = 0;
+  // arrive: this workgroup's stores are out; wait: everybody's are.  Work that depends on neither side of the barrier
+  // (weight rows, K / V rows of earlier tokens) goes between the two calls.
+  __device__ void arrive() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this workgroup's stores have been issued and acknowledged
     __syncthreads();
     ++count;
+    target = base + count;
     if (threadIdx.x == 0) {
       const int nwg = gridDim.x, xcd = blockIdx.x & 7, per = (nwg + 7 - xcd) / 8, groups = nwg < 8 ? nwg : 8;
-      const unsigned target = base + count;
-      bool last = false;
       const unsigned a1 = __hip_atomic_fetch_add(sync + 64 * (1 + xcd), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a1 + 1u == (unsigned)per * target) {
         const unsigned a2 = __hip_atomic_fetch_add(sync + 64 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (a2 + 1u == (unsigned)groups * target);
+        if (a2 + 1u == (unsigned)groups * target)
+          __hip_atomic_store(sync + 64 * 10, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (last) {
-        __hip_atomic_store(sync + 64 * 10, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(sync + 64 * 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-          if (++spins > B1_SPIN_LIMIT) {
-            __hip_atomic_store(sync + 64 * 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __device__ void wait() {
+    if (threadIdx.x == 0) {
+      unsigned spins = 0;
+      while ((int)(__hip_atomic_load(sync + 64 * 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (++spins > B1_SPIN_LIMIT) {
+          __hip_atomic_store(sync + 64 * 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
         }
+        __builtin_amdgcn_s_sleep(1);
       }
     }
     __syncthreads();
   }
 };
 
-// NWV waves per workgroup (8 or 16): one wave per SIMD leaves the load latency exposed
+// NWV waves per workgroup: one wave per SIMD leaves the load latency exposed
 template <int NWV>
 __device__ __forceinline__ float block_sum(float v, float* red) {  // red: NWV floats of LDS
   v = wave_sum(v);
@@ -140,6 +159,13 @@ struct Gemv {
 #pragma unroll
     for (int r = 0; r < R; ++r) dst[r] = *(const u32x4*)(rows[r] + kk);
   }
+  // (a conditional prime() needs this on the other path: otherwise the ring is live around the whole layer loop)
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) w[u][r] = u32x4{0u, 0u, 0u, 0u};
+  }
   __device__ __forceinline__ void prime(const bf16_t* const (&rows)[R], int K) {
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) issue(rows, K, u, w[u]);
@@ -174,16 +200,20 @@ struct Gemv {
   }
 };
 
-constexpr int B1_MAX_DIM = 4096, B1_MAX_FF = 16384, B1_MAX_KEYS = 2048 / B1_SLICES;
+constexpr int B1_MAX_DIM = 4096, B1_MAX_FF = 8192, B1_MAX_KEYS = 2048 / B1_SLICES, B1_MAX_Q = 32;
 
 template <int NWV>
 __global__ __launch_bounds__(64 * NWV) void decode_b1_kernel(const B1Args p) {
-  __shared__ __attribute__((aligned(16))) char lds_row[B1_MAX_DIM * 2];  // ln(x) in phase A, the attention row in phase C
-  __shared__ __attribute__((aligned(16))) char lds_ff[B1_MAX_FF * 2];    // gelu(fc1) in phase C; phase B: P.V partials of the 32 key groups
+  __shared__ __attribute__((aligned(16))) char lds_row[B1_MAX_DIM * 2];  // ln(x) in phase A / D, the attention row in phase C
+  __shared__ __attribute__((aligned(16))) char lds_ff[B1_MAX_FF * 2];    // gelu(fc1), staged at the start of phase B
   __shared__ float red[NWV];
+  __shared__ float pv_lds[NWV * 64];  // phase B: P.V partials of the waves
   __shared__ float sc[B1_MAX_KEYS];
   __shared__ float head_m[64 * B1_SLICES], head_l[64 * B1_SLICES];  // phase C: slice statistics of every head
   __shared__ __attribute__((aligned(16))) bf16_t newrow[3][64];      // phase B: rotated q, rotated k, v of the new token
+  __shared__ float fc2_part[B1_MAX_Q][2][2];                         // fc2 dot products: [pair of the workgroup][K half][row]
+  __shared__ float proj_part[NWV / 2][2][2];
+  __shared__ int best_i[NWV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NT = 64 * NWV;
@@ -205,296 +235,377 @@ __global__ __launch_bounds__(64 * NWV) void decode_b1_kernel(const B1Args p) {
   const int L = pos + 1;
   const int D = p.dim, FF = p.ff, QW = p.qkv_w;
 
+  // ---- work lists (the same for every layer) ---------------------------------------------------------------------------
+  // phase A: row pairs of the fused [qkv | fc1] matrix: workgroup b owns pairs b + gridDim q, its wave w the q = w + NWV i
+  const int np_a = (QW + FF) >> 1;
+  const int npw_a = blockIdx.x < np_a ? (np_a - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+  // phases B / C: output pairs b + gridDim q of proj and fc2; TWO waves share a pair, each takes half of the features
+  const int np_c = D >> 1;
+  const int npw_c = blockIdx.x < np_c ? (np_c - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+  const int nchd = (D + 511) / 512, nch2 = (FF + 511) / 512;
+  constexpr int PPP = NWV / 2;  // pairs per pass
+  const int qw = wave >> 1, half = wave & 1;
+  // phase D: row pairs of lm_head
+  const int np_d = p.vocab >> 1;
+  const int npw_d = (p.lm_w && blockIdx.x < np_d) ? (np_d - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+
+  const bf16_t* rows_a[2];
+  auto set_rows = [&](const bf16_t* wmat, int ld, int q) {
+    const int pp = blockIdx.x + gridDim.x * q;
+    rows_a[0] = wmat + (int64_t)(2 * pp) * ld;
+    rows_a[1] = rows_a[0] + ld;
+  };
+  Gemv<2, 4> ga;  // phases A and D; primed across the barrier that precedes the phase (the weights depend on nothing)
+  auto prime_first = [&](int npw, const bf16_t* wmat, int ld) {
+    if (wave < npw) {
+      set_rows(wmat, ld, wave);
+      ga.prime(rows_a, D);
+    } else {
+      ga.zero();
+    }
+  };
+  // a workgroup's npw row pairs, round-robin over its waves (pair q = wave + NWV i: consecutive pairs land on the four
+  // SIMDs in turn); finish(pp, d0, d1) is called by every lane of the wave that holds the two dot products of row pair pp.
+  // (Sharing the last npw % NWV pairs between waves by K ranges evens the waves out on paper and measured slower.)
+  auto run_rows = [&](int npw, const bf16_t* wmat, int ld, auto finish) {
+    for (int q = wave; q < npw; q += NWV) {
+      if (q != wave) {
+        set_rows(wmat, ld, q);
+        ga.prime(rows_a, D);
+      }
+      float d[2];
+      ga.run(rows_a, D, lds_row, d);
+      finish(blockIdx.x + gridDim.x * q, d[0], d[1]);
+    }
+  };
+  prime_first(npw_a, p.layer[0].w1, p.ld1);
+
+  // layer norm of the residual stream (every workgroup, redundantly) -> lds_row
+  auto layer_norm_to_lds = [&](const bf16_t* xsrc, const bf16_t* lnw, const bf16_t* lnb) {
+    float v[8];
+    float sum = 0.f;
+    const int nch = D >> 3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (tid < nch) {
+      const u32x4 q = ld_coh128(coh_rsrc(xsrc), tid * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = lo_bf(q[e]);
+        v[2 * e + 1] = hi_bf(q[e]);
+        sum += v[2 * e] + v[2 * e + 1];
+      }
+    }
+    const float mean = block_sum<NWV>(sum, red) / (float)D;
+    float ss = 0.f;
+    if (tid < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dlt = v[e] - mean;
+        ss += dlt * dlt;
+      }
+    }
+    const float rstd = rsqrtf(block_sum<NWV>(ss, red) / (float)D + p.eps);
+    if (tid < nch) {
+      const u32x4 wq = *(const u32x4*)(lnw + tid * 8), bq = *(const u32x4*)(lnb + tid * 8);
+      u32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        out[e] = pack_bf16x2((v[2 * e] - mean) * rstd * lo_bf(wq[e]) + lo_bf(bq[e]),
+                             (v[2 * e + 1] - mean) * rstd * hi_bf(wq[e]) + hi_bf(bq[e]));
+      *(u32x4*)(lds_row + tid * 16) = out;
+    }
+    __syncthreads();
+  };
+
+  // phase B's key / value rows of this workgroup's first (head, slice): they were written by earlier launches, so their
+  // loads go out while the barrier in front of the phase is still collecting arrivals
+  constexpr int NG = NT / 8, KPT = (B1_MAX_KEYS + NG - 1) / NG;  // key groups (8 lanes per 128-byte row); keys per group at most
+  const int chunk = (L + B1_SLICES - 1) / B1_SLICES;
+  const int g = tid >> 3, c = tid & 7;
+  auto load_kv = [&](int l, int idx, u32x4 (&kq)[KPT], u32x4 (&vq)[KPT]) {
+    const int h = idx / B1_SLICES, sl = idx % B1_SLICES;
+    const int j0 = sl * chunk, j1 = max(min(L, j0 + chunk), j0 + 1);
+    const bf16_t* kb = p.kslab + (int64_t)l * p.layer_stride + (int64_t)h * p.ctx * 64;
+    const bf16_t* vb = p.vslab + (int64_t)l * p.layer_stride + (int64_t)h * p.ctx * 64;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int j = min(min(j0 + g + NG * i, j1 - 1), p.ctx - 1);
+      kq[i] = *(const u32x4*)(kb + (int64_t)j * 64 + c * 8);
+      vq[i] = *(const u32x4*)(vb + (int64_t)j * 64 + c * 8);
+    }
+  };
+  const int n_items = p.n_heads * B1_SLICES;
+
+  const bf16_t* xc = p.x_first;
+  if (!xc) xc = p.wte + (int64_t)min(max(p.token[0], 0), p.vocab - 1) * D;
   for (int l = 0; l < p.n_layers; ++l) {
     const B1Layer& w = p.layer[l];
-    const bf16_t* xc = p.x[l & 1];
-    bf16_t* xn = p.x[(l + 1) & 1];
+    bf16_t* xn = (l + 1 == p.n_layers && p.x_last) ? p.x_last : p.x[(l + 1) & 1];
 
-    // ================= phase A: layer norm (every workgroup, redundantly) + fused [qkv | fc1] rows ==================
-    {
-      // row pairs of the fused matrix: workgroup b owns pairs b + gridDim q, its wave w the q = w + NWV i of them
-      // (consecutive q land on the four SIMDs in turn)
-      const int np = (QW + FF) >> 1;
-      const int npw = blockIdx.x < np ? (np - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-      const bf16_t* rows_a[2];
-      auto set_rows_a = [&](int q) {
-        const int pp = blockIdx.x + gridDim.x * min(q, npw - 1);
-        rows_a[0] = w.w1 + (int64_t)(2 * pp) * p.ld1;
-        rows_a[1] = rows_a[0] + p.ld1;
-      };
-      Gemv<2, 4> ga;
-      if (npw > 0) {
-        set_rows_a(wave);
-        ga.prime(rows_a, D);  // before the layer norm: the weights do not depend on it
+    // ================= phase A: layer norm + fused [qkv | fc1] rows ===================================================
+    layer_norm_to_lds(xc, w.ln_w, w.ln_b);
+    run_rows(npw_a, w.w1, p.ld1, [&](int pp, float d0, float d1) {
+      if (lane == 0) {
+        const uint32_t bw = *(const uint32_t*)(w.b1 + 2 * pp);
+        uint32_t o = pack_bf16x2(d0 + lo_bf(bw), d1 + hi_bf(bw));  // F.linear's rounding point
+        if (2 * pp >= QW) {  // fc1 rows: gelu on the bf16 value, rounded again (layers.py:24-25,137)
+          const md_f32x2 gl = gelu_tanh_f32x2(md_f32x2{lo_bf(o), hi_bf(o)});
+          o = pack_bf16x2(gl[0], gl[1]);
+        }
+        st_coh32(p.act + 2 * pp, o);
       }
-      float v[8];
-      float sum = 0.f;
-      const int nch = D >> 3;
+    });
+    stamp();
+    bar.arrive();
+    u32x4 kq[KPT], vq[KPT];
+    if ((int)blockIdx.x < n_items) {
+      load_kv(l, blockIdx.x, kq, vq);
+    } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
-      if (tid < nch) {
-        const uint64_t q0 = ld_coh64(xc + tid * 8), q1 = ld_coh64(xc + tid * 8 + 4);
-        const uint32_t q[4] = {(uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32)};
+      for (int i = 0; i < KPT; ++i) kq[i] = vq[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    bar.wait();
+    stamp();
+
+    // ================= phase B: attention partials, one (head, key slice) per workgroup; then the fc2 rows ============
+    // gelu(fc1) -> LDS for the fc2 rows: requested now, parked in LDS after the attention slice (the latency of these
+    // loads runs under it)
+    constexpr int NFQ = B1_MAX_FF / 8 / NT > 0 ? B1_MAX_FF / 8 / NT : 1;
+    u32x4 ffq[NFQ];
+    {
+      const __amdgpu_buffer_rsrc_t r_ff = coh_rsrc(p.act + QW);
+#pragma unroll
+      for (int i = 0; i < NFQ; ++i) {
+        const int ch = tid + NT * i;
+        ffq[i] = ld_coh128(r_ff, (ch < (FF >> 3) ? ch : 0) * 16);
+      }
+    }
+    for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+      const int h = idx / B1_SLICES, sl = idx % B1_SLICES;
+      const int j0 = sl * chunk, j1 = min(L, j0 + chunk);
+      bf16_t* kb = p.kslab + (int64_t)l * p.layer_stride + (int64_t)h * p.ctx * 64;
+      bf16_t* vb = p.vslab + (int64_t)l * p.layer_stride + (int64_t)h * p.ctx * 64;
+      float* out = p.part + (int64_t)idx * B1_PART;
+      __syncthreads();  // LDS reuse across iterations
+      if (j0 >= j1) {   // no keys in this slice
+        if (tid < B1_PART) st_coh32(out + tid, tid == 0 ? 0xff800000u : 0u);
+        continue;
+      }
+      if (idx != (int)blockIdx.x) load_kv(l, idx, kq, vq);
+      // rotated q (every slice needs it) and, for the slice that holds the new position, rotated k and v (rope.py:20-48)
+      {
+        const int hr = p.rot >> 1;
+        auto act_at = [&](int col) -> float {  // one bf16 of the fused row, through a coherent 4-byte load
+          const uint32_t wv = ld_coh32(p.act + (col & ~1));
+          return (col & 1) ? hi_bf(wv) : lo_bf(wv);
+        };
+        if (tid < 2 * hr) {
+          const int which = tid / hr, j = tid % hr;
+          const int base = (which ? (p.n_heads + h) : h) * 64;
+          const float re = act_at(base + j), im = act_at(base + hr + j);
+          const float cs = p.freqs[((int64_t)pos * hr + j) * 2], sn = p.freqs[((int64_t)pos * hr + j) * 2 + 1];
+          newrow[which][2 * j] = f2bf(__fsub_rn(__fmul_rn(re, cs), __fmul_rn(im, sn)));
+          newrow[which][2 * j + 1] = f2bf(__fadd_rn(__fmul_rn(re, sn), __fmul_rn(im, cs)));
+        } else if (tid >= 64 && tid < 64 + 2 * (64 - p.rot)) {
+          const int t2 = tid - 64, which = t2 / (64 - p.rot), i = p.rot + t2 % (64 - p.rot);
+          newrow[which][i] = f2bf(act_at((which ? (p.n_heads + h) : h) * 64 + i));
+        } else if (tid >= 192 && tid < 256) {
+          newrow[2][tid - 192] = f2bf(act_at((2 * p.n_heads + h) * 64 + tid - 192));
+        }
+      }
+      __syncthreads();
+      const bool has_new = pos >= j0 && pos < j1;
+      if (has_new) {
+        if (tid < 64) kb[(int64_t)pos * 64 + tid] = newrow[1][tid];
+        else if (tid < 128) vb[(int64_t)pos * 64 + tid - 64] = newrow[2][tid - 64];
+      }
+      float qv[8];
+      {
+        const u32x4 qq = *(const u32x4*)(&newrow[0][c * 8]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * e] = lo_bf(q[e]);
-          v[2 * e + 1] = hi_bf(q[e]);
-          sum += v[2 * e] + v[2 * e + 1];
+          qv[2 * e] = lo_bf(qq[e]) * p.scale_log2;
+          qv[2 * e + 1] = hi_bf(qq[e]) * p.scale_log2;
         }
       }
-      const float mean = block_sum<NWV>(sum, red) / (float)D;
-      float ss = 0.f;
-      if (tid < nch) {
+      float mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float dlt = v[e] - mean;
-          ss += dlt * dlt;
-        }
-      }
-      const float rstd = rsqrtf(block_sum<NWV>(ss, red) / (float)D + p.eps);
-      if (tid < nch) {
-        const u32x4 wq = *(const u32x4*)(w.ln_w + tid * 8), bq = *(const u32x4*)(w.ln_b + tid * 8);
-        u32x4 out;
+      for (int i = 0; i < KPT; ++i) {
+        const int j = j0 + g + NG * i;
+        const u32x4 kk = (j == pos) ? *(const u32x4*)(&newrow[1][c * 8]) : kq[i];  // the new key is not in global memory for this CU yet
+        float sv = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          out[e] = pack_bf16x2((v[2 * e] - mean) * rstd * lo_bf(wq[e]) + lo_bf(bq[e]),
-                               (v[2 * e + 1] - mean) * rstd * hi_bf(wq[e]) + hi_bf(bq[e]));
-        *(u32x4*)(lds_row + tid * 16) = out;
-      }
-      __syncthreads();
-      for (int q = wave; q < npw; q += NWV) {
-        if (q != wave) {
-          set_rows_a(q);
-          ga.prime(rows_a, D);
-        }
-        float d[2];
-        ga.run(rows_a, D, lds_row, d);
-        if (lane == 0) {
-          const int pp = blockIdx.x + gridDim.x * q;
-          const uint32_t bw = *(const uint32_t*)(w.b1 + 2 * pp);
-          uint32_t o = pack_bf16x2(d[0] + lo_bf(bw), d[1] + hi_bf(bw));  // F.linear's rounding point
-          if (2 * pp >= QW) {  // fc1 rows: gelu on the bf16 value, rounded again (layers.py:24-25,137)
-            const md_f32x2 g = gelu_tanh_f32x2(md_f32x2{lo_bf(o), hi_bf(o)});
-            o = pack_bf16x2(g[0], g[1]);
-          }
-          st_coh32(p.act + 2 * pp, o);
+        for (int e = 0; e < 4; ++e) sv += qv[2 * e] * lo_bf(kk[e]) + qv[2 * e + 1] * hi_bf(kk[e]);
+        sv += __shfl_xor(sv, 1, 64);
+        sv += __shfl_xor(sv, 2, 64);
+        sv += __shfl_xor(sv, 4, 64);
+        if (j < j1) {
+          if (c == 0) sc[j - j0] = sv;
+          mx = fmaxf(mx, sv);
         }
       }
-    }
-    stamp();
-    bar.arrive_and_wait();
-    stamp();
-
-    // ================= phase B: attention partials, one (head, key slice) per workgroup ==============================
-    {
-      const int chunk = (L + B1_SLICES - 1) / B1_SLICES;
-      for (int idx = blockIdx.x; idx < p.n_heads * B1_SLICES; idx += gridDim.x) {
-        const int h = idx / B1_SLICES, sl = idx % B1_SLICES;
-        const int j0 = sl * chunk, j1 = min(L, j0 + chunk);
-        bf16_t* kb = p.kslab + (int64_t)l * p.layer_stride + (int64_t)h * p.ctx * 64;
-        bf16_t* vb = p.vslab + (int64_t)l * p.layer_stride + (int64_t)h * p.ctx * 64;
-        float* out = p.part + (int64_t)idx * B1_PART;
-        __syncthreads();  // LDS reuse across iterations
-        if (j0 >= j1) {   // no keys in this slice
-          if (tid < B1_PART) st_coh32(out + tid, tid == 0 ? 0xff800000u : 0u);
-          continue;
-        }
-        // rotated q (every slice needs it) and, for the slice that holds the new position, rotated k and v (rope.py:20-48)
-        {
-          const int half = p.rot >> 1;
-          auto act_at = [&](int col) -> float {  // one bf16 of the fused row, through a coherent 4-byte load
-            const uint32_t wv = ld_coh32(p.act + (col & ~1));
-            return (col & 1) ? hi_bf(wv) : lo_bf(wv);
-          };
-          if (tid < 2 * half) {
-            const int which = tid / half, j = tid % half;
-            const int base = (which ? (p.n_heads + h) : h) * 64;
-            const float re = act_at(base + j), im = act_at(base + half + j);
-            const float cs = p.freqs[((int64_t)pos * half + j) * 2], sn = p.freqs[((int64_t)pos * half + j) * 2 + 1];
-            newrow[which][2 * j] = f2bf(__fsub_rn(__fmul_rn(re, cs), __fmul_rn(im, sn)));
-            newrow[which][2 * j + 1] = f2bf(__fadd_rn(__fmul_rn(re, sn), __fmul_rn(im, cs)));
-          } else if (tid >= 64 && tid < 64 + 2 * (64 - p.rot)) {
-            const int t2 = tid - 64, which = t2 / (64 - p.rot), i = p.rot + t2 % (64 - p.rot);
-            newrow[which][i] = f2bf(act_at((which ? (p.n_heads + h) : h) * 64 + i));
-          } else if (tid >= 192) {
-            newrow[2][tid - 192] = f2bf(act_at((2 * p.n_heads + h) * 64 + tid - 192));
-          }
-        }
-        __syncthreads();
-        const bool has_new = pos >= j0 && pos < j1;
-        if (has_new) {
-          if (tid < 64) kb[(int64_t)pos * 64 + tid] = newrow[1][tid];
-          else if (tid < 128) vb[(int64_t)pos * 64 + tid - 64] = newrow[2][tid - 64];
-        }
-        const int g = tid >> 3, c = tid & 7;  // 128 key groups x 8 lanes per 128-byte row
-        float qv[8];
-        {
-          const u32x4 qq = *(const u32x4*)(&newrow[0][c * 8]);
+      mx = block_max<NWV>(mx, red);  // (its barriers also publish sc[])
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      float lsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const int j = j0 + g + NG * i;
+        if (j < j1) {
+          const u32x4 vv = (j == pos) ? *(const u32x4*)(&newrow[2][c * 8]) : vq[i];
+          const float pj = __builtin_amdgcn_exp2f(sc[j - j0] - mx);
+          if (c == 0) lsum += pj;
+          const float pr = bf2f(f2bf(pj));  // probabilities enter the second contraction as bf16
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            qv[2 * e] = lo_bf(qq[e]) * p.scale_log2;
-            qv[2 * e + 1] = hi_bf(qq[e]) * p.scale_log2;
+            acc[2 * e] += pr * lo_bf(vv[e]);
+            acc[2 * e + 1] += pr * hi_bf(vv[e]);
           }
         }
-        constexpr int NG = NT / 8, KPT = (B1_MAX_KEYS + NG - 1) / NG;  // key groups; keys per group at most
-        u32x4 kq[KPT], vq[KPT];
+      }
+      const float ltot = block_sum<NWV>(lsum, red);
+      // P.V: the 8 key groups of a wave through a lane butterfly, the waves through LDS
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-          const int j = min(j0 + g + NG * i, j1 - 1);
-          kq[i] = *(const u32x4*)(kb + (int64_t)j * 64 + c * 8);
-          vq[i] = *(const u32x4*)(vb + (int64_t)j * 64 + c * 8);
+      for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8, 64);
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv_lds[wave * 64 + lane * 8 + e] = acc[e];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float o = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NWV; ++ww) o += pv_lds[ww * 64 + tid];
+        st_coh32(out + 4 + tid, __float_as_uint(o));
+      } else if (tid == 64) {
+        st_coh32(out, __float_as_uint(mx));
+      } else if (tid == 65) {
+        st_coh32(out + 1, __float_as_uint(ltot));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NFQ; ++i) {
+      const int ch = tid + NT * i;
+      if (ch < (FF >> 3)) *(u32x4*)(lds_ff + 16 * ch) = ffq[i];
+    }
+    stamp();
+    bar.arrive();  // (also publishes lds_ff to every wave)
+    // fc2 needs gelu(fc1), not the attention: its rows stream while the barrier collects the attention partials
+    const bf16_t *prow[2], *frow[2];
+    int kp = 0, kf = 0;
+    const char *actp = lds_row, *actf = lds_ff;
+    auto set_rows_c = [&](int q) {
+      const int pp = blockIdx.x + gridDim.x * min(q, npw_c - 1);
+      const int cp0 = half ? nchd / 2 : 0, cp1 = half ? nchd : nchd / 2;
+      prow[0] = w.wp + (int64_t)(2 * pp) * p.ldp + 512 * cp0;
+      prow[1] = prow[0] + p.ldp;
+      kp = max(min(D, 512 * cp1) - 512 * cp0, 0);
+      actp = lds_row + 512 * cp0 * 2;
+      const int c0 = half ? nch2 / 2 : 0, c1 = half ? nch2 : nch2 / 2;
+      frow[0] = w.w2 + (int64_t)(2 * pp) * p.ld2 + 512 * c0;
+      frow[1] = frow[0] + p.ld2;
+      kf = max(min(FF, 512 * c1) - 512 * c0, 0);
+      actf = lds_ff + 512 * c0 * 2;
+    };
+    for (int q0 = 0; q0 < npw_c; q0 += PPP) {
+      const int q = q0 + qw;
+      if (q < npw_c) {
+        set_rows_c(q);
+        float df[2] = {0.f, 0.f};
+        if (kf > 0) {
+          Gemv<2, 4> gf;
+          gf.prime(frow, kf);
+          gf.run(frow, kf, actf, df);
         }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-          const int j = j0 + g + NG * i;
-          const u32x4 kk = (j == pos) ? *(const u32x4*)(&newrow[1][c * 8]) : kq[i];  // the new key is not in global memory for this CU yet
-          float sv = 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sv += qv[2 * e] * lo_bf(kk[e]) + qv[2 * e + 1] * hi_bf(kk[e]);
-          sv += __shfl_xor(sv, 1, 64);
-          sv += __shfl_xor(sv, 2, 64);
-          sv += __shfl_xor(sv, 4, 64);
-          if (j < j1) {
-            if (c == 0) sc[j - j0] = sv;
-            mx = fmaxf(mx, sv);
-          }
-        }
-        mx = block_max<NWV>(mx, red);  // (its barriers also publish sc[])
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        float lsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-          const int j = j0 + g + NG * i;
-          if (j < j1) {
-            const u32x4 vv = (j == pos) ? *(const u32x4*)(&newrow[2][c * 8]) : vq[i];
-            const float pj = __builtin_amdgcn_exp2f(sc[j - j0] - mx);
-            if (c == 0) lsum += pj;
-            const float pr = bf2f(f2bf(pj));  // probabilities enter the second contraction as bf16
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc[2 * e] += pr * lo_bf(vv[e]);
-              acc[2 * e + 1] += pr * hi_bf(vv[e]);
-            }
-          }
-        }
-        const float ltot = block_sum<NWV>(lsum, red);
-        // P.V: the 8 key groups of a wave through a lane butterfly, the 16 waves through LDS
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          acc[e] += __shfl_xor(acc[e], 8, 64);
-          acc[e] += __shfl_xor(acc[e], 16, 64);
-          acc[e] += __shfl_xor(acc[e], 32, 64);
-        }
-        float* pv = (float*)lds_ff;  // [16 waves][64]
-        if (lane < 8) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pv[wave * 64 + lane * 8 + e] = acc[e];
-        }
-        __syncthreads();
-        if (tid < 64) {
-          float o = 0.f;
-#pragma unroll
-          for (int ww = 0; ww < NWV; ++ww) o += pv[ww * 64 + tid];
-          st_coh32(out + 2 + tid, __float_as_uint(o));
-        } else if (tid == 64) {
-          st_coh32(out, __float_as_uint(mx));
-        } else if (tid == 65) {
-          st_coh32(out + 1, __float_as_uint(ltot));
+        if (lane == 0) {
+          fc2_part[q][half][0] = df[0];
+          fc2_part[q][half][1] = df[1];
         }
       }
     }
-    stamp();
-    bar.arrive_and_wait();
+    Gemv<2, 2> gp;  // proj rows of the first pass: in flight across the wait and the combination of the partials
+    gp.zero();
+    if (qw < npw_c) {
+      set_rows_c(qw);
+      if (kp > 0) gp.prime(prow, kp);
+    }
+    // the residual operand and the biases of the first pass's pairs
+    uint32_t xo0 = 0, bpw0 = 0, b2w0 = 0;
+    if (tid < PPP && tid < npw_c) {
+      const int pc = blockIdx.x + gridDim.x * tid;
+      xo0 = ld_coh32(xc + 2 * pc);
+      bpw0 = *(const uint32_t*)(w.bp + 2 * pc);
+      b2w0 = *(const uint32_t*)(w.b2 + 2 * pc);
+    }
+    bar.wait();
     stamp();
 
-    // ================= phase C: attention row + gelu(fc1) into LDS; proj and fc2 row pairs, both residual adds =========
+    // ================= phase C: attention row into LDS; proj row pairs, both residual adds ============================
     {
-      // workgroup b owns output pairs b + gridDim q; TWO waves share a pair: the first takes its proj rows and the first
-      // c_split chunks of its fc2 rows, the second the rest of fc2 (equal chunk counts), so all waves stream in one pass
-      // at 2B / 256 CUs (4 pairs per workgroup, 8 waves)
-      const int npc = D >> 1;
-      const int npw = blockIdx.x < npc ? (npc - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-      const int nchd = (D + 511) / 512, nch2 = (FF + 511) / 512;
-      const int c_split = max(0, (nch2 - nchd) / 2);
-      constexpr int PPP = NWV / 2;  // pairs per pass
-      const int qw = wave >> 1, half = wave & 1;
-      const bf16_t *prow[2], *frow[2];
-      int kf = 0;
-      const char* actf = lds_ff;
-      auto set_rows_c = [&](int q) {
-        const int pp = blockIdx.x + gridDim.x * min(q, npw - 1);
-        prow[0] = w.wp + (int64_t)(2 * pp) * p.ldp;
-        prow[1] = prow[0] + p.ldp;
-        const int k0 = half ? 512 * c_split : 0, k1 = half ? FF : min(FF, 512 * c_split);
-        frow[0] = w.w2 + (int64_t)(2 * pp) * p.ld2 + k0;
-        frow[1] = frow[0] + p.ld2;
-        kf = max(k1 - k0, 0);
-        actf = lds_ff + k0 * 2;
+      // one round trip: the slice statistics and this thread's four features of all slices of its head
+      const __amdgpu_buffer_rsrc_t r_part = coh_rsrc(p.part);
+      u32x4 po[B1_SLICES];
+      for (int i = tid; i < n_items; i += NT) {
+        const uint64_t q = ld_coh64(p.part + (int64_t)i * B1_PART);
+        head_m[i] = __uint_as_float((uint32_t)q);
+        head_l[i] = __uint_as_float((uint32_t)(q >> 32));
+      }
+      auto load_po = [&](int e0) {
+        const int e = 4 * e0, h = e >> 6, d = e & 63;
+#pragma unroll
+        for (int s_ = 0; s_ < B1_SLICES; ++s_) po[s_] = ld_coh128(r_part, ((h * B1_SLICES + s_) * B1_PART + 4 + d) * 4);
       };
-      Gemv<2, 4> gp, gf;
-      if (qw < npw) {  // before the prologue: the weights do not depend on it
-        set_rows_c(qw);
-        if (half == 0) gp.prime(prow, D);
-        if (kf > 0) gf.prime(frow, kf);
-      }
-      const int nhs = p.n_heads * B1_SLICES;
-      for (int i = tid; i < nhs; i += NT) {
-        head_m[i] = __uint_as_float(ld_coh32(p.part + (int64_t)i * B1_PART));
-        head_l[i] = __uint_as_float(ld_coh32(p.part + (int64_t)i * B1_PART + 1));
-      }
-      for (int i = tid; i < (FF >> 2); i += NT) {  // 4 bf16 per coherent load
-        const uint64_t q = ld_coh64(p.act + QW + 4 * i);
-        *(uint64_t*)(lds_ff + 8 * i) = q;
+      if (tid < (D >> 2)) {
+        load_po(tid);
+      } else {
+#pragma unroll
+        for (int s_ = 0; s_ < B1_SLICES; ++s_) po[s_] = u32x4{0u, 0u, 0u, 0u};
       }
       __syncthreads();
-      for (int e0 = tid; e0 < (D >> 1); e0 += NT) {  // two features of one head per thread and pass
-        const int e = 2 * e0, h = e >> 6, d = e & 63;
+      for (int e0 = tid; e0 < (D >> 2); e0 += NT) {  // four features of one head per thread and pass
+        if (e0 != tid) load_po(e0);
+        const int e = 4 * e0, h = e >> 6;
         float M = -INFINITY;
 #pragma unroll
         for (int s_ = 0; s_ < B1_SLICES; ++s_) M = fmaxf(M, head_m[h * B1_SLICES + s_]);
-        float Lt = 0.f, o0 = 0.f, o1 = 0.f;
+        float Lt = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s_ = 0; s_ < B1_SLICES; ++s_) {
           const float f = __builtin_amdgcn_exp2f(head_m[h * B1_SLICES + s_] - M);  // empty slice: exp2(-inf) = 0
           Lt += head_l[h * B1_SLICES + s_] * f;
-          const uint64_t q = ld_coh64(p.part + (int64_t)(h * B1_SLICES + s_) * B1_PART + 2 + d);
-          o0 += __uint_as_float((uint32_t)q) * f;
-          o1 += __uint_as_float((uint32_t)(q >> 32)) * f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] += __uint_as_float(po[s_][k]) * f;
         }
         const float inv = Lt > 0.f ? 1.0f / Lt : 0.f;
-        *(uint32_t*)(lds_row + e * 2) = pack_bf16x2(o0 * inv, o1 * inv);
+        *(uint2*)(lds_row + e * 2) = uint2{pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv)};
       }
       __syncthreads();
-      float* part_c = (float*)sc;  // [PPP][3][2]: proj, fc2 first part, fc2 second part  (sc[] is free outside phase B)
-      for (int q0 = 0; q0 < npw; q0 += PPP) {
+      for (int q0 = 0; q0 < npw_c; q0 += PPP) {
         const int q = q0 + qw;
-        float dp[2] = {0.f, 0.f}, df[2] = {0.f, 0.f};
-        if (q < npw) {
+        float dp[2] = {0.f, 0.f};
+        if (q < npw_c) {
           if (q0 > 0) {
             set_rows_c(q);
-            if (half == 0) gp.prime(prow, D);
-            if (kf > 0) gf.prime(frow, kf);
+            if (kp > 0) gp.prime(prow, kp);
           }
-          if (half == 0) gp.run(prow, D, lds_row, dp);
-          if (kf > 0) gf.run(frow, kf, actf, df);
+          if (kp > 0) gp.run(prow, kp, actp, dp);
         }
         if (lane == 0) {
-          if (half == 0) {
-            part_c[(qw * 3) * 2] = dp[0];
-            part_c[(qw * 3) * 2 + 1] = dp[1];
-          }
-          part_c[(qw * 3 + 1 + half) * 2] = df[0];
-          part_c[(qw * 3 + 1 + half) * 2 + 1] = df[1];
+          proj_part[qw][half][0] = dp[0];
+          proj_part[qw][half][1] = dp[1];
         }
         __syncthreads();
-        if (tid < PPP && q0 + tid < npw) {
+        if (tid < PPP && q0 + tid < npw_c) {
           const int pc = blockIdx.x + gridDim.x * (q0 + tid);
-          const float dp0 = part_c[(3 * tid) * 2], dp1 = part_c[(3 * tid) * 2 + 1];
-          const float df0 = part_c[(3 * tid + 1) * 2] + part_c[(3 * tid + 2) * 2];
-          const float df1 = part_c[(3 * tid + 1) * 2 + 1] + part_c[(3 * tid + 2) * 2 + 1];
-          const uint32_t xo = ld_coh32(xc + 2 * pc);
-          const uint32_t bpw = *(const uint32_t*)(w.bp + 2 * pc), b2w = *(const uint32_t*)(w.b2 + 2 * pc);
+          const float dp0 = proj_part[tid][0][0] + proj_part[tid][1][0], dp1 = proj_part[tid][0][1] + proj_part[tid][1][1];
+          const float df0 = fc2_part[q0 + tid][0][0] + fc2_part[q0 + tid][1][0];
+          const float df1 = fc2_part[q0 + tid][0][1] + fc2_part[q0 + tid][1][1];
+          const uint32_t xo = q0 == 0 ? xo0 : ld_coh32(xc + 2 * pc);
+          const uint32_t bpw = q0 == 0 ? bpw0 : *(const uint32_t*)(w.bp + 2 * pc), b2w = q0 == 0 ? b2w0 : *(const uint32_t*)(w.b2 + 2 * pc);
           const uint32_t t1 = pack_bf16x2(dp0 + lo_bf(bpw), dp1 + hi_bf(bpw));
           const uint32_t x1 = pack_bf16x2(lo_bf(xo) + lo_bf(t1), hi_bf(xo) + hi_bf(t1));
           const uint32_t t2 = pack_bf16x2(df0 + lo_bf(b2w), df1 + hi_bf(b2w));
@@ -504,11 +615,93 @@ __global__ __launch_bounds__(64 * NWV) void decode_b1_kernel(const B1Args p) {
       }
     }
     stamp();
-    if (l + 1 < p.n_layers) bar.arrive_and_wait();
+    const bool more = l + 1 < p.n_layers;
+    if (more || p.lm_w) {
+      bar.arrive();
+      // the next phase's first weight rows go out while the barrier collects arrivals
+      if (more) prime_first(npw_a, p.layer[l + 1].w1, p.ld1);
+      else prime_first(npw_d, p.lm_w, p.ld_lm);
+      bar.wait();
+    }
     stamp();
+    xc = xn;
+  }
+
+  // ================= phase D (whole decode step): final layer norm, lm_head rows, argmax ==============================
+  if (p.lm_w) {
+    layer_norm_to_lds(xc, p.post_ln_w, p.post_ln_b);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    run_rows(npw_d, p.lm_w, p.ld_lm, [&](int pp, float d0, float d1) {
+      const uint32_t bw = *(const uint32_t*)(p.lm_b + 2 * pp);
+      const uint32_t o = pack_bf16x2(d0 + lo_bf(bw), d1 + hi_bf(bw));
+      if (lane == 0) *(uint32_t*)(p.logits + 2 * pp) = o;
+      // greedy choice on the bf16 logits, ties -> lowest index, the suppressed id never (argmax_kernel's rule)
+      const float v0 = (2 * pp == p.suppress) ? -INFINITY : lo_bf(o), v1 = (2 * pp + 1 == p.suppress) ? -INFINITY : hi_bf(o);
+      if (v0 > best || (v0 == best && 2 * pp < bi)) {
+        best = v0;
+        bi = 2 * pp;
+      }
+      if (v1 > best || (v1 == best && 2 * pp + 1 < bi)) {
+        best = v1;
+        bi = 2 * pp + 1;
+      }
+    });
+    if (lane == 0) {
+      red[wave] = best;
+      best_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int ww = 1; ww < NWV; ++ww)
+        if (red[ww] > best || (red[ww] == best && best_i[ww] < bi)) {
+          best = red[ww];
+          bi = best_i[ww];
+        }
+      st_coh32(p.part + 2 * blockIdx.x, __float_as_uint(best));
+      st_coh32(p.part + 2 * blockIdx.x + 1, (uint32_t)bi);
+    }
+    bar.arrive();
+    bar.wait();
+    if (blockIdx.x == 0) {
+      best = -INFINITY;
+      bi = 0x7fffffff;
+      for (int i = tid; i < (int)gridDim.x; i += NT) {
+        const float ov = __uint_as_float(ld_coh32(p.part + 2 * i));
+        const int oi = (int)ld_coh32(p.part + 2 * i + 1);
+        if (ov > best || (ov == best && oi < bi)) {
+          best = ov;
+          bi = oi;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      __syncthreads();
+      if (lane == 0) {
+        red[wave] = best;
+        best_i[wave] = bi;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        for (int ww = 1; ww < NWV; ++ww)
+          if (red[ww] > best || (red[ww] == best && best_i[ww] < bi)) {
+            best = red[ww];
+            bi = best_i[ww];
+          }
+        p.next[0] = (bi >= p.vocab) ? 0 : bi;  // an all-NaN row selects nothing: id 0, as argmax_kernel does
+        p.pos_out[0] = pos + 1;
+      }
+    }
   }
   // the next launch continues the barrier targets where this one stopped (every workgroup read the epoch at its start)
-  if (blockIdx.x == 0 && tid == 0) st_coh32(p.sync, bar.base + (unsigned)(3 * p.n_layers - 1));
+  if (blockIdx.x == 0 && tid == 0) st_coh32(p.sync, bar.base + bar.count);
 }
 
 }  // namespace
@@ -520,20 +713,15 @@ extern "C" size_t md_decode_b1_workspace_bytes(const md_text_model* m) {
          ((size_t)m->n_heads * B1_SLICES * B1_PART * 4 + 255) / 256 * 256;
 }
 
-// sync_state: >= 16 KiB of device memory, ZERO when first used and never written by anything else; it carries the barrier
-// counters from one launch to the next.  hidden: bf16 [dim].  x_in: bf16 [dim] (the token embedding).
-extern "C" md_status md_decode_b1_layers(const md_text_model* m, const void* x_in, void* hidden, const int32_t* pos,
-                                         const md_kv_cache* kv, void* workspace, size_t workspace_bytes, void* sync_state,
-                                         void* stream) {
-  MD_CHECK_ARG(m && x_in && hidden && pos && kv && kv->k && kv->v && workspace && sync_state && m->blocks);
+namespace {
+
+md_status b1_fill(const md_text_model* m, const md_kv_cache* kv, const int32_t* pos, void* workspace, void* sync_state, B1Args& a) {
   MD_CHECK_ARG(m->n_layers >= 1 && m->n_layers <= B1_MAX_LAYERS && m->n_heads == m->n_kv_heads && m->dim == m->n_heads * 64);
   MD_CHECK_ARG(m->dim % 8 == 0 && m->dim <= B1_MAX_DIM && m->n_heads <= 64 && kv->ctx <= 2048);
   const md_text_block& b0 = m->blocks[0];
   MD_CHECK_ARG(b0.qkv_fc1.w && b0.qkv_fc1.b && b0.proj.b && b0.fc2.b);
   const int ff = b0.fc1.n;
   MD_CHECK_ARG(ff % 8 == 0 && ff <= B1_MAX_FF && (3 * m->dim + ff) % 2 == 0 && b0.qkv.n == 3 * m->dim);
-  if (workspace_bytes < md_decode_b1_workspace_bytes(m)) return MD_ERR_WORKSPACE;
-  B1Args a;
   for (int l = 0; l < m->n_layers; ++l) {
     const md_text_block& b = m->blocks[l];
     MD_CHECK_ARG(b.qkv_fc1.w && b.qkv_fc1.k_pad == b0.qkv_fc1.k_pad && b.proj.k_pad == b0.proj.k_pad && b.fc2.k_pad == b0.fc2.k_pad);
@@ -564,18 +752,72 @@ extern "C" md_status md_decode_b1_layers(const md_text_model* m, const void* x_i
   a.sync = (unsigned*)sync_state;
   a.eps = 1e-5f;
   a.scale_log2 = 0.125f * 1.4426950408889634f;
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemcpyAsync(a.x[0], x_in, (size_t)m->dim * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return MD_ERR_LAUNCH;
+  a.x_first = nullptr;
+  a.x_last = nullptr;
+  a.token = nullptr;
+  a.wte = a.post_ln_w = a.post_ln_b = a.lm_w = a.lm_b = nullptr;
+  a.ld_lm = a.vocab = 0;
+  a.suppress = -1;
+  a.logits = nullptr;
+  a.next = a.pos_out = nullptr;
+  return MD_OK;
+}
+
+md_status b1_launch(const md_text_model* m, const B1Args& a, hipStream_t s) {
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n >= 8 ? n : 8;
   }();
-  // 8 waves per workgroup (two per SIMD, 256 registers each); MD_B1_WAVES=16: the four-per-SIMD variant (spills) for A/B runs
-  static const int nwv = [] { const char* e = getenv("MD_B1_WAVES"); return (e && atoi(e) == 16) ? 16 : 8; }();
-  if (nwv == 8) hipLaunchKernelGGL(decode_b1_kernel<8>, dim3(n_cu), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL(decode_b1_kernel<16>, dim3(n_cu), dim3(1024), 0, s, a);
-  MD_TRY(md_launch_status());
-  if (hipMemcpyAsync(hidden, a.x[m->n_layers & 1], (size_t)m->dim * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return MD_ERR_LAUNCH;
+  // 8 waves per workgroup: two per SIMD, 256 registers each (16 waves at 128 registers spill the weight rings: 1.39 ms per
+  // token against 0.84, profiles/r02_decode_b1_persistent_phase_times.txt)
+  MD_CHECK_ARG((m->dim / 2 + n_cu - 1) / n_cu <= B1_MAX_Q);            // fc2 partials of a workgroup's pairs live in LDS
+  MD_CHECK_ARG(m->n_heads * B1_SLICES * B1_PART >= 2 * n_cu);          // the argmax candidates reuse the attention partials' buffer
+  hipLaunchKernelGGL(decode_b1_kernel<8>, dim3(n_cu), dim3(512), 0, s, a);
+  return md_launch_status();
+}
+
+}  // namespace
+
+// sync_state: >= 16 KiB of device memory, ZERO when first used and never written by anything else; it carries the barrier
+// counters from one launch to the next.  hidden: bf16 [dim].  x_in: bf16 [dim] (the token embedding; may equal hidden).
+extern "C" md_status md_decode_b1_layers(const md_text_model* m, const void* x_in, void* hidden, const int32_t* pos,
+                                         const md_kv_cache* kv, void* workspace, size_t workspace_bytes, void* sync_state,
+                                         void* stream) {
+  MD_CHECK_ARG(m && x_in && hidden && pos && kv && kv->k && kv->v && workspace && sync_state && m->blocks);
+  if (workspace_bytes < md_decode_b1_workspace_bytes(m)) return MD_ERR_WORKSPACE;
+  B1Args a;
+  MD_TRY(b1_fill(m, kv, pos, workspace, sync_state, a));
+  a.x_first = (const bf16_t*)x_in;
+  // (x_in == hidden is allowed: with one block the in-place update would race, so only then go through the workspace)
+  a.x_last = (m->n_layers > 1 || x_in != hidden) ? (bf16_t*)hidden : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  MD_TRY(b1_launch(m, a, s));
+  if (!a.x_last && hipMemcpyAsync(hidden, a.x[m->n_layers & 1], (size_t)m->dim * 2, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return MD_ERR_LAUNCH;
   return MD_OK;
+}
+
+// internal (api.hip): the whole greedy decode step of one sequence in the one launch
+md_status md_decode_b1_step(const md_text_model* m, const int32_t* token, int32_t* next, int32_t* pos, const md_kv_cache* kv,
+                            int32_t suppress_id, void* logits, void* workspace, size_t workspace_bytes, void* sync_state,
+                            hipStream_t s) {
+  MD_CHECK_ARG(m && token && next && pos && kv && kv->k && kv->v && logits && workspace && sync_state && m->blocks);
+  MD_CHECK_ARG(m->wte && m->post_ln.w && m->post_ln.b && m->lm_head.w && m->lm_head.b && m->vocab % 2 == 0 && m->lm_head.n == m->vocab);
+  if (workspace_bytes < md_decode_b1_workspace_bytes(m)) return MD_ERR_WORKSPACE;
+  B1Args a;
+  MD_TRY(b1_fill(m, kv, pos, workspace, sync_state, a));
+  a.token = token;
+  a.wte = (const bf16_t*)m->wte;
+  a.post_ln_w = (const bf16_t*)m->post_ln.w;
+  a.post_ln_b = (const bf16_t*)m->post_ln.b;
+  a.lm_w = (const bf16_t*)m->lm_head.w;
+  a.lm_b = (const bf16_t*)m->lm_head.b;
+  a.ld_lm = m->lm_head.k_pad;
+  a.vocab = m->vocab;
+  a.suppress = suppress_id;
+  a.logits = (bf16_t*)logits;
+  a.next = next;
+  a.pos_out = pos;
+  return b1_launch(m, a, s);
 }

@@ -31,7 +31,7 @@ namespace {
 constexpr int B1_MAX_LAYERS = 32;
 constexpr int B1_SLICES = 8;        // key slices per head
 constexpr int B1_PART = 68;         // floats per attention partial: max, sum, two pad words, out[64] (16-byte aligned)
-constexpr unsigned B1_SPIN_LIMIT = 4000000u;
+constexpr unsigned B1_SPIN_LIMIT = 400000u;
 
 struct B1Layer {
   const bf16_t *ln_w, *ln_b, *w1, *b1, *wp, *bp, *w2, *b2;
@@ -80,35 +80,37 @@ __device__ __forceinline__ void st_coh32(void* p, uint32_t v) {
   __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Grid barrier: one arrival counter per XCD (workgroup b runs on XCD b % 8), the last arrival of an XCD arrives at the
-// top-level counter, the last of those publishes the flag.  Counters only grow: targets are offsets from the epoch read
-// at kernel start.  Spins are bounded: a barrier that times out raises the error word and lets the kernel finish.
+// Grid barrier without atomics: workgroup b publishes the barrier's number in ITS word of a flag array once its stores
+// are acknowledged; everybody polls the whole array (one 4-byte coherent load per lane, gridDim / 64 waves) until every
+// word has reached the number.  Round trips on the critical path: store acknowledgement, flag store, one poll -- the
+// counter tree this replaces (per-XCD counter, top-level counter, flag) had two atomic round trips more
+// (profiles/r02_decode_b1_persistent_phase_times.txt).  Numbers only grow: targets are offsets from the epoch read at
+// kernel start.  Spins are bounded: a barrier that times out raises the error word and lets the kernel finish.
+// arrive() and wait() are separate calls: work that depends on neither side of the barrier (weight rows, K / V rows of
+// earlier tokens) goes between them.
+// Words of the sync state: [0] epoch, [64 * 11] error, [64 * 12] stamp switch, [1024 + b] flag of workgroup b,
+// stamps from word 2048.
+constexpr int B1_FLAG_WORD = 1024, B1_STAMP_WORD = 2048, B1_MAX_WG = 1024;
 struct GridBarrier {
   unsigned* sync;
   unsigned base;
   unsigned count = 0;
   unsigned target = 0;
-  // arrive: this workgroup's stores are out; wait: everybody's are.  Work that depends on neither side of the barrier
-  // (weight rows, K / V rows of earlier tokens) goes between the two calls.
   __device__ void arrive() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this workgroup's stores have been issued and acknowledged
     __syncthreads();
     ++count;
     target = base + count;
-    if (threadIdx.x == 0) {
-      const int nwg = gridDim.x, xcd = blockIdx.x & 7, per = (nwg + 7 - xcd) / 8, groups = nwg < 8 ? nwg : 8;
-      const unsigned a1 = __hip_atomic_fetch_add(sync + 64 * (1 + xcd), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a1 + 1u == (unsigned)per * target) {
-        const unsigned a2 = __hip_atomic_fetch_add(sync + 64 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a2 + 1u == (unsigned)groups * target)
-          __hip_atomic_store(sync + 64 * 10, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(sync + B1_FLAG_WORD + blockIdx.x, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ void wait() {
-    if (threadIdx.x == 0) {
+    const int nwg = gridDim.x;
+    for (int i0 = (threadIdx.x >> 6) * 64; i0 < nwg; i0 += blockDim.x) {  // wave w: flags [64 w, 64 w + 64) (+ blockDim ...)
+      const int i = i0 + (threadIdx.x & 63);
       unsigned spins = 0;
-      while ((int)(__hip_atomic_load(sync + 64 * 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      while (true) {
+        const bool ok = i >= nwg || (int)(__hip_atomic_load(sync + B1_FLAG_WORD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+        if (__all(ok)) break;
         if (++spins > B1_SPIN_LIMIT) {
           __hip_atomic_store(sync + 64 * 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
@@ -219,14 +221,14 @@ __global__ __launch_bounds__(64 * NWV) void decode_b1_kernel(const B1Args p) {
   constexpr int NT = 64 * NWV;
   GridBarrier bar{p.sync, ld_coh32(p.sync)};
   // measurement hook: with word 768 of the sync state non-zero, workgroup 0 stamps the 100 MHz real-time counter at
-  // every phase boundary into words 1024.. (two per stamp)
+  // every phase boundary into words 2048.. (two per stamp)
   const bool stamp_on = blockIdx.x == 0 && tid == 0 && ld_coh32(p.sync + 64 * 12) != 0u;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (stamp_on && n_stamp < 1400) {
+    if (stamp_on && n_stamp < 1000) {
       const uint64_t t = __builtin_amdgcn_s_memrealtime();
-      p.sync[1024 + 2 * n_stamp] = (unsigned)t;
-      p.sync[1024 + 2 * n_stamp + 1] = (unsigned)(t >> 32);
+      p.sync[B1_STAMP_WORD + 2 * n_stamp] = (unsigned)t;
+      p.sync[B1_STAMP_WORD + 2 * n_stamp + 1] = (unsigned)(t >> 32);
       ++n_stamp;
     }
   };
@@ -771,6 +773,7 @@ md_status b1_launch(const md_text_model* m, const B1Args& a, hipStream_t s) {
   }();
   // 8 waves per workgroup: two per SIMD, 256 registers each (16 waves at 128 registers spill the weight rings: 1.39 ms per
   // token against 0.84, profiles/r02_decode_b1_persistent_phase_times.txt)
+  MD_CHECK_ARG(n_cu <= B1_MAX_WG);
   MD_CHECK_ARG((m->dim / 2 + n_cu - 1) / n_cu <= B1_MAX_Q);            // fc2 partials of a workgroup's pairs live in LDS
   MD_CHECK_ARG(m->n_heads * B1_SLICES * B1_PART >= 2 * n_cu);          // the argmax candidates reuse the attention partials' buffer
   hipLaunchKernelGGL(decode_b1_kernel<8>, dim3(n_cu), dim3(512), 0, s, a);

@@ -127,6 +127,8 @@ class MoondreamModel:
         # all decoder blocks; False = the batched kernels at one row (bit-identical to a row of a batch)
         self.single_sequence_kernel = True
         self._b1_sync = None  # barrier state of that kernel: zeroed once, then owned by it
+        # batch_generate over raw images: image prefix + prompt in one decoder pass (False: the reference's two passes)
+        self.fused_prefill = True
         if setup_caches:
             self._setup_caches(max_batch)
 
@@ -669,6 +671,33 @@ class MoondreamModel:
                 raise ValueError("image must be a PIL Image or EncodedImage")
         mark("start")
         pos = None
+        if len(raw_idx) == b and self.fused_prefill:
+            # Every image is raw: image prefix and prompt go through the decoder in ONE pass per group of equal-length
+            # prompts ([bos | 729 image embeddings | prompt] at position 0).  The attention kernels evaluate the
+            # reference's mask rule per element (bidirectional inside the first 730 positions, causal after), so this is
+            # the same computation as the reference's two passes (moondream.py:228-262 then 280-321) up to accumulation
+            # order -- one pass over the weights saved (fused_prefill = False keeps the two passes).
+            img_emb = self._run_vision_encoder_batch(images, mark)
+            mark("vision")
+            bos = self._embed(torch.full((b, 1), self.config.tokenizer.bos_id, dtype=torch.int32))
+            first = torch.empty(b, dtype=torch.int32, device=self._device)
+            hidden_last = torch.empty(b, self.config.text.dim, dtype=BF16, device=self._device)
+            next_pos = [0] * b
+            g0 = 0
+            while g0 < b:
+                g1 = g0
+                while g1 < b and len(prompts[g1]) == len(prompts[g0]):
+                    g1 += 1
+                pe = self._embed(torch.tensor(prompts[g0:g1], dtype=torch.int32))
+                x = torch.cat([bos[g0:g1], img_emb[g0:g1], pe], dim=1)
+                hidden = self._text_forward(x, 0, g0, lora=lora)
+                first[g0:g1] = self._pick(self._lm_head(hidden), 0.0, 0.0)
+                hidden_last[g0:g1] = hidden[:, -1, :]
+                next_pos[g0:g1] = [x.shape[1]] * (g1 - g0)
+                g0 = g1
+            mark("image_prefill")
+            mark("prompt_prefill")
+            return order, first, hidden_last, next_pos
         if raw_idx:
             img_emb = self._run_vision_encoder_batch([images[i] for i in raw_idx], mark)
             mark("vision")

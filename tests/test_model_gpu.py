@@ -109,6 +109,35 @@ def test_batched_equals_sequential_and_reference(tiny):
         assert batched[i] == model.batch_generate_ids([images[i]], [prompts[i]], max_tokens=n)[0]
 
 
+def test_fused_prefill_equals_two_passes(tiny):
+    """batch_generate over raw images prefills [bos | image | prompt] in ONE decoder pass; the reference does two
+    (encode_image, then the prompt: moondream.py:228-262, 280-321).  Same ids (== the reference's on the goldens); K / V
+    rows agree within bf16 noise, not bit for bit: a 5-row pass runs the decode-regime split-K kernels where the fused
+    pass runs the big tiles, and the attention's deferred rescaling is decided per wave of query rows.  Ragged prompts
+    included."""
+    g, cfg, sd, model = tiny
+    images = [golden_image(g, i) for i in range(3)]
+    prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(3)]
+    prompts[1] = prompts[1] + prompts[1][:2]  # a second prompt length -> two groups
+    n = 6
+    try:
+        model.fused_prefill = False
+        a = model.batch_generate_ids(images, prompts, max_tokens=n, ignore_eos=True)
+        ka, va = model._kv_k[:, :3].clone(), model._kv_v[:, :3].clone()
+        model.fused_prefill = True
+        b = model.batch_generate_ids(images, prompts, max_tokens=n, ignore_eos=True)
+        kb, vb = model._kv_k[:, :3], model._kv_v[:, :3]
+    finally:
+        model.fused_prefill = True
+    assert a == b
+    assert a[0] == g["img0.cap.tokens"].tolist()[:n] and a[2] == g["img2.cap.tokens"].tolist()[:n]  # == the reference's
+    n_pos = 730 + min(len(p) for p in prompts)
+    compare("image K rows", kb[:, :, :, :730], ka[:, :, :, :730], 5e-3)
+    compare("image V rows", vb[:, :, :, :730], va[:, :, :, :730], 5e-3)
+    compare("prompt K rows", kb[:, :, :, 730:n_pos], ka[:, :, :, 730:n_pos], 1e-2)
+    compare("prompt V rows", vb[:, :, :, 730:n_pos], va[:, :, :, 730:n_pos], 1e-2)
+
+
 def test_decode_steps_over_more_than_64_sequences(tiny):
     """> 64 sequences per decode step run as blocks of 64 through the decode-regime kernels
     (md_text_forward); every sequence must still produce the reference's ids."""

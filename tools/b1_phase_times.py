@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 w = model._b1_sync.cpu().numpy().astype(np.uint32)
 L = cfg.text.n_layers
 n = 1 + 6 * L
-t = np.array([int(w[1024 + 2 * i]) | (int(w[1025 + 2 * i]) << 32) for i in range(n)], dtype=np.int64) * 10  # ns (100 MHz)
+t = np.array([int(w[2048 + 2 * i]) | (int(w[2049 + 2 * i]) << 32) for i in range(n)], dtype=np.int64) * 10  # ns (100 MHz)
 d = np.diff(t)
 names = ["phase A (ln + qkv|fc1 rows)", "barrier 1 (+ K/V rows requested)", "phase B (attention partials)", "barrier 2 (+ fc2 rows)", "phase C (combine + proj rows)", "barrier 3 (+ next rows requested)"]
 print(f"one token, {L} layers: total {(t[-1] - t[0]) / 1e3:.1f} us (the lm_head phase is not stamped)")

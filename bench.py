@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the auxiliary FP8-decode-weights leg")
+    ap.add_argument("--no-dedup-leg", action="store_true", help="skip the auxiliary identical-crop-dedup leg")
     ap.add_argument("--no-graphs", action="store_true", help="launch decode steps eagerly instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true", help="run each step's encode and decode back to back on one stream")
     ap.add_argument("--prompt", choices=["caption", "vqa32"], default="caption",
@@ -441,6 +442,31 @@ def main():
             "images_per_sec": B / dt, "ms_per_step": dt * 1e3, "prompt_tokens": len(vqa_prompts[0]),
             "p50_latency_ms": float(np.median(lat) * 1e3) if lat else None,
         }
+
+    # auxiliary leg, NOT the headline: identical crops of an image encoded once (the bench's 378 x 378 images have
+    # tiling (1, 1): their local crop is byte-identical to the global crop).  The reference encodes both, so `value`
+    # above does too; this leg only shows what the opt-in saves, with the ids checked equal to the timed step's.
+    if world == 1 and not args.no_dedup_leg:
+        model.dedup_identical_crops = True
+        try:
+            run_steps(2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            outd = run_steps(2)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+            same = None
+            if outd and outd[-1] is not None and out and out[-1] is not None:
+                idsd = torch.cat([b.cpu() for b in outd[-1]], 0).tolist()
+                ids16 = torch.cat([b.cpu() for b in out[-1]], 0).tolist()
+                same = sum(a == b for a, b in zip(idsd, ids16))
+            result["dedup_identical_crops"] = {
+                "images_per_sec": B / dt, "ms_per_step": dt * 1e3, "sequences_identical_to_timed_step": same, "of": B,
+                "note": "opt-in (MoondreamModel.dedup_identical_crops): 1 ViT pass per image instead of 2 for images that fit one crop; "
+                        "bit-identical embeddings (tests/test_model_gpu.py); not the reference's work per image, hence not `value`",
+            }
+        finally:
+            model.dedup_identical_crops = False
 
     # auxiliary leg, NOT the headline: the opt-in FP8 weight stream for the decode steps (BASELINE configs[4]); a
     # different numerical mode (tolerance-judged in tests/test_model_gpu.py), so it never feeds `value`

@@ -127,8 +127,12 @@ class MoondreamModel:
         # all decoder blocks; False = the batched kernels at one row (bit-identical to a row of a batch)
         self.single_sequence_kernel = True
         self._b1_sync = None  # barrier state of that kernel: zeroed once, then owned by it
-        # batch_generate over raw images: image prefix + prompt in one decoder pass (False: the reference's two passes)
+        # batch_generate over raw images: image prefix + prompt in one decoder pass (False: the reference's two passes).
+        # Token generation only: detect / point keep the two passes, so that a raw image and its EncodedImage give the
+        # same bits there (the region heads' decisions have no planted margins to absorb a changed accumulation order)
         self.fused_prefill = True
+        # encode byte-identical crops of an image once (images that fit one crop: global == local); off = what the reference does
+        self.dedup_identical_crops = False
         if setup_caches:
             self._setup_caches(max_batch)
 
@@ -389,6 +393,26 @@ class MoondreamModel:
             if mark is not None and i0 == 0:
                 mark("host_tiling")  # phase timing: the GPU has nothing of this batch to run before the first crops exist
             cropped.extend(part)
+            if self.dedup_identical_crops:
+                # An image that is no larger than one crop has tiling (1, 1) and its single local crop holds the same
+                # pixels as the global crop (image_crops.py:124-167: both are the image resized to crop_size).  The
+                # encoder maps equal inputs to equal outputs whatever else is in the launch, so such a crop is encoded
+                # once and its features are used for both positions.  Opt-in: the reference encodes both.
+                uniq, expand = [], []
+                for c, tiling in part:
+                    if tiling == (1, 1) and c.shape[0] == 2 and np.array_equal(c[0], c[1]):
+                        expand += [len(uniq), len(uniq)]
+                        uniq.append(c[:1])
+                    else:
+                        expand += list(range(len(uniq), len(uniq) + c.shape[0]))
+                        uniq.extend(c[k : k + 1] for k in range(c.shape[0]))
+                host = np.concatenate(uniq, axis=0)
+                dev_crops = torch.from_numpy(host).to(self._device, non_blocking=True)
+                f = self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC)
+                if len(expand) != host.shape[0]:
+                    f = f[torch.tensor(expand, dtype=torch.int64, device=self._device)]
+                feat_parts.append(f)
+                continue
             host = np.concatenate([c for c, _ in part], axis=0)
             dev_crops = torch.from_numpy(host).to(self._device, non_blocking=True)
             feat_parts.append(self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC))
@@ -650,7 +674,8 @@ class MoondreamModel:
             out.append(tok)
         return out
 
-    def _prepare_sequences(self, images, prompts: Sequence[Sequence[int]], mark=None, lora: Optional[PackedLora] = None):
+    def _prepare_sequences(self, images, prompts: Sequence[Sequence[int]], mark=None, lora: Optional[PackedLora] = None,
+                           fuse: bool = False):
         """Everything before the first generated token, for B (image, prompt-ids) pairs: sequences are
         placed in KV slots in order of prompt length (stable), so that every group of equal-length
         prompts occupies a contiguous slot range; raw images are encoded together and prefilled
@@ -671,7 +696,7 @@ class MoondreamModel:
                 raise ValueError("image must be a PIL Image or EncodedImage")
         mark("start")
         pos = None
-        if len(raw_idx) == b and self.fused_prefill:
+        if len(raw_idx) == b and fuse and self.fused_prefill:
             # Every image is raw: image prefix and prompt go through the decoder in ONE pass per group of equal-length
             # prompts ([bos | 729 image embeddings | prompt] at position 0).  The attention kernels evaluate the
             # reference's mask rule per element (bidirectional inside the first 730 positions, causal after), so this is
@@ -763,7 +788,7 @@ class MoondreamModel:
 
         lora = self._lora({"variant": variant})
         with torch.inference_mode():
-            order, first, _, next_pos = self._prepare_sequences(list(images), prompts, mark, lora)
+            order, first, _, next_pos = self._prepare_sequences(list(images), prompts, mark, lora, fuse=True)
             b = len(order)
             stop = None if ignore_eos else eos
             hist = self._decode_greedy(first, next_pos if len(set(next_pos)) > 1 else next_pos[0], max_tokens,
@@ -809,8 +834,14 @@ class MoondreamModel:
                 enc_s.wait_stream(torch.cuda.current_stream(self._device))
                 with torch.cuda.stream(enc_s):
                     img_emb = self._run_vision_encoder_batch(list(images))
-                    pos = self._prefill_images(img_emb, slot0)
-                    logits, _, p1 = self._prefill_prompts(prompts, pos, slot0)
+                    if self.fused_prefill:  # [bos | image | prompt] in one decoder pass, as in _prepare_sequences
+                        bos = self._embed(torch.full((b, 1), tk.bos_id, dtype=torch.int32))
+                        x = torch.cat([bos, img_emb, self._embed(torch.tensor(prompts, dtype=torch.int32))], dim=1)
+                        logits = self._lm_head(self._text_forward(x, 0, slot0))
+                        p1 = x.shape[1]
+                    else:
+                        pos = self._prefill_images(img_emb, slot0)
+                        logits, _, p1 = self._prefill_prompts(prompts, pos, slot0)
                     first = self._pick(logits, 0.0, 0.0)
                     ev = torch.cuda.Event()
                     ev.record(enc_s)

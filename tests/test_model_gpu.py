@@ -138,6 +138,28 @@ def test_fused_prefill_equals_two_passes(tiny):
     compare("prompt V rows", vb[:, :, :, 730:n_pos], va[:, :, :, 730:n_pos], 1e-2)
 
 
+def test_dedup_identical_crops_is_bit_identical(tiny):
+    """An image that fits one crop has a local crop equal to its global crop; with dedup_identical_crops the encoder
+    runs once per distinct crop.  The projected embeddings must be the same bits as with both crops encoded, in a batch
+    that mixes such images with a multi-crop one."""
+    g, cfg, sd, model = tiny
+    from moondream_amd import synth
+
+    small = [golden_image(g, i) for i in range(2)]
+    assert small[0].size == (378, 378)
+    big = synth.synthetic_image(5, 1).resize((700, 500))
+    images = [small[0], big, small[1]]
+    with torch.inference_mode():
+        try:
+            model.dedup_identical_crops = False
+            a = model._run_vision_encoder_batch(images).clone()
+            model.dedup_identical_crops = True
+            b = model._run_vision_encoder_batch(images).clone()
+        finally:
+            model.dedup_identical_crops = False
+    assert torch.equal(a, b)
+
+
 def test_decode_steps_over_more_than_64_sequences(tiny):
     """> 64 sequences per decode step run as blocks of 64 through the decode-regime kernels
     (md_text_forward); every sequence must still produce the reference's ids."""

@@ -20,6 +20,6 @@ if [[ $STAGE == all || $STAGE == model ]]; then
   echo "model tests rc=$?"; grep -E "passed|failed" gpurun_out/tests_m.log | tail -3; grep -E "^FAILED|^ERROR|bench64 parity|rel-rms vs fp64" gpurun_out/tests_m.log | head -30
 fi
 if [[ $STAGE == all || $STAGE == bench ]]; then
-  timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-vqa-leg --no-fp8-leg --latency-runs 3 > gpurun_out/bench.log 2>&1
+  timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-vqa-leg --no-fp8-leg --no-dedup-leg --latency-runs 3 > gpurun_out/bench.log 2>&1
   tail -1 gpurun_out/bench.log | cut -c1-1800
 fi

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/clockb
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/clockb -o c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vqa-leg --no-fp8-leg --latency-runs 0 --only-timed-steps > $R/gpurun_out/clockb/run.log 2>&1
+timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/clockb -o c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vqa-leg --no-fp8-leg --no-dedup-leg --latency-runs 0 --only-timed-steps > $R/gpurun_out/clockb/run.log 2>&1
 echo "rc=$?"
 cd $R
 python - <<'PY'

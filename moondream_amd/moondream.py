@@ -657,6 +657,16 @@ class MoondreamModel:
                 break
         return hist[: steps + 1]
 
+    def _check_b1_barriers(self):
+        """Call after the tokens of a single-sequence decode have reached the host: the persistent kernel's grid barriers
+        spin with a bound (they need every workgroup resident, which a second such kernel on another stream, or another
+        process on the GPU, can prevent); a barrier that gave up raises the error word and the tokens are not valid."""
+        if self._b1_sync is not None and int(self._b1_sync[64 * 11]) != 0:
+            self._b1_sync[64 * 11] = 0
+            raise _lib.MoondreamHipError(
+                "md_decode_step_b1: a grid barrier timed out (the GPU was shared with another persistent kernel?); "
+                "set single_sequence_kernel = False to decode on the batched kernels")
+
     def _decode_logits(self, b: int) -> torch.Tensor:
         buf = getattr(self, "_logits_buf", None)
         if buf is None or buf.shape[0] < b:
@@ -795,6 +805,8 @@ class MoondreamModel:
                                        tk.answer_id, 0, stop, lora=lora)
             mark("decode")
             cols = hist.t().tolist()
+            if b == 1:
+                self._check_b1_barriers()
             results: List[Optional[List[int]]] = [None] * b
             for slot, src in enumerate(order):
                 results[src] = self._truncate(cols[slot], stop, max_tokens)
@@ -861,6 +873,8 @@ class MoondreamModel:
         hist, done, b = item
         done.synchronize()
         cols = hist.t().tolist()
+        if b == 1:
+            self._check_b1_barriers()
         return [self._truncate(cols[i], eos, max_tokens) for i in range(b)]
 
     def batch_caption(self, images, length: str = "normal", settings: Optional[dict] = None) -> List[str]:
@@ -933,6 +947,7 @@ class MoondreamModel:
                     chunk = min(16, max_tokens - done)
                     hist = self._decode_greedy(first, cur_pos, chunk, self.config.tokenizer.answer_id, 0, None)
                     toks = hist[:, 0].tolist()
+                    self._check_b1_barriers()
                     for tok in toks[:-1]:
                         yield tok
                     done += len(toks) - 1

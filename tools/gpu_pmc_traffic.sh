@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/traffic
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic/$c -o r1 -- python $R/bench.py --steps 1 --warmup 0 --tokens 1 --batch 64 --no-cpu-baseline --no-vqa-leg --no-fp8-leg --no-dedup-leg --latency-runs 0 --no-graphs --no-pipeline --only-timed-steps > $R/gpurun_out/traffic/$c.log 2>&1
+  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic/$c -o r1 -- python $R/bench.py --steps 1 --warmup 0 --tokens 1 --batch 64 --no-cpu-baseline --no-vqa-leg --no-fp8-leg --no-dedup-leg --latency-runs 0 --no-graphs --no-pipeline --only-timed-steps > $R/gpurun_out/traffic/$c.log 2>&1
 done
 cd $R
 python - <<'PY'

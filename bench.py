@@ -372,6 +372,9 @@ def main():
             # is hidden is the host's tiling / launch / D2H time of step i+1 behind the decode kernels of step i
             "host_latency_hiding": "none" if args.no_pipeline else "step i+1's host tiling + encode launches are issued on a second "
                                    "HIP stream while step i decodes (no GPU-side overlap: the GPU is saturated)",
+            # every row of [bos | 729 image embeddings | prompt] goes through every decoder block, as in the reference;
+            # the reference does it as two passes over the weights (encode_image, then the prompt)
+            "prefill": "image prefix + prompt in one decoder pass" if model.fused_prefill else "image prefix, then prompt (two passes)",
         },
         "roofline": {
             "bound": "mfma",

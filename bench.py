@@ -411,6 +411,20 @@ def main():
                     "step waits for first is phase_ms.host_tiling (hidden behind the previous step's decode in the timed region)",
         }
 
+    if args.model == "2b" and phase_ms.get("decode"):
+        # SURVEY 8d's decode roofline: a step reads every decoder + lm_head weight once (2.627 GB) and, per sequence, the
+        # K / V rows of its context (196 608 B per position: 24 layers x 32 heads x 64 x 2 x 2 B); step s attends to
+        # pos + s + 1 keys.  Over the decode phase of the eager step (all kernels of the phase, launch gaps included).
+        p1 = 730 + len(prompt)
+        dec_bytes = sum(2.627e9 + B * (p1 + s_ + 1) * 196608.0 for s_ in range(T))
+        dec_gbs = dec_bytes / (phase_ms["decode"] * 1e-3) / 1e9
+        result["decode_step"] = {
+            "bound": "hbm", "achieved": dec_gbs, "peak": 8000.0, "unit": "GB/s", "frac": dec_gbs / 8000.0,
+            "ms_per_token": phase_ms["decode"] / T,
+            "note": f"{T} lockstep decode steps of {B} sequences: weights 2.627 GB per step + K/V 196608 B per sequence and position "
+                    f"(contexts {p1 + 1}..{p1 + T}); time = the decode phase of one eager step (hipGraph replay in the timed region)",
+        }
+
     # p50 single-image caption latency (B=1), outside the timed region
     lat = []
     one = [images[0]]

@@ -47,3 +47,11 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "moondream_oracle" not in src and "oracle/" not in src, f
+
+
+def test_graft_entry_build_loads_the_library():
+    """The driver's build check: __graft_entry__.build() must succeed on a CPU-only box (cross-compile, dlopen, ABI
+    version).  (It once asserted a stale ABI number.)"""
+    import __graft_entry__ as g
+
+    g.build()

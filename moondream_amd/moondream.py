@@ -566,8 +566,11 @@ class MoondreamModel:
         kv = self._kv_struct(slot0)
         pos_base = torch.tensor(pos_list, dtype=torch.int32, device=self._device)
 
+        # the persistent kernel's static limits (csrc/decode_b1.hip: B1_MAX_DIM / B1_MAX_FF / B1_MAX_LAYERS, head_dim 64,
+        # MHA); anything else decodes on the batched kernels
         b1 = (b == 1 and self.single_sequence_kernel and lora is None and not bool(self.w.text.fp8)
-              and t.n_heads == t.n_kv_heads and t.qkv_dim % 64 == 0)
+              and t.n_heads == t.n_kv_heads and t.qkv_dim % 64 == 0 and t.head_dim == 64 and t.dim <= 4096
+              and t.ff_dim <= 8192 and t.ff_dim % 8 == 0 and t.n_layers <= 32 and t.n_heads <= 64 and t.vocab_size % 2 == 0)
         if b1:
             if self._b1_sync is None:
                 self._b1_sync = torch.zeros(4096, dtype=torch.int32, device=self._device)

@@ -58,3 +58,35 @@ def test_identical_crops_at_378():
     (SURVEY.md section 7); both are still encoded."""
     r = overlap_crop_image(synth.synthetic_image_array(0, 0), overlap_margin=4, max_crops=12)
     assert r["tiling"] == (1, 1) and np.array_equal(r["crops"][0], r["crops"][1])
+
+
+def test_random_sizes_against_the_reference_itself():
+    """Build container only (needs /root/reference): for random image sizes -- portrait, landscape, tiny, larger than the
+    12-tile budget -- this package's select_tiling / overlap_crop_image / reconstruct_from_crops give the SAME tilings,
+    the SAME crop bytes and the SAME stitched grid as the reference's functions (image_crops.py:17-231, PIL branch)."""
+    import importlib.util
+    import pytest
+
+    ref_root = os.environ.get("MOONDREAM_REFERENCE", "/root/reference")
+    path = os.path.join(ref_root, "moondream", "torch", "image_crops.py")
+    if not os.path.isfile(path):
+        pytest.skip("needs the reference checkout (build container)")
+    spec = importlib.util.spec_from_file_location("ref_image_crops", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+
+    rng = np.random.default_rng(7)
+    sizes = [(378, 378), (1, 1), (2, 3000), (3000, 2), (379, 378), (1200, 1600), (4000, 3000), (100, 1000)]
+    sizes += [(int(rng.integers(16, 2200)), int(rng.integers(16, 2200))) for _ in range(12)]
+    for h, w in sizes:
+        assert select_tiling(h, w, 378, 12) == tuple(ref.select_tiling(h, w, 378, 12)), (h, w)
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        a = overlap_crop_image(img, overlap_margin=4, max_crops=12)
+        b = ref.overlap_crop_image(img, overlap_margin=4, max_crops=12)
+        assert tuple(a["tiling"]) == tuple(b["tiling"]), (h, w)
+        assert np.array_equal(np.asarray(a["crops"]), np.asarray(b["crops"])), (h, w)
+        th, tw = a["tiling"]
+        feats = [torch.from_numpy(rng.standard_normal((27, 27, 8)).astype(np.float32)) for _ in range(th * tw)]
+        ra = reconstruct_from_crops(feats, (th, tw), overlap_margin=4, patch_size=1)
+        rb = ref.reconstruct_from_crops(feats, (th, tw), overlap_margin=4, patch_size=1)
+        assert torch.equal(ra, rb), (h, w)

@@ -162,3 +162,39 @@ def test_fp8_fragment_layout_and_scales():
     # quantisation error: half an e4m3 ulp relative to the channel maximum's binade
     err = (q.dequantized()[:n, :k] - w.float()).abs()
     assert float((err / amax[:n, None].clamp_min(1e-30)).max()) <= 2.0 ** -4 + 1e-6
+
+
+def test_reference_config_jsons_load_field_for_field():
+    """Build container only: the reference's shipped JSON configs (moondream/config/config_md2.json, config_md05.json) load
+    through this package's MoondreamConfig.from_dict to the same field values as through the reference's own dataclasses
+    (config.py:5-94), and the dataclass defaults agree too (a config file may omit any field)."""
+    import dataclasses
+    import importlib.util
+    import json
+    import os
+
+    import pytest
+
+    from moondream_amd.config import MoondreamConfig
+
+    ref_root = os.environ.get("MOONDREAM_REFERENCE", "/root/reference")
+    path = os.path.join(ref_root, "moondream", "torch", "config.py")
+    if not os.path.isfile(path):
+        pytest.skip("needs the reference checkout (build container)")
+    spec = importlib.util.spec_from_file_location("ref_config", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+
+    def same(ours, theirs, where):
+        for f in dataclasses.fields(theirs):
+            a, b = getattr(ours, f.name), getattr(theirs, f.name)
+            if dataclasses.is_dataclass(b):
+                same(a, b, f"{where}.{f.name}")
+            else:
+                assert a == b, (where, f.name, a, b)
+
+    same(MoondreamConfig(), ref.MoondreamConfig(), "defaults")
+    for name in ("config_md2.json", "config_md05.json"):
+        with open(os.path.join(ref_root, "moondream", "config", name)) as f:
+            d = json.load(f)
+        same(MoondreamConfig.from_dict(d), ref.MoondreamConfig.from_dict(d), name)

@@ -665,7 +665,8 @@ class MoondreamModel:
         spin with a bound (they need every workgroup resident, which a second such kernel on another stream, or another
         process on the GPU, can prevent); a barrier that gave up raises the error word and the tokens are not valid."""
         if self._b1_sync is not None and int(self._b1_sync[64 * 11]) != 0:
-            self._b1_sync[64 * 11] = 0
+            with torch.inference_mode():  # (the state tensor was created under inference mode)
+                self._b1_sync[64 * 11] = 0
             raise _lib.MoondreamHipError(
                 "md_decode_step_b1: a grid barrier timed out (the GPU was shared with another persistent kernel?); "
                 "set single_sequence_kernel = False to decode on the batched kernels")

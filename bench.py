@@ -70,13 +70,18 @@ def selftest_dist(args):
     assert sd["w"].float().sum().item() == 276.0
     mine = mdist.shard_range(3 * world + 1, rank, world)
     ids = torch.tensor([[i, i + 1] for i in mine], dtype=torch.int32, device=dev).reshape(len(mine), 2)
-    blocks = mdist.gather_token_ids(ids)
+    blocks = mdist.gather_token_ids(ids, n_total=3 * world + 1)
     mdist.barrier()
     t = mdist.max_over_ranks(float(rank), dev)
+    seen = mdist.ranks_seen(dev)
+    per_rank = mdist.gather_floats(float(rank) + 0.5, dev)
+    if os.environ.get("MD_SELFTEST_FAIL_RANK") == str(rank):  # tests: a failing rank must fail the whole launch
+        raise RuntimeError(f"selftest: rank {rank} asked to fail")
     if rank == 0:
         got = torch.cat([b.cpu() for b in blocks], 0)[:, 0].tolist()
         assert got == list(range(3 * world + 1)), got
-        print(json.dumps({"selftest": "dist", "n_gpus": world, "max_rank": t, "items": len(got)}), flush=True)
+        assert per_rank == [r + 0.5 for r in range(world)], per_rank
+        print(json.dumps({"selftest": "dist", "n_gpus": world, "max_rank": t, "items": len(got), "ranks_seen": seen}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -268,7 +273,7 @@ def main():
 
     def finish(ids):
         local_ids = torch.tensor(ids, dtype=torch.int32, device=dev)
-        return mdist.gather_token_ids(local_ids)
+        return mdist.gather_token_ids(local_ids, n_total=n_total)
 
     def run_steps(k, prompts=prompts):
         """k steps = k full passes over this rank's batch.  Pipelined mode overlaps the
@@ -291,7 +296,9 @@ def main():
     torch.cuda.synchronize()
     mdist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = mdist.gather_floats(elapsed / args.steps * 1e3, dev)  # every rank's own clock, on rank 0
     elapsed = mdist.max_over_ranks(elapsed, dev)
+    ranks_seen = mdist.ranks_seen(dev)  # an RCCL all-reduce of ones: the ranks that really took part
     # parity of the timed configuration: the LAST timed step's ids (gathered on rank 0, image order)
     parity = None
     if rank == 0 and out and out[-1] is not None:
@@ -359,6 +366,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
+        "ranks_seen": ranks_seen,
+        "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms] if per_rank_ms else None,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
@@ -530,8 +539,14 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         est, cores, note = cpu_baseline(cfg, sd, args.seed, T)
+        try:
+            host_cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            host_cores = os.cpu_count() or 1
         result["cpu_baseline"] = {
-            "value": est, "unit": "images/s", "cores": cores, "kind": "port",
+            "value": est, "unit": "images/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "cores_note": "cores = the torch thread count used (picked by a short probe: all logical cores is slower on a "
+                          "many-core host); host_cores = the logical cores this process may run on",
             "sample": f"oracle in fast mode = the reference's own ATen calls (bf16 F.linear / SDPA over all 2048 slots), {note}",
             "cross_check": "the unmodified reference on the build container's 8 cores: 0.184 images/s "
                            "(profiles/r02_reference_cpu_timing_build_container.json)",

@@ -456,6 +456,13 @@ md_status md_lm_head(const md_text_model* m, const void* hidden, int32_t batch, 
  * reference as the batched kernels, not bit-identical to them.  Needs the fused qkv|fc1 packing and n_kv_heads ==
  * n_heads, head_dim 64. */
 size_t md_decode_b1_workspace_bytes(const md_text_model* m);
+/* 1 when md_decode_step_b1 / md_decode_b1_layers can run this model with this cache on the current device: every static
+ * limit of the kernel (dims, head layout, ctx <= 2048, fused packing, biases present, no fp8 weights attached) AND one
+ * workgroup per CU of its grid resident at once (occupancy query; its software grid barriers need the whole grid on
+ * the chip).  0: use md_decode_step.  Callers should also keep it off streams that run next to other persistent
+ * kernels: co-residency with ANOTHER kernel's workgroups cannot be queried (a barrier then times out, raises word 704
+ * of sync_state and the step's outputs are invalid -- repeat the step with md_decode_step). */
+int32_t md_decode_step_b1_supported(const md_text_model* m, const md_kv_cache* kv);
 md_status md_decode_b1_layers(const md_text_model* m, const void* x_in, void* hidden, const int32_t* pos,
                               const md_kv_cache* kv, void* workspace, size_t workspace_bytes, void* sync_state,
                               void* stream);

@@ -167,6 +167,7 @@ SIGNATURES = {
     "md_decode_b1_workspace_bytes": (c_size_t, [P(MdTextModel)]),
     "md_decode_b1_layers": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_void_p, P(MdKvCache), c_void_p, c_size_t, c_void_p, c_void_p]),
     "md_decode_step_b1_workspace_bytes": (c_size_t, [P(MdTextModel)]),
+    "md_decode_step_b1_supported": (c_int32, [P(MdTextModel), P(MdKvCache)]),
     "md_decode_step_b1": (C.c_int, [P(MdTextModel), c_void_p, c_void_p, c_void_p, P(MdKvCache), c_int32, c_void_p, c_int64,
                                     c_void_p, c_size_t, c_void_p, c_void_p]),
     "md_decode_workspace_bytes": (c_size_t, [P(MdTextModel), c_int32]),

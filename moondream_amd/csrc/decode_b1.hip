@@ -717,16 +717,14 @@ extern "C" size_t md_decode_b1_workspace_bytes(const md_text_model* m) {
 
 namespace {
 
+bool b1_supported(const md_text_model* m, const md_kv_cache* kv);
+
 md_status b1_fill(const md_text_model* m, const md_kv_cache* kv, const int32_t* pos, void* workspace, void* sync_state, B1Args& a) {
-  MD_CHECK_ARG(m->n_layers >= 1 && m->n_layers <= B1_MAX_LAYERS && m->n_heads == m->n_kv_heads && m->dim == m->n_heads * 64);
-  MD_CHECK_ARG(m->dim % 8 == 0 && m->dim <= B1_MAX_DIM && m->n_heads <= 64 && kv->ctx <= 2048);
+  if (!b1_supported(m, kv)) return MD_ERR_UNSUPPORTED;  // callers ask md_decode_step_b1_supported() first
   const md_text_block& b0 = m->blocks[0];
-  MD_CHECK_ARG(b0.qkv_fc1.w && b0.qkv_fc1.b && b0.proj.b && b0.fc2.b);
   const int ff = b0.fc1.n;
-  MD_CHECK_ARG(ff % 8 == 0 && ff <= B1_MAX_FF && (3 * m->dim + ff) % 2 == 0 && b0.qkv.n == 3 * m->dim);
   for (int l = 0; l < m->n_layers; ++l) {
     const md_text_block& b = m->blocks[l];
-    MD_CHECK_ARG(b.qkv_fc1.w && b.qkv_fc1.k_pad == b0.qkv_fc1.k_pad && b.proj.k_pad == b0.proj.k_pad && b.fc2.k_pad == b0.fc2.k_pad);
     a.layer[l] = B1Layer{(const bf16_t*)b.ln.w,      (const bf16_t*)b.ln.b,   (const bf16_t*)b.qkv_fc1.w, (const bf16_t*)b.qkv_fc1.b,
                          (const bf16_t*)b.proj.w,    (const bf16_t*)b.proj.b, (const bf16_t*)b.fc2.w,     (const bf16_t*)b.fc2.b};
   }
@@ -765,22 +763,67 @@ md_status b1_fill(const md_text_model* m, const md_kv_cache* kv, const int32_t* 
   return MD_OK;
 }
 
+// Per device: the CU count and whether ONE workgroup per CU of decode_b1_kernel<8> can be resident at all (the software
+// grid barriers need the whole grid on the chip; a plain launch of a grid the hardware cannot hold would spin to the
+// bound and raise the error word).  A cooperative launch would only add this same check at +15-19 us per launch.
+struct B1Device {
+  int n_cu = 0;      // 0: not probed yet
+  bool resident = false;
+};
+const B1Device& b1_device() {
+  static B1Device cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  B1Device& d = cache[dev];
+  if (d.n_cu == 0) {
+    int n = 256, per_cu = 0;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_b1_kernel<8>, 512, 0) == hipSuccess;
+    (void)hipGetLastError();
+    d.resident = ok && per_cu >= 1;
+    d.n_cu = n >= 8 ? n : 8;
+  }
+  return d;
+}
+
+// every static limit of the kernel for this model / cache / device, in one place (b1_fill and the public query)
+bool b1_supported(const md_text_model* m, const md_kv_cache* kv) {
+  if (!m || !kv || !m->blocks) return false;
+  const B1Device& d = b1_device();
+  const int n_cu = d.n_cu;
+  if (!d.resident || n_cu > B1_MAX_WG) return false;
+  if (!(m->n_layers >= 1 && m->n_layers <= B1_MAX_LAYERS && m->n_heads == m->n_kv_heads && m->dim == m->n_heads * 64)) return false;
+  if (!(m->dim % 8 == 0 && m->dim <= B1_MAX_DIM && m->n_heads <= 64 && kv->ctx <= 2048)) return false;
+  const md_text_block& b0 = m->blocks[0];
+  if (!(b0.qkv_fc1.w && b0.qkv_fc1.b && b0.proj.b && b0.fc2.b)) return false;
+  const int ff = b0.fc1.n;
+  if (!(ff % 8 == 0 && ff <= B1_MAX_FF && (3 * m->dim + ff) % 2 == 0 && b0.qkv.n == 3 * m->dim)) return false;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const md_text_block& b = m->blocks[l];
+    if (!(b.qkv_fc1.w && b.qkv_fc1.b && b.proj.b && b.fc2.b && b.qkv_fc1.k_pad == b0.qkv_fc1.k_pad &&
+          b.proj.k_pad == b0.proj.k_pad && b.fc2.k_pad == b0.fc2.k_pad))
+      return false;
+  }
+  if ((m->dim / 2 + n_cu - 1) / n_cu > B1_MAX_Q) return false;          // fc2 partials of a workgroup's pairs live in LDS
+  if (m->n_heads * B1_SLICES * B1_PART < 2 * n_cu) return false;        // the argmax candidates reuse the attention partials' buffer
+  return true;
+}
+
 md_status b1_launch(const md_text_model* m, const B1Args& a, hipStream_t s) {
-  static const int n_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n >= 8 ? n : 8;
-  }();
   // 8 waves per workgroup: two per SIMD, 256 registers each (16 waves at 128 registers spill the weight rings: 1.39 ms per
   // token against 0.84, profiles/r02_decode_b1_persistent_phase_times.txt)
-  MD_CHECK_ARG(n_cu <= B1_MAX_WG);
-  MD_CHECK_ARG((m->dim / 2 + n_cu - 1) / n_cu <= B1_MAX_Q);            // fc2 partials of a workgroup's pairs live in LDS
-  MD_CHECK_ARG(m->n_heads * B1_SLICES * B1_PART >= 2 * n_cu);          // the argmax candidates reuse the attention partials' buffer
-  hipLaunchKernelGGL(decode_b1_kernel<8>, dim3(n_cu), dim3(512), 0, s, a);
+  (void)m;
+  hipLaunchKernelGGL(decode_b1_kernel<8>, dim3(b1_device().n_cu), dim3(512), 0, s, a);
   return md_launch_status();
 }
 
 }  // namespace
+
+extern "C" int32_t md_decode_step_b1_supported(const md_text_model* m, const md_kv_cache* kv) {
+  if (!m || !m->wte || !m->post_ln.w || !m->post_ln.b || !m->lm_head.w || !m->lm_head.b || m->vocab % 2 != 0 || m->lm_head.n != m->vocab) return 0;
+  if (m->fp8) return 0;  // the persistent kernel streams the bf16 matrices only
+  return b1_supported(m, kv) ? 1 : 0;
+}
 
 // sync_state: >= 16 KiB of device memory, ZERO when first used and never written by anything else; it carries the barrier
 // counters from one launch to the next.  hidden: bf16 [dim].  x_in: bf16 [dim] (the token embedding; may equal hidden).

@@ -276,7 +276,10 @@ md_status fill(Fp8K& k, const void* a, int64_t lda, const md_linear_fp8* lin, in
   MD_CHECK_ARG(((uintptr_t)lin->scale & 15) == 0);
   k.A = (const bf16_t*)a;
   k.lda = lda;
-  k.Ka = (int)std::min<int64_t>(lda, lin->k_pad) / 8 * 8;  // columns k .. of A are zero padding up to lda
+  // Columns [k, round_up(k, 64)) of A are the producer's zero padding (the bf16 packing pads to 64); nothing past that is
+  // promised to be zero or even to belong to the row (A may be a column slice of a wider fused activation, lda > k_pad),
+  // while k_pad here is rounded to 128: the loader supplies zeros beyond Ka itself.
+  k.Ka = (int)std::min<int64_t>(std::min<int64_t>(lda, lin->k_pad), ((int64_t)lin->k + 63) / 64 * 64) / 8 * 8;
   k.W = (const uint8_t*)lin->w;
   k.scale = lin->scale;
   k.bias = (const bf16_t*)lin->b;

@@ -61,9 +61,16 @@ def relaunch_under_torchrun(n_procs: int, script: str, argv: Sequence[str]) -> O
 
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}", "--max-restarts=0",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
-    return subprocess.call(cmd, env=env)
+    # the ranks inherit this process's stdout / stderr (torchrun does not redirect them), so a failing rank's
+    # traceback is already on the caller's stderr; make the failure itself unmissable and non-zero
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f"{os.path.basename(script)}: a rank of the {n_procs}-process launch failed (torch.distributed.run exit code {rc}); "
+              "its traceback is above", file=sys.stderr, flush=True)
+        return rc if rc > 0 else 1
+    return 0
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:
@@ -110,24 +117,60 @@ def state_dict_template(sd: Dict[str, torch.Tensor]) -> Dict[str, Tuple[Tuple[in
     return {k: (tuple(v.shape), v.dtype) for k, v in sd.items()}
 
 
-def gather_token_ids(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+def gather_token_ids(local: torch.Tensor, dst: int = 0, n_total: Optional[int] = None) -> Optional[List[torch.Tensor]]:
     """local: int32 [B_local, T].  Rank ``dst`` gets the list of every rank's block
-    (in rank order = image order under ``shard_range``); others get None."""
+    (in rank order = image order under ``shard_range``); others get None.
+
+    A GATHER to ``dst`` (not an all-gather: no other rank needs the ids).  Blocks may differ by one row;
+    with ``n_total`` (the number of items ``shard_range`` split) every rank knows every block size and no
+    size exchange is needed, otherwise one tiny all-reduce (MAX) sizes the padded blocks and the true row
+    counts travel in the same gather as one extra row."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [local]
-    world = dist.get_world_size()
-    # block sizes may differ by one row: exchange the row counts first
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    mx = int(max(int(c) for c in counts))
-    pad = torch.zeros(mx, local.shape[1], dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    if dist.get_rank() != dst:
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if n_total is not None:
+        counts = [len(shard_range(n_total, r, world)) for r in range(world)]
+        assert counts[rank] == local.shape[0], (counts, rank, local.shape)
+        mx = max(counts)
+    else:
+        counts = None
+        t = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mx = int(t[0])
+    # row 0 carries this rank's row count, rows 1.. the ids (zero padded to the largest block)
+    pad = torch.zeros(mx + 1, max(1, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[0, 0] = local.shape[0]
+    pad[1 : 1 + local.shape[0], : local.shape[1]] = local
+    bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
         return None
-    return [b[: int(c)] for b, c in zip(bufs, counts)]
+    out = []
+    for r, b in enumerate(bufs):
+        c = int(b[0, 0])
+        if counts is not None and c != counts[r]:
+            raise RuntimeError(f"rank {r} sent {c} rows, shard_range says {counts[r]}")
+        out.append(b[1 : 1 + c, : local.shape[1]])
+    return out
+
+
+def ranks_seen(device) -> int:
+    """An all-reduce (SUM) of ones: how many ranks actually took part in the collectives of this run."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t[0])
+
+
+def gather_floats(value: float, device, dst: int = 0) -> Optional[List[float]]:
+    """One float per rank, on rank ``dst`` (per-rank timings for the bench line); None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    bufs = [torch.zeros_like(t) for _ in range(dist.get_world_size())] if dist.get_rank() == dst else None
+    dist.gather(t, bufs, dst=dst)
+    return [float(b[0]) for b in bufs] if bufs is not None else None
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -127,6 +127,7 @@ class MoondreamModel:
         # all decoder blocks; False = the batched kernels at one row (bit-identical to a row of a batch)
         self.single_sequence_kernel = True
         self._b1_sync = None  # barrier state of that kernel: zeroed once, then owned by it
+        self._b1_used = False
         # batch_generate over raw images: image prefix + prompt in one decoder pass (False: the reference's two passes).
         # Token generation only: detect / point keep the two passes, so that a raw image and its EncodedImage give the
         # same bits there (the region heads' decisions have no planted margins to absorb a changed accumulation order)
@@ -212,9 +213,11 @@ class MoondreamModel:
         return self._variants[vid]
 
     def enable_fp8_decode(self, on: bool = True):
-        """Opt-in numerical mode (BASELINE configs[4]): decode steps (launches of <= 64 rows) stream FP8 e4m3fn copies
-        of the decoder weights -- half the bytes of the bandwidth-bound decode step -- with bf16 activations and fp32
-        accumulation; prefill, the vision path and the KV cache stay bf16.  Outputs are judged by tolerance against
+        """Opt-in numerical mode (BASELINE configs[4]): every decoder launch of <= 64 rows streams FP8 e4m3fn copies of
+        the decoder weights -- half the bytes of the bandwidth-bound decode step -- with bf16 activations and fp32
+        accumulation.  That is every decode step, and also any SHORT prefill (a text-only prompt, the prompt pass of the
+        two-pass path at batch 1) and the lm_head of a prompt prefill of <= 64 sequences; the 730-row image prefill, the
+        vision path and the KV cache stay bf16.  Outputs are judged by tolerance against
         the bf16 path (tests/test_model_gpu.py), not bit parity; off by default."""
         if on:
             self.w.enable_fp8_decode()
@@ -273,11 +276,11 @@ class MoondreamModel:
     def _causal_text_struct(self):
         """The decoder description with an empty bidirectional prefix: the plain causal
         mask the reference builds for a text-only query (moondream.py:571-575)."""
-        st = getattr(self, "_text_causal", None)
-        if st is None:
-            st = type(self.w.text).from_buffer_copy(self.w.text)
-            st.prefix_len = 0
-            self._text_causal = st
+        # rebuilt on every call: a cached byte copy would keep a stale ``fp8`` pointer across
+        # enable_fp8_decode / disable_fp8_decode (the library reads the struct on the host, during the call)
+        st = type(self.w.text).from_buffer_copy(self.w.text)
+        st.prefix_len = 0
+        self._text_causal = st
         return st
 
     def _text_forward(self, x: torch.Tensor, pos0: Union[int, Sequence[int]], slot0: int = 0, causal: bool = False,
@@ -544,7 +547,30 @@ class MoondreamModel:
 
     def _decode_greedy(self, first: torch.Tensor, pos: Union[int, Sequence[int]], max_tokens: int, suppress_id: int,
                        slot0: int = 0, eos_id: Optional[int] = None, check_every: int = 16,
-                       lora: Optional[PackedLora] = None) -> torch.Tensor:
+                       lora: Optional[PackedLora] = None, allow_b1: bool = True) -> torch.Tensor:
+        """``_decode_greedy_impl`` plus the safety net of the persistent single-sequence kernel: its software grid barriers
+        need every workgroup resident; if one times out (the GPU was shared with another persistent kernel) the kernel
+        raises an error word and finishes with garbage.  That state is fully re-initialised by decoding the same tokens
+        again (K / V rows at positions >= ``pos``, the id history, the position buffer), so the call is repeated on the
+        batched kernels and the persistent kernel is switched off for this model."""
+        hist = self._decode_greedy_impl(first, pos, max_tokens, suppress_id, slot0, eos_id, check_every, lora, allow_b1)
+        if self._b1_used:
+            torch.cuda.current_stream(self._device).synchronize()
+            if int(self._b1_sync[64 * 11]) != 0:
+                import warnings
+
+                with torch.inference_mode():
+                    self._b1_sync[64 * 11] = 0
+                self.single_sequence_kernel = False
+                self._graphs.clear()
+                warnings.warn("md_decode_step_b1: a grid barrier timed out (GPU shared with another persistent kernel?); "
+                              "repeating the decode on the batched kernels and disabling the single-sequence kernel", RuntimeWarning)
+                hist = self._decode_greedy_impl(first, pos, max_tokens, suppress_id, slot0, eos_id, check_every, lora, False)
+        return hist
+
+    def _decode_greedy_impl(self, first: torch.Tensor, pos: Union[int, Sequence[int]], max_tokens: int, suppress_id: int,
+                            slot0: int = 0, eos_id: Optional[int] = None, check_every: int = 16,
+                            lora: Optional[PackedLora] = None, allow_b1: bool = True) -> torch.Tensor:
         """Device-resident greedy loop: returns int32 [steps+1, B] (row 0 = ``first``).
         reference: the generator of moondream.py:471-530 without its per-token host sync.
         ``pos`` is the position of the next token, one int or one per sequence (sequences whose
@@ -558,6 +584,7 @@ class MoondreamModel:
         max_tokens = max(0, min(max_tokens, t.max_context - 1 - max(pos_list)))
         hist = torch.zeros(max_tokens + 1, b, dtype=torch.int32, device=self._device)
         hist[0] = first
+        self._b1_used = False
         if max_tokens == 0:
             return hist
         logits = self._decode_logits(b)
@@ -566,11 +593,13 @@ class MoondreamModel:
         kv = self._kv_struct(slot0)
         pos_base = torch.tensor(pos_list, dtype=torch.int32, device=self._device)
 
-        # the persistent kernel's static limits (csrc/decode_b1.hip: B1_MAX_DIM / B1_MAX_FF / B1_MAX_LAYERS, head_dim 64,
-        # MHA); anything else decodes on the batched kernels
-        b1 = (b == 1 and self.single_sequence_kernel and lora is None and not bool(self.w.text.fp8)
-              and t.n_heads == t.n_kv_heads and t.qkv_dim % 64 == 0 and t.head_dim == 64 and t.dim <= 4096
-              and t.ff_dim <= 8192 and t.ff_dim % 8 == 0 and t.n_layers <= 32 and t.n_heads <= 64 and t.vocab_size % 2 == 0)
+        # one sequence, greedy, no side path: the whole step as ONE persistent launch (csrc/decode_b1.hip) when the library
+        # says this model / cache / device fits its static limits and its grid can be co-resident; anything else decodes on
+        # the batched kernels.  Never from the pipelined engine (allow_b1 = False): a second stream's persistent GEMMs
+        # could keep workgroups of the grid off the chip and its software barriers would time out.
+        b1 = (b == 1 and allow_b1 and self.single_sequence_kernel and lora is None and not bool(self.w.text.fp8)
+              and bool(self.lib.md_decode_step_b1_supported(C.byref(self.w.text), C.byref(kv))))
+        self._b1_used = b1
         if b1:
             if self._b1_sync is None:
                 self._b1_sync = torch.zeros(4096, dtype=torch.int32, device=self._device)
@@ -864,7 +893,7 @@ class MoondreamModel:
                 with torch.cuda.stream(dec_s):
                     dec_s.wait_event(ev)
                     first.record_stream(dec_s)
-                    hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, slot0, None, check_every=16)
+                    hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, slot0, None, check_every=16, allow_b1=False)
                     done = torch.cuda.Event()
                     done.record(dec_s)
             pending.append((hist, done, b))

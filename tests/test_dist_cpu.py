@@ -44,15 +44,20 @@ def _worker(rank, world, port, out_dir):
     mine = mdist.shard_range(7, rank, world)
     local = torch.tensor([[i * 10 + t for t in range(4)] for i in mine], dtype=torch.int32).reshape(len(mine), 4)
     blocks = mdist.gather_token_ids(local)
+    blocks_known = mdist.gather_token_ids(local, n_total=7)  # block sizes from shard_range: no size exchange
     t = mdist.max_over_ranks(float(rank + 1), "cpu")
     assert t == float(world)
+    assert mdist.ranks_seen("cpu") == world
+    per_rank = mdist.gather_floats(10.0 + rank, "cpu")
+    assert per_rank == ([10.0 + r for r in range(world)] if rank == 0 else None)
     mdist.barrier()
     if rank == 0:
         allids = torch.cat(blocks, 0)
         assert allids.tolist() == [[i * 10 + t for t in range(4)] for i in range(7)]
+        assert torch.equal(torch.cat(blocks_known, 0), allids)
         open(os.path.join(out_dir, "ok"), "w").write("1")
     else:
-        assert blocks is None
+        assert blocks is None and blocks_known is None  # a gather to rank 0, not an all-gather
     dist.destroy_process_group()
 
 
@@ -77,7 +82,21 @@ def test_bench_self_launches_n2_without_torchrun():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["items"] == 7 and d["max_rank"] == 1.0
+    assert d["n_gpus"] == 2 and d["items"] == 7 and d["max_rank"] == 1.0 and d["ranks_seen"] == 2
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """A rank that dies must make `python bench.py --gpus 2` exit non-zero with that rank's traceback on stderr
+    (the driver only sees the parent's exit code)."""
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MD_SELFTEST_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest-dist"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert r.returncode != 0
+    assert "rank 1 asked to fail" in r.stderr and "a rank of the 2-process launch failed" in r.stderr
 
 
 def test_relaunch_is_a_noop_inside_a_rank_and_for_one_gpu(monkeypatch):

@@ -7,8 +7,9 @@ methods ``_vis_enc / _vis_proj / _prefill / _decode_one_tok``
 (moondream.py:168-192) -- here bound to hand-written gfx950 kernels through the
 C ABI instead of ATen ops.  New: ``batch_generate`` / ``batch_caption`` /
 ``batch_query`` run B images in lockstep (the reference has no batching;
-hf_moondream.py:99-103 is a sequential loop) and return exactly what the
-sequential path returns.
+hf_moondream.py:99-103 is a sequential loop) and return what the sequential
+path returns (bit for bit under ``set_strict_batch_invariance``; see
+``batch_generate_ids`` for the default mode's contract).
 
 PyTorch is used for device memory, streams and (optionally) hipGraph capture
 only.  There is no eager / CPU fallback: without the built library or a GPU the
@@ -224,6 +225,18 @@ class MoondreamModel:
         else:
             self.w.disable_fp8_decode()
         self._graphs.clear()  # captured decode steps baked the other launches in
+
+    def set_strict_batch_invariance(self, on: bool = True):
+        """``on``: every sequence gets the same bits whatever the batch it travels in -- ``batch_generate_ids([a, b, ..])[i]``
+        == ``batch_generate_ids([x])`` == ``caption(x)`` bit for bit -- by giving up the two B=1 / batch-level shortcuts whose
+        accumulation order differs from the batched kernels': the persistent single-sequence decode kernel (fp32 matrix-vector
+        products, per-slice softmax maxima) and the fused [image | prompt] prefill pass (``caption`` / ``query`` make the
+        reference's two passes).  Off (the default) those two are used; outputs then agree with the strict mode within bf16
+        accumulation-order noise, i.e. ids can part only at decisions whose top-1/top-2 margin is inside that noise
+        (quantified on the 64 bench images by tests/test_model_gpu.py::test_batch_equals_sequential_unfiltered)."""
+        self.single_sequence_kernel = not on
+        self.fused_prefill = not on
+        self._graphs.clear()
 
     def compile(self):
         """The reference rebinds the seam to torch.compile'd functions here
@@ -718,7 +731,7 @@ class MoondreamModel:
         return out
 
     def _prepare_sequences(self, images, prompts: Sequence[Sequence[int]], mark=None, lora: Optional[PackedLora] = None,
-                           fuse: bool = False):
+                           fuse: bool = False, logits_capture: Optional[torch.Tensor] = None):
         """Everything before the first generated token, for B (image, prompt-ids) pairs: sequences are
         placed in KV slots in order of prompt length (stable), so that every group of equal-length
         prompts occupies a contiguous slot range; raw images are encoded together and prefilled
@@ -759,7 +772,10 @@ class MoondreamModel:
                 pe = self._embed(torch.tensor(prompts[g0:g1], dtype=torch.int32))
                 x = torch.cat([bos[g0:g1], img_emb[g0:g1], pe], dim=1)
                 hidden = self._text_forward(x, 0, g0, lora=lora)
-                first[g0:g1] = self._pick(self._lm_head(hidden), 0.0, 0.0)
+                lg = self._lm_head(hidden)
+                if logits_capture is not None:
+                    logits_capture[g0:g1] = lg
+                first[g0:g1] = self._pick(lg, 0.0, 0.0)
                 hidden_last[g0:g1] = hidden[:, -1, :]
                 next_pos[g0:g1] = [x.shape[1]] * (g1 - g0)
                 g0 = g1
@@ -793,6 +809,8 @@ class MoondreamModel:
             while g1 < b and len(prompts[g1]) == len(prompts[g0]):
                 g1 += 1
             logits, hidden, p1 = self._prefill_prompts(prompts[g0:g1], pos, g0, lora=lora)
+            if logits_capture is not None:
+                logits_capture[g0:g1] = logits
             first[g0:g1] = self._pick(logits, 0.0, 0.0)
             hidden_last[g0:g1] = hidden[:, -1, :]
             next_pos[g0:g1] = [p1] * (g1 - g0)
@@ -811,11 +829,18 @@ class MoondreamModel:
     ) -> List[List[int]]:
         """Greedy token ids for B (image, prompt-ids) pairs, decoded in lockstep.
 
-        Defined as: element i equals what the sequential reference path
-        (encode_image -> load_encoded_image -> _generate_answer with
-        temperature 0) returns for (images[i], prompts[i]).  Every kernel's
-        accumulation order is independent of the batch, so this holds
-        bit-for-bit against this model's own B=1 path.
+        Defined as: element i is what the sequential path (encode_image ->
+        load_encoded_image -> _generate_answer with temperature 0) returns for
+        (images[i], prompts[i]).  Every BATCHED kernel's accumulation order is a
+        function of the layer shape only, never of the number of sequences in
+        the launch, so under ``set_strict_batch_invariance(True)`` this holds bit
+        for bit (tested on the 64 unfiltered bench images at 2B).  By default two
+        shortcuts change the accumulation order between the two sides -- raw
+        images take ONE fused [image | prompt] decoder pass here where
+        ``caption`` makes the reference's two, and a lone sequence decodes on the
+        persistent single-sequence kernel -- so then the two sides agree within
+        bf16 accumulation-order noise: ids can differ only from a decision on
+        whose top-1/top-2 logit margin is inside that noise.
         """
         b = len(images)
         assert b == len(prompts) and b > 0
@@ -847,6 +872,45 @@ class MoondreamModel:
             torch.cuda.synchronize(self._device)
             self.last_phase_ms = {marks[i][0]: marks[i - 1][1].elapsed_time(marks[i][1]) for i in range(1, len(marks))}
         return results  # type: ignore[return-value]
+
+    def teacher_forced_logits(self, images, prompts: Sequence[Sequence[int]], forced_ids, gather_idx) -> torch.Tensor:
+        """Parity instrument (tests / bench.py): the logits of every greedy decision when each sequence is FORCED to follow
+        ``forced_ids[i]`` (the reference's ids) instead of its own argmax, gathered at ``gather_idx[i][j]`` (the reference's
+        top-k ids of decision j).  Decision 0 is the prompt prefill's, decision j the decode step that consumed
+        forced_ids[i][j-1] -- the same launches as ``batch_generate_ids`` (fused or two-pass prefill as configured, the
+        batched decode step; at B=1 the persistent kernel if enabled), so the error measured here is the error of the ids'
+        own logits.  Returns float32 [B, T+1, k] on the CPU (``answer_id`` suppressed from decision 1 on, moondream.py:517)."""
+        b = len(images)
+        forced = torch.as_tensor(np.asarray(forced_ids), dtype=torch.int32)
+        idx = torch.as_tensor(np.asarray(gather_idx), dtype=torch.int64)
+        t_steps = forced.shape[1]
+        assert forced.shape[0] == b and idx.shape[0] == b and idx.shape[1] >= t_steps + 1
+        tk, t = self.config.tokenizer, self.config.text
+        out = torch.empty(b, t_steps + 1, idx.shape[2], dtype=torch.float32)
+        with torch.inference_mode():
+            cap = torch.empty(b, t.vocab_size, dtype=BF16, device=self._device)
+            order, _, _, next_pos = self._prepare_sequences(list(images), prompts, None, None, fuse=True, logits_capture=cap)
+            src = torch.tensor(order, dtype=torch.int64)
+            forced_s, idx_s = forced[src].to(self._device), idx[src].to(self._device)  # slot order
+            vals = torch.empty(b, t_steps + 1, idx.shape[2], dtype=torch.float32, device=self._device)
+            vals[:, 0] = torch.gather(cap.float(), 1, idx_s[:, 0])
+            hist = torch.cat([forced_s.t().contiguous(), torch.zeros(1, b, dtype=torch.int32, device=self._device)], 0)
+            scratch = torch.empty(b, dtype=torch.int32, device=self._device)
+            logits = self._decode_logits(b)
+            ws = self._workspace(self.lib.md_decode_workspace_bytes(C.byref(self.w.text), b), 2)
+            kv = self._kv_struct(0)
+            pos_t = torch.tensor([int(p) for p in next_pos], dtype=torch.int32, device=self._device)
+            for j in range(t_steps):
+                _lib.check(
+                    self.lib.md_decode_step(
+                        C.byref(self.w.text), hist[j].data_ptr(), scratch.data_ptr(), pos_t.data_ptr(), b, C.byref(kv),
+                        tk.answer_id, logits.data_ptr(), t.vocab_size, ws.data_ptr(), ws.numel(), self._stream(),
+                    ),
+                    "md_decode_step",
+                )
+                vals[:, j + 1] = torch.gather(logits[:b].float(), 1, idx_s[:, j + 1])
+            out[src] = vals.cpu()
+        return out
 
     # ------------------------------------------------------ pipelined batches
     def _streams(self):
@@ -934,7 +998,8 @@ class MoondreamModel:
 
     def batch_generate(self, images, prompts: Optional[Sequence[str]] = None, settings: Optional[dict] = None) -> List[str]:
         """BASELINE.json's ``batch_generate``: captions when ``prompts`` is None, else answers
-        (greedy; element i == caption(images[i]) / query(images[i], prompts[i]) at temperature 0)."""
+        (greedy; element i == caption(images[i]) / query(images[i], prompts[i]) at temperature 0: bit for bit under
+        ``set_strict_batch_invariance``, within bf16 accumulation-order noise otherwise -- see ``batch_generate_ids``)."""
         if prompts is None:
             return self.batch_caption(images, "normal", settings)
         return self.batch_query(images, prompts, settings)

@@ -1,0 +1,82 @@
+"""Margin-aware comparison of greedy ids against the reference's, with a MEASURED noise threshold.
+
+Two correct bf16 implementations share rounding points but not GEMM accumulation order, so their
+logits differ by a few bf16 ulps.  Greedy ids are an integer output only where the reference's
+top-1/top-2 logit margin exceeds that noise: the implementation under test picks another token at
+a decision exactly when  (its error on the runner-up) - (its error on the winner) >= margin,
+i.e. only where  margin <= 2 * max|logit error|.  So the licence for a divergence is not a flat
+constant: it is TWICE THE LARGEST LOGIT ERROR MEASURED ON THIS VERY RUN, teacher-forced on the
+reference's ids over every decision of every sequence (``MoondreamModel.teacher_forced_logits``
+against the reference's recorded top-k logits, tests/golden/md2b_bench64.npz), and that error is
+itself capped (``max_err_cap``) so that a broken kernel cannot buy itself a wide licence.
+
+Used by bench.py (after the timed region) and tests/test_model_gpu.py.  Host-side numpy only.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+NOISE_FACTOR = 2.0  # a flip needs e(runner-up) - e(winner) >= margin, and each |e| <= max_err
+
+
+def logit_error_stats(got_topk: np.ndarray, ref_topk: np.ndarray) -> Dict[str, float]:
+    """got/ref: float [B, T+1, k] logits at the reference's top-k ids of every decision."""
+    err = np.abs(np.asarray(got_topk, dtype=np.float64) - np.asarray(ref_topk, dtype=np.float64))
+    err = err[np.isfinite(np.asarray(ref_topk))]
+    # bf16 spacing at the reference logit's magnitude (8 significand bits)
+    mag = np.abs(np.asarray(ref_topk, dtype=np.float64))[np.isfinite(np.asarray(ref_topk))]
+    ulp = np.exp2(np.floor(np.log2(np.maximum(mag, 2.0 ** -120))) - 7)
+    return {
+        "max": float(err.max()), "p99": float(np.quantile(err, 0.99)), "mean": float(err.mean()),
+        "max_ulps": float((err / ulp).max()), "p99_ulps": float(np.quantile(err / ulp, 0.99)),
+        "decisions": int(np.asarray(ref_topk).shape[0] * np.asarray(ref_topk).shape[1]),
+    }
+
+
+def first_divergences(got_ids: Sequence[Sequence[int]], ref_ids, margins, tokens: Optional[int] = None):
+    """[(sequence, position, got, want, reference margin of that decision)] for every sequence that leaves the
+    reference's stream, and the number of sequences that never do."""
+    out, exact = [], 0
+    for i, (g, r) in enumerate(zip(got_ids, ref_ids)):
+        g, r = list(g), list(r)
+        n = min(len(g), len(r)) if tokens is None else min(len(g), len(r), tokens)
+        j = next((t for t in range(n) if g[t] != r[t]), None)
+        if j is None:
+            exact += 1
+        else:
+            out.append((i, j, int(g[j]), int(r[j]), float(margins[i][j])))
+    return exact, out
+
+
+def parity_report(got_ids, ref_ids, margins, got_topk: Optional[np.ndarray], ref_topk: Optional[np.ndarray],
+                  tokens: Optional[int] = None, max_err_cap: float = 0.75, min_exact: Optional[int] = None) -> Dict[str, object]:
+    """The JSON-able verdict.  ``parity_ok`` iff (a) the measured logit error is under ``max_err_cap``, (b) every
+    first divergence sits at a reference margin <= NOISE_FACTOR x the measured max error, (c) at least ``min_exact``
+    sequences are identical (when given)."""
+    exact, div = first_divergences(got_ids, ref_ids, margins, tokens)
+    n = min(len(got_ids), len(ref_ids))
+    rep: Dict[str, object] = {"parity_checked": n, "parity_exact": exact}
+    worst = max((d[4] for d in div), default=0.0)
+    rep["parity_max_divergence_margin"] = worst
+    if got_topk is not None and ref_topk is not None:
+        st = logit_error_stats(got_topk, ref_topk)
+        thr = NOISE_FACTOR * st["max"]
+        rep.update({
+            "parity_max_logit_err": st["max"], "parity_p99_logit_err": st["p99"], "parity_max_logit_err_ulps": st["max_ulps"],
+            "parity_p99_logit_err_ulps": st["p99_ulps"], "parity_decisions": st["decisions"], "parity_threshold": thr,
+        })
+        err_ok = st["max"] <= max_err_cap
+    else:
+        thr, err_ok = 0.5, True  # no logits available: the flat round-2 licence
+        rep["parity_threshold"] = thr
+    bad = [d for d in div if d[4] > thr]
+    ok = err_ok and not bad and (min_exact is None or exact >= min_exact)
+    rep["parity_ok"] = bool(ok)
+    rep["parity_note"] = (
+        f"ids vs the reference's (tests/golden/md2b_bench64.npz): {exact}/{n} sequences identical; every first difference must sit at "
+        f"a reference top-1/top-2 margin <= {NOISE_FACTOR:g} x the max |logit error| measured teacher-forced on this run "
+        f"(= {thr:.4f}; cap on that error {max_err_cap}); largest margin at a first difference {worst:.4f}"
+        + (f"; VIOLATIONS {bad[:6]}" if bad else "") + ("" if err_ok else f"; LOGIT ERROR ABOVE CAP"))
+    return rep

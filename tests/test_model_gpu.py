@@ -636,6 +636,39 @@ def test_fp8_decode_mode_tiny(tiny):
     fp8_decode_report(model, images, prompts, ids, None, "tiny")
 
 
+def batch_equals_sequential_unfiltered(model, imgs64, prompt, got64_default, ref_ids, ref_margins, thr):
+    """test_batch_equals_sequential_unfiltered (run inside the 2B test: one 2B model per session).  The 64 UNFILTERED bench
+    images, Moondream-2B, 32 greedy tokens.
+      strict mode (set_strict_batch_invariance): B=64 batch == 64 sequential B=1 calls == caption() BIT FOR BIT;
+      default mode (fused prefill at any B, persistent kernel at B=1): counted, and wherever batch and sequential part
+      while both still follow the reference's stream, the reference margin of that decision must be inside the
+      measured noise threshold."""
+    n = len(imgs64)
+    try:
+        model.set_strict_batch_invariance(True)
+        strict_batch = model.batch_generate_ids(imgs64, [prompt] * n, max_tokens=32, ignore_eos=True)
+        strict_seq = [model.batch_generate_ids([im], [prompt], max_tokens=32, ignore_eos=True)[0] for im in imgs64]
+        assert strict_batch == strict_seq, [i for i in range(n) if strict_batch[i] != strict_seq[i]]
+        cap = model.caption(imgs64[3], settings={"temperature": 0, "max_tokens": 32})["caption"]
+        assert [int(t) for t in cap.split()] == strict_seq[3][: len(cap.split())]
+    finally:
+        model.set_strict_batch_invariance(False)
+    seq_default = [model.batch_generate_ids([im], [prompt], max_tokens=32, ignore_eos=True)[0] for im in imgs64]
+    same_ds = sum(a == b for a, b in zip(got64_default, seq_default))
+    same_strict = sum(a == b for a, b in zip(got64_default, strict_batch))
+    worst = 0.0
+    for i in range(n):
+        a, b, r = got64_default[i], seq_default[i], ref_ids[i]
+        j = next((t for t in range(32) if a[t] != b[t]), None)
+        if j is not None and a[:j] == r[:j]:  # both on the reference's stream up to j: its margin describes this decision
+            worst = max(worst, float(ref_margins[i][j]))
+    print(f"batch vs sequential, unfiltered 64 images at 2B: strict mode 64/64 bit-identical; default mode batch(B=64, fused prefill) vs "
+          f"B=1 (fused prefill + persistent kernel): {same_ds}/64 identical, batch(default) vs batch(strict): {same_strict}/64; largest "
+          f"reference margin where default batch and default B=1 part on the reference's stream: {worst:.4f} (threshold {thr:.4f})")
+    assert worst <= thr, (worst, thr)
+    assert same_ds >= 32 and same_strict >= 32  # quantified above; the hard claims are the strict-mode equality and the margin bound
+
+
 @pytest.mark.parametrize("name,cfg_name", [("md05b_seed1.npz", "0.5b"), ("md2b_seed1.npz", "2b")])
 def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     """BASELINE.json configs at full size: greedy ids bit-exact against the
@@ -682,6 +715,12 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     gb = load_golden(golden_dir, "md2b_bench64.npz")
     imgs64 = [synth.synthetic_image(i, int(gb["seed"])) for i in range(gb["tokens"].shape[0])]
     pr = gb["prompt"].tolist()
+    from moondream_amd import parity as P
+
+    ref_ids = gb["tokens"].tolist()
+    # the licence for a divergence is MEASURED: the HIP path teacher-forced on the reference's ids, its logits at the
+    # reference's top-8 ids of all 64 x 33 decisions against the reference's (moondream_amd/parity.py)
+    topk = model.teacher_forced_logits(imgs64, [pr] * 64, gb["tokens"], gb["top8_idx"]).numpy()
     for pipelined in (False, True):
         if pipelined:
             model.compile()
@@ -691,12 +730,15 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
             got64 = outs[1]
         else:
             got64 = model.batch_generate_ids(imgs64, [pr] * 64, max_tokens=32, ignore_eos=True)
-        exact, bad = margin_aware_mismatches(got64, gb["tokens"].tolist(), gb["margins"])
-        print(f"bench64 parity ({'pipelined+graphs' if pipelined else 'eager'}): {exact}/64 sequences identical to the reference, {len(bad)} violations")
-        assert not bad, bad[:5]
+        rep = P.parity_report(got64, ref_ids, gb["margins"], topk, gb["top8_val"], tokens=32, min_exact=48)
+        print(f"bench64 parity ({'pipelined+graphs' if pipelined else 'eager'}): {rep['parity_exact']}/64 identical; max |logit err| "
+              f"{rep['parity_max_logit_err']:.4f} ({rep['parity_max_logit_err_ulps']:.1f} bf16 ulps, p99 {rep['parity_p99_logit_err']:.4f}) over "
+              f"{rep['parity_decisions']} decisions -> threshold {rep['parity_threshold']:.4f}; largest reference margin at a first "
+              f"divergence {rep['parity_max_divergence_margin']:.4f}")
+        assert rep["parity_ok"], rep["parity_note"]
         for i in g["image_index"].tolist():  # the wide-margin images of md2b_seed1 are among the 64: exact
             assert got64[i] == gb["tokens"][i].tolist(), i
-        assert exact >= 4  # most of the 64 have at least one decision inside bf16 noise (margins recorded in the fixture)
+    batch_equals_sequential_unfiltered(model, imgs64, pr, got64, ref_ids, gb["margins"], rep["parity_threshold"])
     # opt-in FP8 weight stream for the decode steps of the same configuration (BASELINE configs[4]): a different
     # numerical mode, judged by tolerance against the bf16 path -- never by bit parity
     fp8_decode_report(model, imgs64, [pr] * 64, got64, gb["margins"], "2b B=64")

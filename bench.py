@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--prompt", choices=["caption", "vqa32"], default="caption",
                     help="caption: the 5-id caption template; vqa32: 32-id seeded question prompts (SURVEY 8d)")
     ap.add_argument("--no-vqa-leg", action="store_true", help="skip the auxiliary 32-token-prompt measurement")
+    ap.add_argument("--no-detect13-leg", action="store_true", help="skip the BASELINE configs[4]-shaped leg (768x1024 -> 13 crops, detect)")
+    ap.add_argument("--detect13-batch", type=int, default=32, help="images per step of that leg (configs[4]: 256 over 8 GPUs)")
     ap.add_argument("--only-timed-steps", action="store_true",
                     help="exit after the timed region (rocprofv3 --pmc passes: exactly --steps steps of kernels in the trace)")
     ap.add_argument("--selftest-dist", action="store_true",
@@ -215,6 +217,57 @@ def check_parity(model, images, prompts, ids_per_image, cfg_name, seed, prompt_k
     got_topk = model.teacher_forced_logits(images[:n], prompts[:n], g["tokens"][:n, :t], g["top8_idx"][:n, : t + 1]).numpy()
     return P.parity_report([ids[:t] for ids in ids_per_image[:n]], g["tokens"][:n, :t].tolist(), g["margins"][:n],
                            got_topk, g["top8_val"][:n, : t + 1], tokens=t, min_exact=(48 * n) // 64 if t == 32 else None)
+
+
+def detect13_leg(model, cfg, args, dev):
+    """BASELINE.json configs[4]'s WORKLOAD on one GPU (its fp8 arithmetic is a separate opt-in mode): seeded 768 x 1024
+    images -> tiling (3, 4) = 13 crops each (image_crops.py:58-167), ``detect`` with a fixed ``max_objects``, 32 images per
+    step.  Reported: images/s over whole steps (host tiling NOT hidden: one step after the other on one stream), the
+    per-phase GPU times of one step, the vision phase against the MFMA roofline (13 x 666.45 + 51.98 GFLOP per image),
+    and the objects of the first 8 images against the reference's (tests/golden/md2b_detect13.npz)."""
+    from moondream_amd import parity as P
+    from moondream_amd import synth
+
+    gpath = os.path.join(REPO, "tests", "golden", "md2b_detect13.npz")
+    g = np.load(gpath) if os.path.exists(gpath) and args.model == "2b" and args.seed == 1 else None
+    size = tuple(int(x) for x in g["size"]) if g is not None else (768, 1024)
+    max_objects = int(g["max_objects"]) if g is not None else 4
+    obj = " ".join(str(t) for t in (g["object_ids"].tolist() if g is not None else [7, 8]))
+    B2 = args.detect13_batch
+    imgs = [synth.synthetic_image(i, args.seed, size) for i in range(B2)]
+    st = {"max_objects": max_objects, "_run_all_objects": True}
+    t_host = time.perf_counter()
+    crops = [model._crop(im) for im in imgs[:4]]
+    host_ms_per_image = (time.perf_counter() - t_host) / 4 * 1e3
+    n_crops = int(crops[0][0].shape[0])
+    res = model.batch_detect(imgs, [obj] * B2, settings=st)  # warm-up (arenas, KV slabs)
+    torch.cuda.synchronize()
+    steps = 2
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        res = model.batch_detect(imgs, [obj] * B2, settings=st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / steps
+    model.collect_timing = True
+    model.batch_detect(imgs, [obj] * B2, settings=st)
+    torch.cuda.synchronize()
+    model.collect_timing = False
+    phase = {k: round(v, 2) for k, v in model.last_phase_ms.items()}
+    out = {
+        "workload": f"Moondream-{args.model.upper()} bf16 batch_detect: {B2} images/GPU x {size[0]}x{size[1]} ({n_crops} crops each, tiling "
+                    f"{tuple(crops[0][1])}), detect prompt, max_objects {max_objects} (every sequence runs all rounds)",
+        "images_per_sec": B2 / dt, "ms_per_step": dt * 1e3, "batch": B2, "crops_per_image": n_crops, "max_objects": max_objects,
+        "phase_ms": phase, "host_tiling_ms_per_image_one_thread": host_ms_per_image,
+        "note": "steps run back to back on one stream: phase_ms.host_tiling (PIL LANCZOS resize + crop cutting on the thread pool, "
+                "reference image_crops.py:124-167) is NOT hidden behind GPU work here",
+    }
+    if phase.get("vision"):
+        fl = B2 * (n_crops * FLOP_VIT_PER_CROP + 51.98e9)
+        out["vit_encoder"] = {"achieved": fl / (phase["vision"] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                              "frac": fl / (phase["vision"] * 1e-3) / 1e12 / 2500.0}
+    if g is not None:
+        out["parity"] = P.detect_parity([r["objects"] for r in res], g)
+    return out
 
 
 def main():
@@ -461,6 +514,10 @@ def main():
             "images_per_sec": B / dt, "ms_per_step": dt * 1e3, "prompt_tokens": len(vqa_prompts[0]),
             "p50_latency_ms": float(np.median(lat) * 1e3) if lat else None,
         }
+
+    # BASELINE configs[4]'s workload shape (multi-crop + detect head) as its own leg
+    if world == 1 and not args.no_detect13_leg and args.model == "2b":
+        result["detect13"] = detect13_leg(model, cfg, args, dev)
 
     # auxiliary leg, NOT the headline: identical crops of an image encoded once (the bench's 378 x 378 images have
     # tiling (1, 1): their local crop is byte-identical to the global crop).  The reference encodes both, so `value`

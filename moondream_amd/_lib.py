@@ -238,20 +238,27 @@ def audit_asm_owned_accumulators(asm_path: str) -> None:
     v_accvgpr_* outside an inline-asm block, or any scratch access, fails the build."""
     if not os.path.exists(asm_path):
         raise MoondreamHipError(f"{asm_path} missing: gemm_w4.hip must be compiled with -save-temps=obj for the ISA audit")
-    in_asm, kernel, bad = False, None, []
+    import re
+
+    in_asm, kernel, bad, seen = False, None, [], 0
+    label = re.compile(r"^(_Z\S*gemm_w4_kernel\S*):")  # the label line may carry a trailing "; @name" comment
     for ln in open(asm_path):
         t = ln.strip()
-        if t.endswith(":") and "gemm_w4_kernel" in t:
-            kernel = t
-        if ";;#ASMSTART" in t or t.startswith(";ASMSTART") or "ASMSTART" in t:
+        m = label.match(t)
+        if m:
+            kernel = m.group(1)
+            seen += 1
+        if "ASMSTART" in t:
             in_asm = True
         elif "ASMEND" in t:
             in_asm = False
         elif kernel and not t.startswith(";"):
-            if ("v_accvgpr" in t and not in_asm) or t.startswith("scratch_"):
-                bad.append(t)
+            if ("v_accvgpr" in t and not in_asm) or t.startswith("scratch_") or ("a[" in t and not in_asm and t.startswith("v_mfma")):
+                bad.append(f"{kernel[-40:]}: {t}")
         if t.startswith("s_endpgm"):
             kernel = None
+    if seen == 0:
+        raise MoondreamHipError(f"{asm_path}: no gemm_w4_kernel label found -- the ISA audit would be vacuous")
     if bad:
         raise MoondreamHipError("gemm_w4.hip: compiler-generated accumulator-file / scratch traffic in a kernel whose "
                                 "a[0:255] are owned by inline asm:\n  " + "\n  ".join(bad[:10]))

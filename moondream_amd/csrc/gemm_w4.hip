@@ -133,53 +133,30 @@ __device__ __forceinline__ float acc_read() {
 // used by MFMAs 0 0 1 2 3 4 8 12 of the consuming half.
 constexpr int kReadOrder[8] = {0, 4, 1, 2, 3, 5, 6, 7};
 constexpr int kFirstUse[8] = {0, 0, 1, 2, 3, 4, 8, 12};  // by read position k
-// WS = spacing of the 16 ds_writes of a pair in gaps: 3 -> gaps 0, 3, .., 45 (the last one three gaps before the barrier
-// of gap 48); 2 -> gaps 0, 2, .., 30 (the writes have 17 gaps to complete before the barrier collects them; their loads
-// are then needed up to 15 gaps earlier, which a two-pair register ring affords).  Loads always one gap after their write.
-constexpr int pmod64(int g) { return ((g % 64) + 64) % 64; }
-template <int WS> constexpr bool gap_has_write(int g) { return pmod64(g) % WS == 0 && pmod64(g) < 16 * WS; }
+constexpr bool gap_has_write(int g) { return ((g % 64) + 64) % 64 % 3 == 0 && ((g % 64) + 64) % 64 < 48; }
 // LDS operations issued strictly after the read of gap g_issue and before MFMA x_need (gaps along the periodic stream)
-template <int WS> constexpr int lds_ops_between(int g_issue, int x_need) {
-  int n = gap_has_write<WS>(g_issue) ? 1 : 0;  // the write of the read's own gap is issued after the read
-  for (int g = g_issue + 1; g < x_need; ++g) n += (pmod64(g) % 2 == 1) + (gap_has_write<WS>(g) ? 1 : 0);
+constexpr int lds_ops_between(int g_issue, int x_need) {
+  int n = gap_has_write(g_issue) ? 1 : 0;  // the write of the read's own gap is issued after the read
+  for (int g = g_issue + 1; g < x_need; ++g) n += (((g % 2) + 2) % 2 == 1) + (gap_has_write(g) ? 1 : 0);
   return n;
 }
 // lgkmcnt to wait for before MFMA m of half h (0..3) of a pair; -1: the MFMA introduces no new fragment.  The
 // fragments of half h are read in gaps 16 (h - 1) + 1 + 2 k  (half 0: at the end of the previous pair).
-template <int WS> constexpr int frag_wait(int h, int m) {
+constexpr int frag_wait(int h, int m) {
   int w = -1;
   for (int k = 0; k < 8; ++k)
     if (kFirstUse[k] == m) {
-      const int c = lds_ops_between<WS>(16 * (h - 1) + 1 + 2 * k, 16 * h + m);
+      const int c = lds_ops_between(16 * (h - 1) + 1 + 2 * k, 16 * h + m);
       w = (w < 0 || c < w) ? c : w;
     }
   return w;
 }
-// LDS operations a wave issues after its last ds_write of a pair and before the barrier of gap 48 (the reads of the odd
-// gaps in between): what may stay in flight when the wave declares its writes complete
-template <int WS> constexpr int reads_after_last_write() {
-  int n = 0;
-  for (int g = 16 * WS - WS + 1; g < 48; ++g) n += (g % 2 == 1);
-  return n;
-}
-static_assert(reads_after_last_write<3>() == 1 && reads_after_last_write<2>() == 9, "barrier wait");
-template <int WS> constexpr bool waits_fit() {
-  for (int h = 0; h < 4; ++h)
-    for (int m = 0; m < 16; ++m)
-      if (frag_wait<WS>(h, m) > 15) return false;
-  return reads_after_last_write<WS>() <= 15;
-}
-static_assert(waits_fit<3>() && waits_fit<2>(), "lgkmcnt is a 4-bit counter");
+static_assert(frag_wait(0, 0) <= 15 && frag_wait(1, 12) <= 15 && frag_wait(2, 12) <= 15 && frag_wait(3, 0) <= 15, "lgkmcnt is a 4-bit counter");
 
 // ABL: timing ablations for profiling (bit 0: no ds_write, 1: no global loads, 2: no barrier, 3: no
 // fragment reads, 4: no epilogue stores); results are garbage with any bit set.
-// NP: pieces of the register staging ring.  16 = one pair of slices in flight (each register re-requested right after it
-// is written out: a load has 63 gaps, ~1 us, to arrive).  32 = TWO alternating sets of 16: the set written during pair i
-// was requested during pair i - 2, so a load has 127 gaps and 128 KiB per CU are in flight (K / 64 must be even: the set
-// a pair writes is then a compile-time constant of an unrolled double body).
-template <int EPI, int ABL = 0, int NP = 16, int WS = 3>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
-  static_assert(NP == 16 || NP == 32, "one or two sets of 16 pieces");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -224,19 +201,19 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   };
   set_load_tile(ld_tile);
 
-  u32x4 R[NP];  // the staging ring: a piece is re-requested right after it is written out (set S = R[16 S .. 16 S + 15])
+  u32x4 R[16];  // one pair of slices in registers; each piece is re-requested right after it is written out
   if constexpr (ABL != 0) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) R[j] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    for (int j = 0; j < 16; ++j) R[j] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   }
-  auto load_piece = [&](auto j_c, auto set_c) {
-    constexpr int J = decltype(j_c)::value, Q = 16 * decltype(set_c)::value + J;
+  auto load_piece = [&](auto j_c) {
+    constexpr int J = decltype(j_c)::value;
     if constexpr (ABL & 2)
-      opaque(R[Q]);
+      opaque(R[J]);
     else if constexpr (J < 8)
-      R[Q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[J], ld_soff, 0));
+      R[J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[J], ld_soff, 0));
     else
-      R[Q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff[J], ld_soff, 0));
+      R[J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff[J], ld_soff, 0));
   };
   auto advance_load_cursor = [&]() {
     ld_soff += 128;
@@ -263,12 +240,12 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   const uint32_t wr_even = lds_base + r8w * ROW_BYTES + (((c8w & 3) ^ ((r8w >> 2) & 3)) * 16);
   const uint32_t wr_odd = lds_base + STAGE + (r8w ^ 1) * ROW_BYTES + (((c8w & 3) ^ ((r8w >> 2) & 3)) * 16);
   const uint32_t wr_lane = (c8w < 4) ? wr_even : wr_odd;
-  auto write_piece = [&](auto j_c, auto set_c, uint32_t pair) {
-    constexpr int J = decltype(j_c)::value, Q = 16 * decltype(set_c)::value + J;
+  auto write_piece = [&](auto j_c, uint32_t pair) {
+    constexpr int J = decltype(j_c)::value;
     if constexpr (ABL & 1)
-      keep_alive(R[Q]);
+      keep_alive(R[J]);
     else
-      ds_write_b128<(J < 8 ? J * 32 * ROW_BYTES : A_BYTES + (J - 8) * 32 * ROW_BYTES)>(wr_lane + pair, R[Q]);
+      ds_write_b128<(J < 8 ? J * 32 * ROW_BYTES : A_BYTES + (J - 8) * 32 * ROW_BYTES)>(wr_lane + pair, R[J]);
   };
 
   // ---- fragment reads: K step s of a slice = logical chunks 2s (lanes 0-31) and 2s+1 (lanes 32-63)
@@ -299,22 +276,16 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   };
 
   acc_reserve();
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
 
   // ---- stream prologue: pair 0 written, pair 1 requested ---------------------------------------
-  // NP = 16: pair 0 -> set 0 -> LDS, pair 1 -> set 0.  NP = 32: pair 0 -> set 0, pair 1 -> set 1, set 0 -> LDS, pair 2 -> set 0
-  // (the first pair body writes set 1 = pair 1 and re-requests it with pair 3)
-  static_for<0, 16>([&](auto j) { load_piece(j, I0{}); });
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  static_for<0, 16>([&](auto j) { load_piece(j); });
   advance_load_cursor();
-  if constexpr (NP == 32) {
-    static_for<0, 16>([&](auto j) { load_piece(j, I1{}); });
-    advance_load_cursor();
-  }
   asm volatile("" ::: "memory");
-  static_for<0, 16>([&](auto j) { write_piece(j, I0{}, pair_cur); });
+  static_for<0, 16>([&](auto j) { write_piece(j, pair_cur); });
   asm volatile("" ::: "memory");
-  static_for<0, 16>([&](auto j) { load_piece(j, I0{}); });
+  static_for<0, 16>([&](auto j) { load_piece(j); });
   advance_load_cursor();
   wait_lgkm<0>();
   __builtin_amdgcn_s_barrier();
@@ -329,9 +300,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   // gap 48 publishes it (every wave drains its own writes first); its stages were last read in gap 47 of the
   // PREVIOUS pair, before that pair's barrier.  ONE straight-line body, no branch inside it (a second code path
   // would be a join over ~200 live registers); past the end of the stream the fillers keep running on data nobody reads.
-  auto pair_body = [&](auto first_c, auto setw_c) {
+  auto pair_body = [&](auto first_c) {
     constexpr bool FIRST = decltype(first_c)::value;  // first K step of a tile: accumulate onto zero
-    using SETW = decltype(setw_c);                    // the register set this pair writes out and re-requests
     const uint32_t a_e1 = ra[0][1] + pair_cur, b_e1 = rb[0][1] + pair_cur;   // even slice, K step 1
     const uint32_t a_o0 = ra[1][0] + pair_cur, b_o0 = rb[1][0] + pair_cur;   // odd slice, K step 0
     const uint32_t a_o1 = ra[1][1] + pair_cur, b_o1 = rb[1][1] + pair_cur;   // odd slice, K step 1
@@ -340,14 +310,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     static_for<0, 64>([&](auto xc) {
       constexpr int X = decltype(xc)::value, H = X / 16, M = X % 16, I = M / 4, J = M % 4, SET = H & 1;
       if constexpr (X == 48 && !(ABL & 4)) {
-        // this wave's writes are complete (WS = 3: the last one in gap 45, one younger read in gap 47 may stay in flight)
-        wait_lgkm<reads_after_last_write<WS>()>();
+        // this wave's writes (the last one in gap 45; one younger read in gap 47) are complete
+        wait_lgkm<1>();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
       // counted wait: the fragments this MFMA is the first to use have landed, younger LDS operations stay in flight
-      if constexpr (frag_wait<WS>(H, M) >= 0 && !(ABL & 8)) wait_lgkm<frag_wait<WS>(H, M)>();
+      if constexpr (frag_wait(H, M) >= 0 && !(ABL & 8)) wait_lgkm<frag_wait(H, M)>();
       mfma_acc<M, FIRST && H == 0>(fb[SET][J], fa[SET][I]);
       MD_PIN();
       if constexpr (X % 2 == 1) {
@@ -357,8 +327,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
         if constexpr (H == 2) read_frag(I1{}, Q{}, a_o1, b_o1);
         if constexpr (H == 3) read_frag(I0{}, Q{}, a_n0, b_n0);
       }
-      if constexpr (X % WS == 0 && X < 16 * WS) write_piece(std::integral_constant<int, X / WS>{}, SETW{}, wr);
-      if constexpr (X % WS == 1 && X < 16 * WS) load_piece(std::integral_constant<int, X / WS>{}, SETW{});
+      if constexpr (X % 3 == 0 && X < 48) write_piece(std::integral_constant<int, X / 3>{}, wr);
+      if constexpr (X % 3 == 1 && X < 48) load_piece(std::integral_constant<int, X / 3>{});
       MD_PIN();
     });
     advance_load_cursor();
@@ -385,17 +355,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   for (int vtile = blockIdx.x; vtile < nwg; vtile += gridDim.x) {
     // the accumulators are (re)defined by the first K step of every tile: nothing is carried from
     // one tile to the next in them
-    if constexpr (NP == 16) {
-      pair_body(std::true_type{}, I0{});
-      for (int u = 1; u < npair; ++u) pair_body(std::false_type{}, I0{});
-    } else {  // even pairs of the tile write set 1, odd pairs set 0 (K / 64 is even: every tile starts on an even pair)
-      pair_body(std::true_type{}, I1{});
-      pair_body(std::false_type{}, I0{});
-      for (int u = 2; u < npair; u += 2) {
-        pair_body(std::false_type{}, I1{});
-        pair_body(std::false_type{}, I0{});
-      }
-    }
+    pair_body(std::true_type{});
+    for (int u = 1; u < npair; ++u) pair_body(std::false_type{});
     wait_lgkm<0>();
     MD_PIN();
 
@@ -571,9 +532,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
 
 int g_w4_variant = 0;  // measurement hook (md_gemm_set_tuning "w4_variant"): 16 * ABL, bias epilogue only
 
-template <int EPI, int ABL = 0, int NP = 16, int WS = 3>
+template <int EPI, int ABL = 0>
 md_status launch(const GemmK& k, hipStream_t stream) {
-  auto fn = gemm_w4_kernel<EPI, ABL, NP, WS>;
+  auto fn = gemm_w4_kernel<EPI, ABL>;
   MD_TRY(md_ensure_dynamic_lds((const void*)fn, LDS_BYTES));
   GemmK kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
@@ -603,16 +564,8 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   // the residual epilogue takes its bias from the LDS-resident vector only (md_gemm_bf16 sends wider residual
   // layers to the eight-wave kernel)
   if (epi == MD_EPI_RESIDUAL && k.n_pad > md_gemm_w4_residual_max_cols()) return MD_ERR_UNSUPPORTED;
-  // schedule variants of the bias-epilogue kernel (md_gemm_set_tuning "w4_variant" 1..3): ring depth x write spacing
-  if (epi == MD_EPI_BIAS && g_w4_variant >= 1 && g_w4_variant <= 3) {
-    const bool deep = (g_w4_variant & 1) && (k.K % 128 == 0);
-    const bool ws2 = g_w4_variant & 2;
-    if (deep && ws2) return launch<MD_EPI_BIAS, 0, 32, 2>(k, stream);
-    if (deep) return launch<MD_EPI_BIAS, 0, 32, 3>(k, stream);
-    if (ws2) return launch<MD_EPI_BIAS, 0, 16, 2>(k, stream);
-  }
 #ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
-  if (epi == MD_EPI_BIAS && g_w4_variant >= 16) {
+  if (epi == MD_EPI_BIAS && g_w4_variant != 0) {
     switch (g_w4_variant) {
       case 16 * 1: return launch<MD_EPI_BIAS, 1>(k, stream);
       case 16 * 2: return launch<MD_EPI_BIAS, 2>(k, stream);

@@ -80,3 +80,37 @@ def parity_report(got_ids, ref_ids, margins, got_topk: Optional[np.ndarray], ref
         f"(= {thr:.4f}; cap on that error {max_err_cap}); largest margin at a first difference {worst:.4f}"
         + (f"; VIOLATIONS {bad[:6]}" if bad else "") + ("" if err_ok else f"; LOGIT ERROR ABOVE CAP"))
     return rep
+
+
+def leading_wide_objects(margins: np.ndarray, thr_ulps: float) -> int:
+    """detect / point goldens: number of leading objects all of whose decisions (and every decision before them)
+    have a reference top-1/top-2 margin >= thr_ulps bf16 ulps of the top logit."""
+    n = 0
+    for row in np.asarray(margins).reshape(len(margins), -1):
+        if float(row.min()) < thr_ulps:
+            break
+        n += 1
+    return n
+
+
+def detect_parity(objects_per_image, golden, thr_ulps: float = 4.0) -> Dict[str, object]:
+    """``detect`` objects against the reference's (tests/golden/md2b_detect13.npz: unfiltered images, every decision's
+    margin recorded).  The region heads' 1024-bin argmaxes are integer decisions like token ids: compared EXACTLY (the
+    floats are functions of the bins) for the leading objects whose every decision -- x, y, w, h bins and the next
+    token -- has a reference margin >= ``thr_ulps`` bf16 ulps; after the first narrower decision the two streams may
+    legitimately part."""
+    n_img = min(len(objects_per_image), int(golden["n_images"]))
+    compared = mismatched = 0
+    detail = []
+    for i in range(n_img):
+        ref = np.asarray(golden[f"img{i}.objects"]).reshape(-1, 4)
+        n_ok = leading_wide_objects(golden[f"img{i}.margins"], thr_ulps) if len(ref) else 0
+        got = objects_per_image[i]
+        for k in range(n_ok):
+            compared += 1
+            g = [got[k][f] for f in ("x_min", "y_min", "x_max", "y_max")] if k < len(got) else None
+            if g != ref[k].tolist():
+                mismatched += 1
+                detail.append((i, k, g, ref[k].tolist()))
+    return {"images": n_img, "objects_compared": compared, "objects_mismatched": mismatched, "margin_floor_ulps": thr_ulps,
+            "ok": mismatched == 0 and compared > 0, "mismatches": detail[:4]}

@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [lora] [0.5b] [2b] [bench64] [reftime]
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [lora] [0.5b] [2b] [bench64] [detect13] [reftime]
 """
 from __future__ import annotations
 
@@ -534,6 +534,82 @@ def gen_detect(name="tiny_detect", cfg_name="tiny", seed=1, n_cases=2, max_objec
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
 
 
+def gen_detect13(name="md2b_detect13", cfg_name="2b", seed=1, n_images=8, max_objects=4, size=(768, 1024)):
+    """BASELINE.json configs[4]'s workload shape at full size: the reference's own ``detect`` on seeded
+    768 x 1024 images (tiling (3, 4) -> 13 crops, image_crops.py:58-167), Moondream-2B, fixed ``max_objects``.
+    UNFILTERED: every image is kept with the bf16-ulp margin of every decision (x, y, w, h bins, next token), so
+    consumers compare objects up to the first narrow decision; the projected multi-crop embeddings (vision.py:77-89 on
+    the stitched 3 x 4 grid, moondream.py:206-228) of the first two images are recorded (sampled) as well.
+    reference: moondream.py:735-781 -> 653-733, region.py:12-93."""
+    from PIL import Image
+
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    out = {"seed": np.int64(seed), "cfg": np.array(cfg_name), "max_objects": np.int64(max_objects), "object_ids": np.array([7, 8]),
+           "size": np.array(size), "n_images": np.int64(n_images), "proj_row_stride": np.int64(9), "proj_col_stride": np.int64(8)}
+    names = ("decode_coordinate", "decode_size")
+    orig = {n: getattr(ref_md, n) for n in names}
+    orig_decode_tok, orig_vis_proj = model._decode_one_tok, model._vis_proj
+
+    def ulps(lg):
+        top = torch.topk(lg.float().reshape(-1), 2).values
+        return float(top[0] - top[1]) / 2.0 ** (np.floor(np.log2(max(abs(float(top[0])), 2.0 ** -120))) - 7)
+
+    for i in range(n_images):
+        image = synth.synthetic_image_array(i, seed, size)
+        rec = {"decode_coordinate": [], "decode_size": [], "next": [], "proj": []}
+
+        def tap(n):
+            def f(x, w):
+                y = orig[n](x, w)
+                rec[n].append(y.detach().clone())
+                return y
+            return f
+
+        def decode_tok_tap(x, mask, pos_ids, lora):
+            logits, hidden = orig_decode_tok(x, mask, pos_ids, lora)
+            rec["next"].append(logits[0].detach().clone())
+            return logits, hidden
+
+        def proj_tap(g, r):
+            y = orig_vis_proj(g, r)
+            rec["proj"].append((tuple(r.shape[:2]), y.detach().clone()))
+            return y
+
+        for n in names:
+            setattr(ref_md, n, tap(n))
+        model._decode_one_tok, model._vis_proj = decode_tok_tap, proj_tap
+        t0 = time.perf_counter()
+        try:
+            res = model.detect(Image.fromarray(image, "RGB"), "7 8", settings={"max_objects": max_objects, "variant": None})
+        finally:
+            for n in names:
+                setattr(ref_md, n, orig[n])
+            model._decode_one_tok, model._vis_proj = orig_decode_tok, orig_vis_proj
+        dt = time.perf_counter() - t0
+        objs = res["objects"]
+        nxt = rec["next"][2::3]  # three decoder steps per object; the last one decides the next token
+        margins = []
+        for k in range(len(objs)):
+            sz = rec["decode_size"][k]
+            margins.append([ulps(rec["decode_coordinate"][2 * k]), ulps(rec["decode_coordinate"][2 * k + 1]), ulps(sz[0]), ulps(sz[1]), ulps(nxt[k])])
+        pfx = f"img{i}."
+        out[pfx + "objects"] = np.array([[o[k] for k in ("x_min", "y_min", "x_max", "y_max")] for o in objs], dtype=np.float64).reshape(len(objs), 4)
+        out[pfx + "margins"] = np.array(margins, dtype=np.float32).reshape(len(objs), 5)
+        out[pfx + "next_tokens"] = np.array([int(torch.argmax(l.float())) for l in nxt], dtype=np.int64)
+        out[pfx + "seconds"] = np.float64(dt)
+        (gh, gw), proj = rec["proj"][0]
+        out[pfx + "grid"] = np.array([gh, gw])
+        if i < 2:
+            out[pfx + "vis.proj"] = bf16_bits(proj[::9, ::8])
+        print(f"[{name}] image {i}: grid {gh}x{gw}, {len(objs)} objects in {dt:.1f}s, margins(ulps) "
+              f"{[round(min(m), 2) for m in margins]}", flush=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
+
+
 def gen_sampling(name="sampling_top_p", seed=7):
     """The reference's sampling filter on fixed logits: softmax(logits / T) -> MoondreamModel._apply_top_p
     (moondream.py:270-278, called at :316-317 and :526-527), bf16 like the decode path's logits.
@@ -764,6 +840,8 @@ def main():
         gen_reftime()
     if "bench64" in which:
         gen_bench64()
+    if "detect13" in which:
+        gen_detect13()
     if "2b" in which:
         gen_model_case("md2b_seed1", "2b", 1, [(378, 378)], 32, False, n_images=3, min_margin=0.5)
 

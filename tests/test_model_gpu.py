@@ -636,6 +636,34 @@ def test_fp8_decode_mode_tiny(tiny):
     fp8_decode_report(model, images, prompts, ids, None, "tiny")
 
 
+def detect13_vs_reference(model, golden_dir):
+    """BASELINE configs[4]'s workload at full size (run inside the 2B test): 768 x 1024 images -> 13 crops, tiling (3, 4);
+    the projected multi-crop embeddings (stitch + adaptive pool to 27 x 27 + projector: moondream.py:206-228, vision.py:77-89)
+    and ``detect`` objects against the reference's (tests/golden/md2b_detect13.npz, unfiltered, margin-aware)."""
+    from moondream_amd import parity as P
+
+    g = load_golden(golden_dir, "md2b_detect13.npz")
+    size, n = tuple(int(x) for x in g["size"]), int(g["n_images"])
+    imgs = [synth.synthetic_image(i, int(g["seed"]), size) for i in range(n)]
+    crops, tiling = model._crop(imgs[0])
+    assert crops.shape[0] == 13 and tuple(tiling) == (3, 4)
+    rs, cs = int(g["proj_row_stride"]), int(g["proj_col_stride"])
+    with torch.inference_mode():
+        emb = model._run_vision_encoder_batch(imgs[:2])
+    for i in range(2):
+        compare(f"2b 13-crop vis.proj img{i}", emb[i][::rs, ::cs], bits_to_bf16(g[f"img{i}.vis.proj"]), 1.5e-2)
+    obj = " ".join(str(t) for t in g["object_ids"].tolist())
+    st = {"max_objects": int(g["max_objects"])}
+    res = model.batch_detect(imgs, [obj] * n, settings=st)
+    rep = P.detect_parity([r["objects"] for r in res], g)
+    print(f"detect13 at 2B: {rep['objects_compared']} objects with every decision >= {rep['margin_floor_ulps']} ulps compared exactly, "
+          f"{rep['objects_mismatched']} mismatched")
+    assert rep["ok"], rep
+    one = model.detect(imgs[3], obj, settings=st)
+    k = P.leading_wide_objects(g["img3.margins"], 4.0)
+    assert one["objects"][:k] == res[3]["objects"][:k]
+
+
 def batch_equals_sequential_unfiltered(model, imgs64, prompt, got64_default, ref_ids, ref_margins, thr):
     """test_batch_equals_sequential_unfiltered (run inside the 2B test: one 2B model per session).  The 64 UNFILTERED bench
     images, Moondream-2B, 32 greedy tokens.
@@ -739,6 +767,7 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
         for i in g["image_index"].tolist():  # the wide-margin images of md2b_seed1 are among the 64: exact
             assert got64[i] == gb["tokens"][i].tolist(), i
     batch_equals_sequential_unfiltered(model, imgs64, pr, got64, ref_ids, gb["margins"], rep["parity_threshold"])
+    detect13_vs_reference(model, golden_dir)
     # opt-in FP8 weight stream for the decode steps of the same configuration (BASELINE configs[4]): a different
     # numerical mode, judged by tolerance against the bf16 path -- never by bit parity
     fp8_decode_report(model, imgs64, [pr] * 64, got64, gb["margins"], "2b B=64")

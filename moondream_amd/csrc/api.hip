@@ -70,10 +70,27 @@ VitWs vit_layout(const md_vit_model* m, int n_crops, void* base) {
   return w;
 }
 
+// Zero fill as a KERNEL, never hipMemsetAsync: a memset captured into a hipGraph becomes a memset node, and from the
+// second replay of a graph on this stack (ROCm 7.2) such a node is not reliably ordered against its neighbouring kernel
+// nodes -- the arrival tickets of the in-launch split-K GEMM were re-zeroed while its K slices were arriving, and decode
+// graphs replayed in a later generator run produced garbage (tools/debug_stale_graph.py; profiles/r03_stale_graph_replay.txt).
+// A kernel node is ordered like every other kernel of the captured stream.
+__global__ void zero_fill_kernel(u32x4* p, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+md_status zero_fill(void* p, size_t bytes, hipStream_t s) {  // p 16-byte aligned, bytes a multiple of 16
+  if (bytes == 0) return MD_OK;
+  if (((uintptr_t)p & 15) != 0 || (bytes & 15) != 0) return MD_ERR_INVALID_ARG;
+  const size_t n16 = bytes / 16;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (u32x4*)p, n16);
+  return md_launch_status();
+}
+
 // zero an A-operand buffer whose leading dimension is padded beyond its logical width
 md_status zero_if_padded(void* p, size_t rows, int ld, int width, hipStream_t s) {
   if (ld == width) return MD_OK;
-  return hipMemsetAsync(p, 0, rows * (size_t)ld * 2, s) == hipSuccess ? MD_OK : MD_ERR_LAUNCH;
+  return zero_fill(p, (rows * (size_t)ld * 2 + 15) / 16 * 16, s);
 }
 
 struct TextWs {
@@ -309,7 +326,7 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       return MD_ERR_LAUNCH;
   }
   if (w.splitk_bytes) {
-    if (hipMemsetAsync(w.splitk, 0, 8192, s) != hipSuccess) return MD_ERR_LAUNCH;  // arrival tickets
+    MD_TRY(zero_fill(w.splitk, 8192, s));  // arrival tickets
   }
   int32_t* kv_len = (int32_t*)w.pos_kv;
   hipLaunchKernelGGL(kv_len_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, pos0, kv_len, q_len, batch);

@@ -55,17 +55,24 @@ def overlap_crop_image(
     max_crops: int,
     base_size: Tuple[int, int] = (378, 378),
     patch_size: int = 14,
+    out: "np.ndarray | None" = None,
 ) -> OverlapCropOutput:
     """crops[0] = whole image resized to base_size; crops[1:] = base_size windows
     at stride (base - 2*margin*patch) over the image resized to the tiling.
-    reference: image_crops.py:58-167."""
+    reference: image_crops.py:58-167.  ``out``: a caller-owned uint8 array of the right shape
+    (``crop_count`` x base x base x C, e.g. a slice of a pinned staging buffer) to cut the crops into."""
     src_h, src_w = image.shape[:2]
     margin_px = patch_size * overlap_margin
     window = (base_size[0] // patch_size - 2 * overlap_margin) * patch_size  # stride between crops
 
     tiling = select_tiling(src_h - 2 * margin_px, src_w - 2 * margin_px, window, max_crops)
     th, tw = tiling
-    crops = np.zeros((th * tw + 1, base_size[0], base_size[1], image.shape[2]), dtype=np.uint8)
+    shape = (th * tw + 1, base_size[0], base_size[1], image.shape[2])
+    if out is None:
+        crops = np.zeros(shape, dtype=np.uint8)
+    else:
+        assert out.shape == shape and out.dtype == np.uint8, (out.shape, shape)
+        crops = out
 
     resized = _resize(image, th * window + 2 * margin_px, tw * window + 2 * margin_px)
     crops[0] = _resize(image, base_size[0], base_size[1])
@@ -73,8 +80,19 @@ def overlap_crop_image(
         for tx in range(tw):
             y0, x0 = ty * window, tx * window
             piece = resized[y0 : min(y0 + base_size[0], resized.shape[0]), x0 : min(x0 + base_size[1], resized.shape[1])]
+            if out is not None and piece.shape[:2] != tuple(base_size):
+                crops[1 + ty * tw + tx] = 0  # (cannot happen for the reference's geometry: the resized image is th*window + 2*margin)
             crops[1 + ty * tw + tx, : piece.shape[0], : piece.shape[1]] = piece
     return {"crops": crops, "tiling": tiling}
+
+
+def crop_count(height: int, width: int, overlap_margin: int, max_crops: int, base_size: Tuple[int, int] = (378, 378),
+               patch_size: int = 14) -> Tuple[int, Tuple[int, int]]:
+    """(number of crops incl. the global one, tiling) ``overlap_crop_image`` will produce for an image of this size."""
+    margin_px = patch_size * overlap_margin
+    window = (base_size[0] // patch_size - 2 * overlap_margin) * patch_size
+    th, tw = select_tiling(height - 2 * margin_px, width - 2 * margin_px, window, max_crops)
+    return th * tw + 1, (th, tw)
 
 
 def reconstruct_from_crops(

@@ -28,7 +28,7 @@ from PIL import Image
 
 from . import _lib
 from .config import MoondreamConfig
-from .image_crops import overlap_crop_image, reconstruct_from_crops
+from .image_crops import crop_count, overlap_crop_image, reconstruct_from_crops
 from .lora import variant_state_dict
 from .weights import PackedLora, PackedModel
 
@@ -410,17 +410,39 @@ class MoondreamModel:
 
         Host tiling (PIL, reference image_crops.py:58-167) runs on a thread pool and is
         pipelined against the GPU: the ViT of image chunk k is enqueued (async) while
-        the crops of chunk k+1 are still being cut."""
+        the crops of chunk k+1 are still being cut.  The workers cut their crops STRAIGHT
+        INTO the pinned staging buffer the H2D copy reads (the tiling, hence every image's
+        crop count and offset, follows from its size alone): no concatenation pass over the
+        crop bytes on the host."""
         v = self.config.vision
         n_img = len(images)
         pool = self._crop_pool()
-        futures = [pool.submit(self._crop, im) for im in images]
-        per_chunk = max(1, self.vit_chunk_crops // 2)  # images per ViT launch group
+        per_chunk = max(1, self.vit_chunk_crops // 2)  # images per ViT launch group (2 crops each at 378 x 378; more for large images)
+        counts = [crop_count(im.size[1], im.size[0], v.overlap_margin, v.max_crops, (v.crop_size, v.crop_size), v.enc_patch_size)
+                  for im in images]
         cropped: List[Tuple[np.ndarray, Tuple[int, int]]] = []
         feat_parts = []
-        for i0 in range(0, n_img, per_chunk):
-            part = [f.result() for f in futures[i0 : i0 + per_chunk]]
-            if mark is not None and i0 == 0:
+        # chunks: consecutive images whose crops total <= vit_chunk_crops (at least one image)
+        chunks, i0 = [], 0
+        while i0 < n_img:
+            i1, tot = i0, 0
+            while i1 < n_img and (i1 == i0 or (tot + counts[i1][0] <= max(self.vit_chunk_crops, 1) and i1 - i0 < per_chunk * 8)):
+                tot += counts[i1][0]
+                i1 += 1
+            chunks.append((i0, i1, tot))
+            i0 = i1
+        staged = []
+        for (c0, c1, tot) in chunks:  # all host work is queued up front; the GPU side follows chunk by chunk
+            host, token = self._pinned_crops(tot, (v.crop_size, v.crop_size, 3))
+            futs, off = [], 0
+            for i in range(c0, c1):
+                n = counts[i][0]
+                futs.append(pool.submit(self._crop_into, images[i], host[off : off + n]))
+                off += n
+            staged.append((host, token, futs))
+        for ci, ((c0, c1, tot), (host, token, futs)) in enumerate(zip(chunks, staged)):
+            part = [f.result() for f in futs]
+            if mark is not None and ci == 0:
                 mark("host_tiling")  # phase timing: the GPU has nothing of this batch to run before the first crops exist
             cropped.extend(part)
             if self.dedup_identical_crops:
@@ -436,13 +458,16 @@ class MoondreamModel:
                     else:
                         expand += list(range(len(uniq), len(uniq) + c.shape[0]))
                         uniq.extend(c[k : k + 1] for k in range(c.shape[0]))
-                dev_crops = self._upload_crops(uniq)
+                host2, token2 = self._pinned_crops(len(uniq), (v.crop_size, v.crop_size, 3))
+                np.concatenate(uniq, axis=0, out=host2)
+                dev_crops = self._upload_pinned(host2, token2)
+                self._release_pinned(token)
                 f = self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC)
                 if len(expand) != dev_crops.shape[0]:
                     f = f[torch.tensor(expand, dtype=torch.int64, device=self._device)]
                 feat_parts.append(f)
                 continue
-            dev_crops = self._upload_crops([c for c, _ in part])
+            dev_crops = self._upload_pinned(host, token)
             feat_parts.append(self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC))
         feats = feat_parts[0] if len(feat_parts) == 1 else torch.cat(feat_parts, dim=0)  # [sum crops, 729, Dv]
         out = torch.empty(n_img, v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
@@ -475,32 +500,52 @@ class MoondreamModel:
                 out[torch.tensor(idxs, device=self._device)] = o
         return out
 
-    def _upload_crops(self, parts: Sequence[np.ndarray]) -> torch.Tensor:
-        """uint8 crops [n_i, 378, 378, 3] -> one device tensor, through PINNED staging buffers (a pageable source makes
-        the runtime bounce the copy through its own small pinned buffers, synchronously: ~2x the time, and the host
-        cannot queue the ViT launches behind it).  Four buffers rotate; a buffer is reused only after the copy that
-        read it has completed (its event)."""
-        n = sum(int(p.shape[0]) for p in parts)
-        shape = (n,) + tuple(parts[0].shape[1:])
+    def _crop_into(self, image: Image.Image, out: np.ndarray):
+        v = self.config.vision
+        arr = np.asarray(image.convert("RGB"))
+        oc = overlap_crop_image(arr, max_crops=v.max_crops, overlap_margin=v.overlap_margin, base_size=(v.crop_size, v.crop_size),
+                                patch_size=v.enc_patch_size, out=out)
+        return oc["crops"], tuple(oc["tiling"])
+
+    # PINNED staging for the uint8 crops (a pageable source makes the runtime bounce the copy through its own small pinned
+    # buffers, synchronously: ~2x the time, and the host cannot queue the ViT launches behind it).  A small set of buffers
+    # rotates; a buffer is handed out again only after the copy that read it has completed (its event).
+    def _pinned_crops(self, n_crops: int, crop_shape):
+        shape = (int(n_crops),) + tuple(crop_shape)
         nbytes = int(np.prod(shape))
         ring = getattr(self, "_pinned", None)
         if ring is None:
-            ring = self._pinned = {"bufs": [None] * 4, "events": [None] * 4, "next": 0}
-        i = ring["next"]
-        ring["next"] = (i + 1) % len(ring["bufs"])
-        buf = ring["bufs"][i]
-        if buf is None or buf.numel() < nbytes:
+            ring = self._pinned = {"bufs": [], "events": [], "busy": []}
+        pick = None
+        for i, (buf, busy) in enumerate(zip(ring["bufs"], ring["busy"])):
+            if not busy and buf.numel() >= nbytes:
+                pick = i
+                break
+        if pick is None:
             with torch.inference_mode(False):
-                buf = ring["bufs"][i] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
-        elif ring["events"][i] is not None:
-            ring["events"][i].synchronize()
-        host = buf[:nbytes].numpy().reshape(shape)
-        np.concatenate(parts, axis=0, out=host)
-        dev = buf[:nbytes].view(shape).to(self._device, non_blocking=True)
+                ring["bufs"].append(torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True))
+            ring["events"].append(None)
+            ring["busy"].append(False)
+            pick = len(ring["bufs"]) - 1
+        if ring["events"][pick] is not None:
+            ring["events"][pick].synchronize()
+            ring["events"][pick] = None
+        ring["busy"][pick] = True
+        host = ring["bufs"][pick][:nbytes].numpy().reshape(shape)
+        return host, pick
+
+    def _upload_pinned(self, host: np.ndarray, token: int) -> torch.Tensor:
+        ring = self._pinned
+        nbytes = int(host.size)
+        dev = ring["bufs"][token][:nbytes].view(host.shape).to(self._device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self._device))
-        ring["events"][i] = ev
+        ring["events"][token] = ev
+        ring["busy"][token] = False  # reusable once the event has passed (checked when it is handed out again)
         return dev
+
+    def _release_pinned(self, token: int):
+        self._pinned["busy"][token] = False
 
     def _crop_pool(self):
         pool = getattr(self, "_pool", None)
@@ -512,7 +557,7 @@ class MoondreamModel:
                 n = len(os.sched_getaffinity(0))
             except AttributeError:
                 n = os.cpu_count() or 1
-            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(16, n)))
+            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(32, n)))
         return pool
 
     def _run_vision_encoder(self, image: Image.Image) -> torch.Tensor:

@@ -90,3 +90,19 @@ def test_random_sizes_against_the_reference_itself():
         ra = reconstruct_from_crops(feats, (th, tw), overlap_margin=4, patch_size=1)
         rb = ref.reconstruct_from_crops(feats, (th, tw), overlap_margin=4, patch_size=1)
         assert torch.equal(ra, rb), (h, w)
+
+
+def test_crop_count_and_out_buffer_match_the_allocating_form():
+    """crop_count predicts what overlap_crop_image produces; cutting into a caller-owned buffer (the pinned staging
+    path of the engine) gives the same bytes as the allocating form."""
+    from moondream_amd.image_crops import crop_count
+
+    rng = np.random.default_rng(11)
+    for size in [(378, 378), (200, 300), (500, 700), (768, 1024), (420, 1000), (1500, 900)]:
+        img = rng.integers(0, 256, (size[0], size[1], 3), dtype=np.uint8)
+        ref = overlap_crop_image(img, overlap_margin=4, max_crops=12)
+        n, tiling = crop_count(size[0], size[1], 4, 12)
+        assert n == ref["crops"].shape[0] and tuple(tiling) == tuple(ref["tiling"])
+        out = np.full((n, 378, 378, 3), 7, dtype=np.uint8)
+        got = overlap_crop_image(img, overlap_margin=4, max_crops=12, out=out)
+        assert got["crops"] is out and np.array_equal(out, ref["crops"])

@@ -24,6 +24,30 @@ def img(i):
     return Image.fromarray(synth.synthetic_image_array(int(g["image_index"][i]), int(g["seed"]), tuple(g[f"img{i}.cap.size"])), "RGB")
 
 
+MODE = os.environ.get("MD_REPEAT_MODE", "")
+if MODE == "one_stream":
+    st = torch.cuda.Stream()
+    model._pipe_streams = (st, st)
+elif MODE == "no_priority":
+    model._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+elif MODE == "sync_before_decode":
+    _orig = model._decode_greedy
+
+    def _synced(*a, **k):
+        torch.cuda.synchronize()
+        return _orig(*a, **k)
+
+    model._decode_greedy = _synced
+elif MODE == "sync_after_decode":
+    _orig = model._decode_greedy
+
+    def _synced(*a, **k):
+        r = _orig(*a, **k)
+        torch.cuda.synchronize()
+        return r
+
+    model._decode_greedy = _synced
+print("mode:", MODE or "default", flush=True)
 images = [img(i) for i in range(3)]
 prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(3)]
 n = len(g["img0.cap.tokens"])
@@ -34,6 +58,9 @@ bad = 0
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     for use_graphs in (False, True):
         model.use_graphs = use_graphs
+        if MODE == "fresh_graphs":
+            torch.cuda.synchronize()
+            model._graphs.clear()
         outs = list(model.batch_generate_ids_pipelined(batches, max_tokens=n))
         model.use_graphs = False
         for bi, (o, w) in enumerate(zip(outs, want)):

@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the auxiliary FP8-decode-weights leg")
+    ap.add_argument("--no-fp8-full-leg", action="store_true", help="skip the auxiliary full-FP8 leg (fp8 MFMA for ViT / projector / prefill + fp8 decode weights)")
     ap.add_argument("--no-dedup-leg", action="store_true", help="skip the auxiliary identical-crop-dedup leg")
     ap.add_argument("--no-graphs", action="store_true", help="launch decode steps eagerly instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true", help="run each step's encode and decode back to back on one stream")
@@ -586,6 +587,51 @@ def main():
             }
         finally:
             model.enable_fp8_decode(False)
+
+    # auxiliary leg, NOT the headline: the full opt-in FP8 mode (BASELINE configs[4] "fp8 weights, CDNA4 fp8 MFMA") -- every
+    # MFMA-bound linear of the ViT blocks, the projector and the prefill on md_gemm_f8 (e4m3 operands, static per-tensor
+    # activation scales calibrated on 8 of these images), plus the fp8 decode weight stream.  A different numerical mode
+    # (tolerance-judged in tests/test_model_gpu.py), so it never feeds `value`; its ids are compared with this run's bf16 ids.
+    if world == 1 and not args.no_fp8_full_leg:
+        info = model.enable_fp8(images[:8], prompt)
+        try:
+            run_steps(2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out8 = run_steps(3)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 3
+            graphs_were = model.use_graphs
+            model.use_graphs = False
+            model.collect_timing = True
+            model.batch_generate_ids(images, prompts, max_tokens=T, ignore_eos=True)
+            torch.cuda.synchronize()
+            model.collect_timing = False
+            model.use_graphs = graphs_were
+            phase8 = {k: round(v, 2) for k, v in model.last_phase_ms.items()}
+            ids8 = torch.cat([b.cpu() for b in out8[-1]], 0).tolist() if out8 and out8[-1] is not None else None
+            same, prefix = None, None
+            if ids8 is not None and out and out[-1] is not None:
+                ids16 = torch.cat([b.cpu() for b in out[-1]], 0).tolist()
+                same = sum(a == b for a, b in zip(ids8, ids16))
+                prefix = float(np.mean([next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(b)) for a, b in zip(ids8, ids16)]))
+            leg8 = {
+                "images_per_sec": B / dt, "ms_per_step": dt * 1e3, "speedup_vs_bf16_value": (B / dt) / (n_total * args.steps / elapsed),
+                "phase_ms": phase8, "sequences_identical_to_bf16": same, "mean_matching_prefix_tokens": prefix, "of": B,
+                "calibration": {"images": 8, "margin": info["margin"], "vit_amax_max": max(info["vit_amax"]), "text_amax_max": max(info["text_amax"])},
+                "note": "md_gemm_f8: OCP e4m3 operands on v_mfma_f32_32x32x64_f8f6f4, fp32 accumulation, per-channel weight scales, one "
+                        "static scale per activation tensor; LN -> fp8, GELU epilogue -> fp8, attention output quantised by a separate "
+                        "pass; patch embedding, attention, RoPE, KV cache, residual stream and lm_head at prefill stay bf16; decode "
+                        "steps stream e4m3 weights (the fp8_decode leg's mode)",
+            }
+            if args.model == "2b" and phase8.get("vision"):
+                vit_flops = len(images) * (2 * FLOP_VIT_PER_CROP + 51.98e9)
+                leg8["vit_encoder"] = {"achieved": vit_flops / (phase8["vision"] * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                       "frac_of_bf16_peak_2500": vit_flops / (phase8["vision"] * 1e-3) / 1e12 / 2500.0,
+                                       "frac_of_fp8_peak_5000": vit_flops / (phase8["vision"] * 1e-3) / 1e12 / 5000.0}
+            result["fp8_full"] = leg8
+        finally:
+            model.enable_fp8(on=False)
 
     if world == 1 and not args.no_cpu_baseline:
         est, cores, note = cpu_baseline(cfg, sd, args.seed, T)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 2 /* 2: md_text_model.fp8 (trailing, optional) */
+#define MD_ABI_VERSION 3 /* 2: md_text_model.fp8 (trailing, optional); 3: md_vit_model.f8, md_text_model.f8 (trailing, optional), md_gemm_f8 + fp8 producers, md_decode_step_b1_supported */
 
 typedef int md_status;
 enum {
@@ -155,6 +155,55 @@ int32_t md_gemm_fp8w_partial_slices(const md_linear_fp8* lin);
 md_status md_gemm_fp8w_partial_f32_pair(const void* a0, int64_t lda0, const md_linear_fp8* lin0, float* partial0,
                                         const void* a1, int64_t lda1, const md_linear_fp8* lin1, float* partial1,
                                         int32_t m, int64_t ld_partial, int64_t slice_stride, void* stream);
+
+/* ---- FP8 operands for the MFMA-bound linears (opt-in numerical mode; BASELINE configs[4] "CDNA4 fp8 MFMA") ---------
+ * Both operands OCP e4m3fn, ROW-MAJOR with K contiguous (the layout v_mfma_f32_32x32x64_f8f6f4 consumes: a lane's
+ * operand is 32 consecutive bytes of a row), fp32 accumulation:
+ *   value[m][n] = a_scale * scale[n] * sum_k a8[m][k] * w8[n][k] + b[n]
+ * then the bf16 kernels' rounding points (ONE rounding of value to bf16, then GELU / residual add).  The reference has
+ * no fp8 path (its only quantised format is int4, layers.py:38-109): this mode is judged by tolerance against the
+ * bf16 path, never by bit parity.
+ * w: [n_pad][k_pad] bytes, zero padded, k_pad % 64 == 0, n_pad % 64 == 0; scale: fp32 [n_pad] (weight[n][k] ~=
+ * scale[n] * fp8[n][k]); b: bf16 [n_pad] or NULL. */
+typedef struct {
+  const void* w;
+  const float* scale;
+  const void* b;
+  int32_t n, k, n_pad, k_pad;
+} md_linear_f8;
+
+typedef struct {
+  const void* a;      /* e4m3fn [m][lda] bytes, lda >= k_pad, lda % 16 == 0, columns k..k_pad-1 ZERO (0x00) */
+  int64_t lda;
+  float a_scale;      /* activation[m][k] ~= a_scale * fp8 (one scale per tensor) */
+  md_linear_f8 lin;
+  void* c;            /* bf16 result [m][ldc] (columns < f8_from_col when c8 is given); may be NULL if everything goes to c8 */
+  int64_t ldc;
+  void* c8;           /* optional e4m3fn result of columns >= f8_from_col: c8[m][n - f8_from_col] = fp8(sat(value * c8_inv_scale)) */
+  int64_t ldc8;       /* bytes between rows of c8 (% 8 == 0) */
+  float c8_inv_scale;
+  int32_t f8_from_col; /* multiple of 64 */
+  const void* r;      /* MD_EPI_RESIDUAL operand (bf16), may alias c */
+  int64_t ldr;
+  int32_t res_row_mod;
+  int32_t m;
+  int32_t epilogue;       /* MD_EPI_* */
+  int32_t store_pad_cols; /* 1: also store columns [n, n_pad) (zeros) */
+  int32_t gelu_from_col;  /* MD_EPI_GELU: GELU applies to columns >= this */
+} md_gemm_f8_args;
+md_status md_gemm_f8(const md_gemm_f8_args* args, void* stream);
+
+/* bf16 [rows][ldx] -> e4m3fn [rows][ldy bytes]: y = fp8(sat(x * inv_scale)) for columns < cols, 0x00 for columns
+ * cols..cols_pad-1 (the consumer's K padding).  cols % 8 == 0, cols_pad % 8 == 0. */
+md_status md_quantize_f8(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t cols_pad,
+                         float inv_scale, void* stream);
+/* md_layernorm_bf16 with the result rounded to bf16 (the reference's rounding point) and then quantised like
+ * md_quantize_f8; columns dim..dim_pad-1 of y are written as zero. */
+md_status md_layernorm_f8(const void* x, int64_t ldx, void* y, int64_t ldy, const md_layernorm* p, int32_t rows,
+                          int32_t dim, int32_t dim_pad, float eps, float inv_scale, void* stream);
+/* *amax = max(*amax, max |x[r][c]|) over rows x cols (calibration of the activation scales; *amax is device memory the
+ * caller zeroes; non-finite values are ignored). */
+md_status md_amax_bf16(const void* x, int64_t ldx, int32_t rows, int32_t cols, float* amax, void* stream);
 
 /* Measurement / test hook, not needed by the product path: overrides one of the GEMM dispatch
  * knobs at run time (the same knobs are read once from MD_GEMM_* / MD_DECODE_* environment
@@ -322,6 +371,24 @@ typedef struct {
   md_linear fc1, fc2;
 } md_vit_block;
 
+/* Optional FP8 mode of the vision path (md_gemm_f8 above): e4m3 copies of every block's four linears and of the
+ * projector MLP, and ONE static scale per quantised activation tensor (s_*: activation ~= s * fp8), found by a
+ * calibration pass.  calib != NULL: md_vit_encode / md_vision_project run the bf16 path and record the running
+ * max |x| of every quantisation site into calib (device fp32, zeroed by the caller: [4 l + {0 ln1, 1 attention,
+ * 2 ln2, 3 gelu}] for block l, then [4 n_layers] the projector's concatenated input, [4 n_layers + 1] its GELU
+ * output).  calib == NULL and blocks != NULL: the fp8 path runs (patch embedding, attention, layer norms'
+ * statistics and the residual stream stay bf16 / fp32). */
+typedef struct {
+  md_linear_f8 qkv, proj, fc1, fc2;
+  float s_ln1, s_att, s_ln2, s_ff;
+} md_vit_block_f8;
+typedef struct {
+  const md_vit_block_f8* blocks; /* host array of n_layers, or NULL */
+  md_linear_f8 proj_fc1, proj_fc2;
+  float s_cat, s_pff;
+  float* calib;
+} md_vit_f8;
+
 typedef struct {
   int32_t dim, n_heads, n_layers, ff_dim;
   int32_t patch, crop;     /* 14, 378 */
@@ -331,6 +398,7 @@ typedef struct {
   md_layernorm post_ln;
   md_linear proj_fc1, proj_fc2; /* vision projector MLP (vision.py:77-89) */
   const void* pixel_lut;   /* bf16 [256] */
+  const md_vit_f8* f8;     /* NULL: bf16 everywhere (the reference's precision) */
 } md_vit_model;
 
 enum { MD_CROPS_U8_HWC = 0, MD_CROPS_BF16_CHW = 1 };
@@ -383,6 +451,19 @@ typedef struct {
   md_linear_fp8 lm_head;
 } md_text_fp8;
 
+/* Optional FP8 mode of the decoder's PREFILL (launches of more than 64 rows; md_gemm_f8): e4m3 copies of the fused
+ * qkv|fc1, proj and fc2 matrices of every block and one static scale per quantised activation tensor.  calib as in
+ * md_vit_f8: [3 l + {0 ln, 1 attention, 2 gelu}].  Needs the fused qkv|fc1 packing.  RoPE, attention, the KV cache
+ * and the residual stream stay bf16. */
+typedef struct {
+  md_linear_f8 qkv_fc1, proj, fc2;
+  float s_ln, s_att, s_ff;
+} md_text_block_f8;
+typedef struct {
+  const md_text_block_f8* blocks; /* host array of n_layers, or NULL */
+  float* calib;
+} md_text_f8;
+
 typedef struct {
   int32_t dim, n_heads, n_kv_heads, n_layers, ff_dim, vocab, max_context, prefix_len, rot_dim;
   const md_text_block* blocks; /* host array of n_layers */
@@ -391,6 +472,7 @@ typedef struct {
   const void* wte;       /* bf16 [vocab][dim] */
   const float* freqs;    /* fp32 [max_context][rot_dim/2][2] */
   const md_text_fp8* fp8; /* NULL: bf16 weights everywhere (the reference's precision) */
+  const md_text_f8* f8;  /* NULL: bf16 prefill */
 } md_text_model;
 
 /* KV slabs: layer l's keys at k + l*layer_stride, element (b,h,p,d) at

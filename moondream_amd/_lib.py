@@ -16,10 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "decode_b1.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "gemm_f8.hip", "quant_f8.hip", "decode_b1.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
-ABI_VERSION = 2  # include/moondream_hip.h MD_ABI_VERSION
+ABI_VERSION = 3  # include/moondream_hip.h MD_ABI_VERSION
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
 MD_CROPS_U8_HWC, MD_CROPS_BF16_CHW = 0, 1
 
@@ -60,12 +60,27 @@ class MdVitBlock(C.Structure):
                 ("fc1", MdLinear), ("fc2", MdLinear)]
 
 
+class MdLinearF8(C.Structure):
+    _fields_ = [("w", c_void_p), ("scale", c_void_p), ("b", c_void_p), ("n", c_int32), ("k", c_int32),
+                ("n_pad", c_int32), ("k_pad", c_int32)]
+
+
+class MdVitBlockF8(C.Structure):
+    _fields_ = [("qkv", MdLinearF8), ("proj", MdLinearF8), ("fc1", MdLinearF8), ("fc2", MdLinearF8),
+                ("s_ln1", c_float), ("s_att", c_float), ("s_ln2", c_float), ("s_ff", c_float)]
+
+
+class MdVitF8(C.Structure):
+    _fields_ = [("blocks", C.POINTER(MdVitBlockF8)), ("proj_fc1", MdLinearF8), ("proj_fc2", MdLinearF8),
+                ("s_cat", c_float), ("s_pff", c_float), ("calib", c_void_p)]
+
+
 class MdVitModel(C.Structure):
     _fields_ = [
         ("dim", c_int32), ("n_heads", c_int32), ("n_layers", c_int32), ("ff_dim", c_int32),
         ("patch", c_int32), ("crop", c_int32), ("patch_emb", MdLinear), ("pos_emb", c_void_p),
         ("blocks", C.POINTER(MdVitBlock)), ("post_ln", MdLayerNorm), ("proj_fc1", MdLinear),
-        ("proj_fc2", MdLinear), ("pixel_lut", c_void_p),
+        ("proj_fc2", MdLinear), ("pixel_lut", c_void_p), ("f8", C.POINTER(MdVitF8)),
     ]
 
 
@@ -79,6 +94,14 @@ class MdLinearFp8(C.Structure):
                 ("n_pad", c_int32), ("k_pad", c_int32)]
 
 
+class MdGemmF8Args(C.Structure):
+    _fields_ = [
+        ("a", c_void_p), ("lda", c_int64), ("a_scale", c_float), ("lin", MdLinearF8), ("c", c_void_p), ("ldc", c_int64),
+        ("c8", c_void_p), ("ldc8", c_int64), ("c8_inv_scale", c_float), ("f8_from_col", c_int32), ("r", c_void_p), ("ldr", c_int64),
+        ("res_row_mod", c_int32), ("m", c_int32), ("epilogue", c_int32), ("store_pad_cols", c_int32), ("gelu_from_col", c_int32),
+    ]
+
+
 class MdTextBlockFp8(C.Structure):
     _fields_ = [("qkv_fc1", MdLinearFp8), ("proj", MdLinearFp8), ("fc2", MdLinearFp8)]
 
@@ -87,12 +110,22 @@ class MdTextFp8(C.Structure):
     _fields_ = [("blocks", C.POINTER(MdTextBlockFp8)), ("lm_head", MdLinearFp8)]
 
 
+class MdTextBlockF8(C.Structure):
+    _fields_ = [("qkv_fc1", MdLinearF8), ("proj", MdLinearF8), ("fc2", MdLinearF8),
+                ("s_ln", c_float), ("s_att", c_float), ("s_ff", c_float)]
+
+
+class MdTextF8(C.Structure):
+    _fields_ = [("blocks", C.POINTER(MdTextBlockF8)), ("calib", c_void_p)]
+
+
 class MdTextModel(C.Structure):
     _fields_ = [
         ("dim", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("n_layers", c_int32),
         ("ff_dim", c_int32), ("vocab", c_int32), ("max_context", c_int32), ("prefix_len", c_int32),
         ("rot_dim", c_int32), ("blocks", C.POINTER(MdTextBlock)), ("post_ln", MdLayerNorm),
         ("lm_head", MdLinear), ("wte", c_void_p), ("freqs", c_void_p), ("fp8", C.POINTER(MdTextFp8)),
+        ("f8", C.POINTER(MdTextF8)),
     ]
 
 
@@ -125,6 +158,10 @@ SIGNATURES = {
     "md_gemm_fp8w_partial_slices": (c_int32, [P(MdLinearFp8)]),
     "md_gemm_fp8w_partial_f32_pair": (C.c_int, [c_void_p, c_int64, P(MdLinearFp8), c_void_p, c_void_p, c_int64, P(MdLinearFp8),
                                                 c_void_p, c_int32, c_int64, c_int64, c_void_p]),
+    "md_gemm_f8": (C.c_int, [P(MdGemmF8Args), c_void_p]),
+    "md_quantize_f8": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "md_layernorm_f8": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
+    "md_amax_bf16": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "md_gemm_set_tuning": (C.c_int, [C.c_char_p, c_int32]),
     "md_profile_gemm": (None, [c_int32]),
     "md_profile_gemm_read": (C.c_int, [c_int32, P(C.c_double), P(C.c_double), P(c_int64)]),

@@ -52,6 +52,25 @@ md_status gemm(const void* a, int64_t lda, const md_linear& lin, void* c, int64_
   return md_gemm_bf16(&g, s);
 }
 
+
+// ---- FP8 mode helpers (md_gemm_f8 and its activation producers; opt-in, see md_vit_f8 / md_text_f8) ----------------
+md_status gemm_f8(const void* a8, int64_t lda, float a_scale, const md_linear_f8& lin, void* c, int64_t ldc, int m, int epi,
+                  const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s, void* c8 = nullptr, int64_t ldc8 = 0,
+                  float c8_scale = 1.f, int f8_from = 0, int gelu_from = 0) {
+  md_gemm_f8_args g;
+  g.a = a8; g.lda = lda; g.a_scale = a_scale; g.lin = lin; g.c = c; g.ldc = ldc;
+  g.c8 = c8; g.ldc8 = ldc8; g.c8_inv_scale = c8 ? 1.0f / c8_scale : 1.0f; g.f8_from_col = f8_from;
+  g.r = r; g.ldr = ldr; g.res_row_mod = res_row_mod; g.m = m; g.epilogue = epi; g.store_pad_cols = store_pad;
+  g.gelu_from_col = gelu_from;
+  return md_gemm_f8(&g, s);
+}
+// calibration: running max |x| of a quantisation site
+md_status calib_site(float* calib, int site, const void* x, int64_t ldx, int rows, int cols, hipStream_t s) {
+  if (!calib) return MD_OK;
+  return md_amax_bf16(x, ldx, rows, cols / 8 * 8, calib + site, s);
+}
+bool f8_scales_ok(float a, float b, float c, float d = 1.f) { return a > 0.f && b > 0.f && c > 0.f && d > 0.f; }
+
 struct VitWs {
   void *patches, *x, *h, *qkv, *ff;
   size_t total;
@@ -194,11 +213,15 @@ extern "C" md_status md_vit_encode(const md_vit_model* m, const void* crops, int
   MD_TRY(gemm(w.patches, kp, m->patch_emb, w.x, D, M, MD_EPI_RESIDUAL, m->pos_emb, D, T, 0, s));
 
   const float scale = 1.0f / sqrtf((float)hd);
+  // FP8 mode (opt-in): LN -> fp8, the four linears on md_gemm_f8, attention output quantised for proj.  The fp8
+  // activations live in the (then unused) bf16 ff buffer: [ff8: M x fc1.n_pad bytes | h8: M x Dp bytes].
+  const md_vit_f8* f8 = m->f8;
+  float* calib = f8 ? f8->calib : nullptr;
+  const bool use_f8 = f8 && !calib && f8->blocks;
+  uint8_t *ff8 = (uint8_t*)w.ff, *h8 = (uint8_t*)w.ff + (size_t)M * m->blocks[0].fc1.n_pad;
+  if (use_f8) MD_CHECK_ARG(m->blocks[0].fc1.n_pad >= Dp);
   for (int l = 0; l < m->n_layers; ++l) {
     const md_vit_block& b = m->blocks[l];
-    // x = x + attn(ln1(x))                    (vision.py:70, layers.py:155-166)
-    MD_TRY(md_layernorm_bf16(w.x, D, w.h, Dp, &b.ln1, M, D, 1e-5f, s));
-    MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, 3 * D, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));
     md_attn_args a;
     const bf16_t* qkv = (const bf16_t*)w.qkv;
     a.q = qkv;
@@ -220,11 +243,31 @@ extern "C" md_status md_vit_encode(const md_vit_model* m, const void* crops, int
     a.kv_len = nullptr;
     a.prefix_len = T;  // everything visible: no mask
     a.scale = scale;
+    if (use_f8) {
+      const md_vit_block_f8& q = f8->blocks[l];
+      MD_CHECK_ARG(f8_scales_ok(q.s_ln1, q.s_att, q.s_ln2, q.s_ff) && q.fc2.k_pad == q.fc1.n_pad && q.qkv.k_pad == Dp);
+      MD_TRY(md_layernorm_f8(w.x, D, h8, Dp, &b.ln1, M, D, Dp, 1e-5f, 1.0f / q.s_ln1, s));
+      MD_TRY(gemm_f8(h8, Dp, q.s_ln1, q.qkv, w.qkv, 3 * D, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));
+      MD_TRY(md_attention_prefill(&a, s));
+      MD_TRY(md_quantize_f8(w.h, Dp, h8, Dp, M, D, Dp, 1.0f / q.s_att, s));
+      MD_TRY(gemm_f8(h8, Dp, q.s_att, q.proj, w.x, D, M, MD_EPI_RESIDUAL, w.x, D, 0, 0, s));
+      MD_TRY(md_layernorm_f8(w.x, D, h8, Dp, &b.ln2, M, D, Dp, 1e-5f, 1.0f / q.s_ln2, s));
+      MD_TRY(gemm_f8(h8, Dp, q.s_ln2, q.fc1, nullptr, 0, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, ff8, q.fc1.n_pad, q.s_ff, 0, 0));
+      MD_TRY(gemm_f8(ff8, q.fc1.n_pad, q.s_ff, q.fc2, w.x, D, M, MD_EPI_RESIDUAL, w.x, D, 0, 0, s));
+      continue;
+    }
+    // x = x + attn(ln1(x))                    (vision.py:70, layers.py:155-166)
+    MD_TRY(md_layernorm_bf16(w.x, D, w.h, Dp, &b.ln1, M, D, 1e-5f, s));
+    MD_TRY(calib_site(calib, 4 * l + 0, w.h, Dp, M, D, s));
+    MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, 3 * D, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));
     MD_TRY(md_attention_prefill(&a, s));
+    MD_TRY(calib_site(calib, 4 * l + 1, w.h, Dp, M, D, s));
     MD_TRY(gemm(w.h, Dp, b.proj, w.x, D, M, MD_EPI_RESIDUAL, w.x, D, 0, 0, s));
     // x = x + mlp(ln2(x))                     (vision.py:71, layers.py:129-146)
     MD_TRY(md_layernorm_bf16(w.x, D, w.h, Dp, &b.ln2, M, D, 1e-5f, s));
+    MD_TRY(calib_site(calib, 4 * l + 2, w.h, Dp, M, D, s));
     MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, b.fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s));
+    MD_TRY(calib_site(calib, 4 * l + 3, w.ff, b.fc1.n_pad, M, b.fc1.n, s));
     MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad);
     MD_TRY(gemm(w.ff, b.fc1.n_pad, b.fc2, w.x, D, M, MD_EPI_RESIDUAL, w.x, D, 0, 0, s));
   }
@@ -235,6 +278,26 @@ extern "C" size_t md_vision_project_workspace_bytes(const md_vit_model* m, int32
   if (!m || n_images <= 0) return 0;
   const size_t g = m->crop / m->patch, M = (size_t)n_images * g * g;
   return align_up(M * m->proj_fc1.k_pad * 2) + align_up(M * m->proj_fc1.n_pad * 2);
+}
+
+// the projector MLP over M rows of [global | pooled] features (vision.py:87-89); fp8 mode: the concatenated input is
+// quantised into the second half of the (bf16-sized) ff buffer, the GELU output into its first half
+static md_status projector_mlp(const md_vit_model* m, void* cat, int Cp, void* ff, int M, void* out, int64_t ld_out, hipStream_t s) {
+  const md_vit_f8* f8 = m->f8;
+  float* calib = f8 ? f8->calib : nullptr;
+  const int nl = m->n_layers, D2 = m->proj_fc1.k;
+  if (f8 && !calib && f8->blocks && f8->proj_fc1.w && f8->proj_fc2.w) {
+    MD_CHECK_ARG(f8_scales_ok(f8->s_cat, f8->s_pff, 1.f) && f8->proj_fc1.k_pad == Cp && f8->proj_fc2.k_pad == f8->proj_fc1.n_pad &&
+                 f8->proj_fc1.n_pad >= Cp);
+    uint8_t *ff8 = (uint8_t*)ff, *cat8 = (uint8_t*)ff + (size_t)M * f8->proj_fc1.n_pad;
+    MD_TRY(md_quantize_f8(cat, Cp, cat8, Cp, M, D2 / 8 * 8, Cp, 1.0f / f8->s_cat, s));
+    MD_TRY(gemm_f8(cat8, Cp, f8->s_cat, f8->proj_fc1, nullptr, 0, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, ff8, f8->proj_fc1.n_pad, f8->s_pff, 0, 0));
+    return gemm_f8(ff8, f8->proj_fc1.n_pad, f8->s_pff, f8->proj_fc2, out, ld_out, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
+  }
+  MD_TRY(calib_site(calib, 4 * nl + 0, cat, Cp, M, D2, s));
+  MD_TRY(gemm(cat, Cp, m->proj_fc1, ff, m->proj_fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s));
+  MD_TRY(calib_site(calib, 4 * nl + 1, ff, m->proj_fc1.n_pad, M, m->proj_fc1.n, s));
+  return gemm(ff, m->proj_fc1.n_pad, m->proj_fc2, out, ld_out, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
 }
 
 // reference: moondream.py:213-228 + vision.py:77-89
@@ -255,8 +318,7 @@ extern "C" md_status md_vision_project(const md_vit_model* m, const void* feats,
   MD_TRY(zero_if_padded(cat, M, Cp, 2 * D, s));
   MD_TRY(md_stitch_pool_batched(feats, cat, Cp, (int64_t)T * Cp, n_images, D, g, margin, tiles_h,
                                 tiles_w, s));
-  MD_TRY(gemm(cat, Cp, m->proj_fc1, ff, m->proj_fc1.n_pad, M, MD_EPI_GELU, nullptr, 0, 0, 1, s));
-  return gemm(ff, m->proj_fc1.n_pad, m->proj_fc2, out, ld_out, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
+  return projector_mlp(m, cat, Cp, ff, M, out, ld_out, s);
 }
 
 // the seam form: _vis_proj(g, r) with r already stitched (moondream.py:171-172, vision.py:77-89)
@@ -275,8 +337,7 @@ extern "C" md_status md_vision_project_grid(const md_vit_model* m, const void* g
   void* ff = a.take((size_t)T * m->proj_fc1.n_pad * 2);
   MD_TRY(zero_if_padded(cat, T, Cp, 2 * D, s));
   MD_TRY(md_pool_grid_concat(global_feats, grid_feats, H, W, cat, Cp, D, g, s));
-  MD_TRY(gemm(cat, Cp, m->proj_fc1, ff, m->proj_fc1.n_pad, T, MD_EPI_GELU, nullptr, 0, 0, 1, s));
-  return gemm(ff, m->proj_fc1.n_pad, m->proj_fc2, out, ld_out, T, MD_EPI_BIAS, nullptr, 0, 0, 0, s);
+  return projector_mlp(m, cat, Cp, ff, T, out, ld_out, s);
 }
 
 // -------------------------------------------------------------------- text
@@ -337,34 +398,10 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
   const bool tail_fused = tail_allowed && M <= 64 && D % 8 == 0 && m->blocks[0].proj.b && m->blocks[0].fc2.b &&
                           m->blocks[0].proj.n == D && m->blocks[0].fc2.n == D;
 
-  for (int l = 0; l < m->n_layers; ++l) {
-    const md_text_block& b = m->blocks[l];
+  // rope(q), rope(k), cache update (text.py:42-46) and attention over the slab (text.py:48-51) of block l
+  auto rope_and_attention = [&](int l, int64_t qld, bool fuse_rope) -> md_status {
     bf16_t* kl = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
     bf16_t* vl = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
-    // l_in = ln(x)                                            (text.py:145)
-    // (decode regime: blocks > 0 get it from the previous block's tail kernel)
-    if (!tail_fused || l == 0) MD_TRY(md_layernorm_bf16(x, D, w.h, Dp, &b.ln, M, D, 1e-5f, s));
-    // qkv, rope(q), rope(k), cache update                      (text.py:30-46)
-    const bool fused = b.qkv_fc1.w != nullptr;
-    const int64_t qld = fused ? b.qkv_fc1.n_pad : qkv_w;  // leading dimension of the qkv activation
-    const int64_t ffld = fused ? b.qkv_fc1.n_pad : b.fc1.n_pad;
-    // decode regime with FP8 weight copies attached (opt-in): the same three launches over half the bytes
-    const md_text_block_fp8* f8 = (m->fp8 && m->fp8->blocks && tail_fused && fused) ? &m->fp8->blocks[l] : nullptr;
-    if (f8 && f8->qkv_fc1.w) {
-      MD_CHECK_ARG(f8->qkv_fc1.n_pad == b.qkv_fc1.n_pad && qkv_w % 64 == 0);
-      MD_TRY(md_gemm_fp8w(w.h, Dp, &f8->qkv_fc1, w.qkv, qld, M, MD_EPI_GELU, 1, qkv_w, s));
-    } else if (fused) {
-      // one GEMM for both consumers of l_in: [qkv | gelu(fc1)]   (text.py:30 and layers.py:130-138)
-      MD_CHECK_ARG(b.qkv_fc1.n_pad == qkv_w + b.fc1.n_pad && qkv_w % 64 == 0);
-      md_gemm_args g;
-      g.a = w.h; g.lda = Dp; g.lin = b.qkv_fc1; g.c = w.qkv; g.ldc = qld; g.r = nullptr; g.ldr = 0;
-      g.res_row_mod = 0; g.m = M; g.epilogue = MD_EPI_GELU; g.store_pad_cols = 1; g.gelu_from_col = qkv_w;
-      g.splitk_ws = w.splitk; g.splitk_ws_bytes = w.splitk_bytes;
-      MD_TRY(md_gemm_bf16(&g, s));
-    } else {
-      MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s, w.splitk, w.splitk_bytes));
-    }
-    const bool fuse_rope = (q_len == 1) && (m->n_kv_heads == m->n_heads);  // decode step: rope + KV write inside attention
     if (!fuse_rope)
       MD_TRY(md_rope_kv_write(w.qkv, qld, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
                               q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
@@ -402,9 +439,64 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       a.scale = scale;
       MD_TRY(md_attention_prefill(&a, s));
     }
+    return MD_OK;
+  };
+
+  // FP8 prefill (opt-in, md_text_f8): launches of more than 64 rows with the fused qkv|fc1 packing
+  const md_text_f8* f8p = m->f8;
+  float* calib = (f8p && M > 64) ? f8p->calib : nullptr;  // calibration records the PREFILL's activation ranges
+  const bool use_f8 = f8p && !f8p->calib && f8p->blocks && M > 64 && m->blocks[0].qkv_fc1.w != nullptr && qkv_w % 64 == 0;
+
+  for (int l = 0; l < m->n_layers; ++l) {
+    const md_text_block& b = m->blocks[l];
+    if (use_f8) {
+      const md_text_block_f8& q = f8p->blocks[l];
+      const int64_t qld = b.qkv_fc1.n_pad;
+      MD_CHECK_ARG(f8_scales_ok(q.s_ln, q.s_att, q.s_ff) && q.qkv_fc1.n_pad == b.qkv_fc1.n_pad && q.qkv_fc1.k_pad == Dp &&
+                   q.fc2.k_pad == b.fc1.n_pad && q.proj.k_pad == Dp && b.qkv_fc1.n_pad == qkv_w + b.fc1.n_pad);
+      // fp8 activations: ln(x) / the attention output in the (bf16-sized) h buffer, gelu(fc1) in the fc1 columns' own
+      // (bf16-sized) slots of the fused activation rows
+      uint8_t* h8 = (uint8_t*)w.h;
+      uint8_t* ff8 = (uint8_t*)w.qkv + (size_t)qkv_w * 2;
+      MD_TRY(md_layernorm_f8(x, D, h8, Dp, &b.ln, M, D, Dp, 1e-5f, 1.0f / q.s_ln, s));
+      MD_TRY(gemm_f8(h8, Dp, q.s_ln, q.qkv_fc1, w.qkv, qld, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, ff8, qld * 2, q.s_ff, qkv_w, qkv_w));
+      MD_TRY(rope_and_attention(l, qld, false));
+      MD_TRY(md_quantize_f8(w.att, Dp, h8, Dp, M, D, Dp, 1.0f / q.s_att, s));
+      MD_TRY(gemm_f8(h8, Dp, q.s_att, q.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
+      MD_TRY(gemm_f8(ff8, qld * 2, q.s_ff, q.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
+      continue;
+    }
+    // l_in = ln(x)                                            (text.py:145)
+    // (decode regime: blocks > 0 get it from the previous block's tail kernel)
+    if (!tail_fused || l == 0) MD_TRY(md_layernorm_bf16(x, D, w.h, Dp, &b.ln, M, D, 1e-5f, s));
+    MD_TRY(calib_site(calib, 3 * l + 0, w.h, Dp, M, D, s));
+    // qkv, rope(q), rope(k), cache update                      (text.py:30-46)
+    const bool fused = b.qkv_fc1.w != nullptr;
+    const int64_t qld = fused ? b.qkv_fc1.n_pad : qkv_w;  // leading dimension of the qkv activation
+    const int64_t ffld = fused ? b.qkv_fc1.n_pad : b.fc1.n_pad;
+    // decode regime with FP8 weight copies attached (opt-in): the same three launches over half the bytes
+    const md_text_block_fp8* f8 = (m->fp8 && m->fp8->blocks && tail_fused && fused) ? &m->fp8->blocks[l] : nullptr;
+    if (f8 && f8->qkv_fc1.w) {
+      MD_CHECK_ARG(f8->qkv_fc1.n_pad == b.qkv_fc1.n_pad && qkv_w % 64 == 0);
+      MD_TRY(md_gemm_fp8w(w.h, Dp, &f8->qkv_fc1, w.qkv, qld, M, MD_EPI_GELU, 1, qkv_w, s));
+    } else if (fused) {
+      // one GEMM for both consumers of l_in: [qkv | gelu(fc1)]   (text.py:30 and layers.py:130-138)
+      MD_CHECK_ARG(b.qkv_fc1.n_pad == qkv_w + b.fc1.n_pad && qkv_w % 64 == 0);
+      md_gemm_args g;
+      g.a = w.h; g.lda = Dp; g.lin = b.qkv_fc1; g.c = w.qkv; g.ldc = qld; g.r = nullptr; g.ldr = 0;
+      g.res_row_mod = 0; g.m = M; g.epilogue = MD_EPI_GELU; g.store_pad_cols = 1; g.gelu_from_col = qkv_w;
+      g.splitk_ws = w.splitk; g.splitk_ws_bytes = w.splitk_bytes;
+      MD_TRY(md_gemm_bf16(&g, s));
+    } else {
+      MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s, w.splitk, w.splitk_bytes));
+    }
+    const bool fuse_rope = (q_len == 1) && (m->n_kv_heads == m->n_heads);  // decode step: rope + KV write inside attention
+    MD_TRY(rope_and_attention(l, qld, fuse_rope));
+    MD_TRY(calib_site(calib, 3 * l + 1, w.att, Dp, M, D, s));
     // x = (x + proj(att)) + fc2(gelu(fc1(l_in)))               (text.py:53,157-158)
     if (!fused)
       MD_TRY(gemm(w.h, Dp, b.fc1, w.ff, ffld, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, w.splitk, w.splitk_bytes));
+    MD_TRY(calib_site(calib, 3 * l + 2, w.ff, ffld, M, b.fc1.n, s));
     MD_CHECK_ARG(b.fc2.k_pad == b.fc1.n_pad);
     if (tail_fused) {
       // decode regime: both linears leave fp32 K-slice partials; ONE tail kernel sums them, applies

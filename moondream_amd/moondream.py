@@ -227,6 +227,43 @@ class MoondreamModel:
             self.w.disable_fp8_decode()
         self._graphs.clear()  # captured decode steps baked the other launches in
 
+    def enable_fp8(self, calibration_images: Optional[Sequence[Image.Image]] = None, prompt: Optional[Sequence[int]] = None,
+                   on: bool = True, decode_weights: bool = True, margin: float = 1.5) -> Optional[dict]:
+        """Opt-in FP8 mode of the whole hot path (BASELINE configs[4] "fp8 weights, CDNA4 fp8 MFMA"): every MFMA-bound
+        linear of the ViT blocks, the projector and the decoder prefill runs on ``md_gemm_f8`` (e4m3 operands,
+        v_mfma_f32_32x32x64_f8f6f4 at twice the bf16 matrix rate, fp32 accumulation) with per-channel weight scales and ONE
+        static scale per quantised activation tensor; ``decode_weights`` also streams e4m3 weights in the decode steps
+        (``enable_fp8_decode``).  Patch embedding, layer-norm statistics, attention, RoPE, the KV cache, the residual
+        stream, lm_head at prefill and the region head stay bf16 / fp32.
+
+        The activation scales are CALIBRATED: ``calibration_images`` (a handful is enough) are run through the bf16
+        path once with range recording on (vision + image / prompt prefill), then the e4m3 weight copies are built.
+        The reference has no fp8 path: outputs are judged by tolerance against the bf16 mode (tests/test_model_gpu.py),
+        never by bit parity, and the mode is off by default.  Returns the recorded ranges."""
+        self._graphs.clear()
+        if not on:
+            self.w.disable_f8()
+            if decode_weights:
+                self.enable_fp8_decode(False)
+            return None
+        if not calibration_images:
+            raise ValueError("enable_fp8 needs a few calibration images (PIL) to size the activation scales")
+        tpl = self.config.tokenizer.templates["caption"]
+        prompt = list(prompt) if prompt is not None else list(tpl["normal"] if tpl else [self.config.tokenizer.bos_id])
+        self.w.begin_f8_calibration()
+        try:
+            with torch.inference_mode():
+                n = len(calibration_images)
+                self._prepare_sequences(list(calibration_images), [prompt] * n, None, None, fuse=True)
+                torch.cuda.synchronize(self._device)
+            info = self.w.finish_f8_calibration(margin)
+        except Exception:
+            self.w.disable_f8()
+            raise
+        if decode_weights:
+            self.enable_fp8_decode(True)
+        return info
+
     def set_strict_batch_invariance(self, on: bool = True):
         """``on``: every sequence gets the same bits whatever the batch it travels in -- ``batch_generate_ids([a, b, ..])[i]``
         == ``batch_generate_ids([x])`` == ``caption(x)`` bit for bit -- by giving up the two B=1 / batch-level shortcuts whose

@@ -123,6 +123,29 @@ class PackedLinearFp8:
                                 self.n, self.k, self.n_pad, self.k_pad)
 
 
+class PackedLinearF8:
+    """An already packed bf16 linear (``w`` [n_pad][k_pad], zero padded; ``b`` bf16 [n_pad] or None) quantised to OCP
+    e4m3fn with one fp32 scale per output channel (max |w| -> 448), ROW-MAJOR with K contiguous: the operand layout
+    of md_gemm_f8 (include/moondream_hip.h: md_linear_f8).  An opt-in copy for the MFMA-bound launches of the fp8
+    mode; the bf16 original stays in place."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], n: int, k: int):
+        assert w.dim() == 2 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+        self.n, self.k, self.n_pad, self.k_pad = n, k, w.shape[0], w.shape[1]
+        wf = w.float()
+        amax = wf.abs().amax(dim=1)
+        self.scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax)).contiguous()
+        self.q = (wf / self.scale[:, None]).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).contiguous()
+        self.b = b
+
+    def dequantized(self) -> torch.Tensor:
+        return self.q.float() * self.scale[:, None]
+
+    def struct(self) -> _lib.MdLinearF8:
+        return _lib.MdLinearF8(self.q.data_ptr(), self.scale.data_ptr(), self.b.data_ptr() if self.b is not None else None,
+                               self.n, self.k, self.n_pad, self.k_pad)
+
+
 class PackedLayerNorm:
     def __init__(self, w: torch.Tensor, b: torch.Tensor, device):
         self.w = w.to(device=device, dtype=BF16).contiguous()
@@ -298,15 +321,18 @@ class PackedModel:
         self.pos_emb = sd["vision.pos_emb"].to(device=dev, dtype=BF16).reshape(v.n_patches, v.enc_dim).contiguous()
         self.pixel_lut = reference_pixel_lut().to(dev)
         self.vit_blocks = (_lib.MdVitBlock * v.enc_n_layers)()
+        self._vit_packed: List[dict] = []  # per block: the packed bf16 linears, for the fp8 mode's copies
         for i in range(v.enc_n_layers):
             p = f"vision.blocks.{i}"
             blk = self.vit_blocks[i]
+            pk = {"qkv": lin(p + ".attn.qkv"), "proj": lin(p + ".attn.proj"), "fc1": lin(p + ".mlp.fc1"), "fc2": lin(p + ".mlp.fc2")}
+            self._vit_packed.append(pk)
             blk.ln1 = ln(p + ".ln1").struct()
-            blk.qkv = lin(p + ".attn.qkv").struct()
-            blk.proj = lin(p + ".attn.proj").struct()
+            blk.qkv = pk["qkv"].struct()
+            blk.proj = pk["proj"].struct()
             blk.ln2 = ln(p + ".ln2").struct()
-            blk.fc1 = lin(p + ".mlp.fc1").struct()
-            blk.fc2 = lin(p + ".mlp.fc2").struct()
+            blk.fc1 = pk["fc1"].struct()
+            blk.fc2 = pk["fc2"].struct()
         self.vit_post_ln = ln("vision.post_ln")
         self.proj_fc1 = lin("vision.proj_mlp.fc1")
         self.proj_fc2 = lin("vision.proj_mlp.fc2")
@@ -392,6 +418,64 @@ class PackedModel:
     def disable_fp8_decode(self) -> None:
         self.text.fp8 = C.POINTER(_lib.MdTextFp8)()
         self._fp8 = None
+
+    # ---- FP8 mode of the MFMA-bound launches (ViT, projector, decoder prefill): md_gemm_f8 -------------------------------
+    def begin_f8_calibration(self) -> None:
+        """Attach calibration buffers (md_vit_f8.calib / md_text_f8.calib): the bf16 path keeps running and records the
+        running max |x| of every tensor the fp8 mode will quantise."""
+        v, t = self.config.vision, self.config.text
+        self.disable_f8()
+        self._f8_calib_vit = torch.zeros(4 * v.enc_n_layers + 2, dtype=torch.float32, device=self.device)
+        self._f8_calib_text = torch.zeros(3 * t.n_layers, dtype=torch.float32, device=self.device)
+        self._f8_vit = _lib.MdVitF8(C.POINTER(_lib.MdVitBlockF8)(), _lib.MdLinearF8(), _lib.MdLinearF8(), 0.0, 0.0,
+                                   self._f8_calib_vit.data_ptr())
+        self._f8_text = _lib.MdTextF8(C.POINTER(_lib.MdTextBlockF8)(), self._f8_calib_text.data_ptr())
+        self.vit.f8 = C.pointer(self._f8_vit)
+        self.text.f8 = C.pointer(self._f8_text)
+
+    def finish_f8_calibration(self, margin: float = 1.5) -> dict:
+        """Turn the recorded ranges into static per-tensor scales (max |x| * margin -> 448: e4m3 is a floating-point
+        format, so head-room costs no precision, only range at the small end) and attach e4m3 copies (one fp32 scale per
+        output channel) of every linear of the ViT blocks, the projector and the decoder blocks.  Returns the ranges."""
+        v, t = self.config.vision, self.config.text
+        av = self._f8_calib_vit.cpu().tolist()
+        at = self._f8_calib_text.cpu().tolist()
+        sc = lambda a: (a * margin / FP8_MAX) if a > 0 else 1.0
+        keep: List[PackedLinearF8] = []
+
+        def q8(p):
+            f = PackedLinearF8(p.w, p.b, p.n, p.k)
+            keep.append(f)
+            return f.struct()
+
+        vb = (_lib.MdVitBlockF8 * v.enc_n_layers)()
+        for i, pk in enumerate(self._vit_packed):
+            vb[i].qkv, vb[i].proj, vb[i].fc1, vb[i].fc2 = q8(pk["qkv"]), q8(pk["proj"]), q8(pk["fc1"]), q8(pk["fc2"])
+            vb[i].s_ln1, vb[i].s_att, vb[i].s_ln2, vb[i].s_ff = (sc(av[4 * i + j]) for j in range(4))
+        L = v.enc_n_layers
+        self._f8_vit_blocks = vb
+        self._f8_vit = _lib.MdVitF8(C.cast(vb, C.POINTER(_lib.MdVitBlockF8)), q8(self.proj_fc1), q8(self.proj_fc2),
+                                   sc(av[4 * L]), sc(av[4 * L + 1]), None)
+        tb = (_lib.MdTextBlockF8 * t.n_layers)()
+        for i, pk in enumerate(self._text_packed):
+            if pk["qkv_fc1"] is None:
+                raise ValueError("the fp8 prefill needs the fused qkv|fc1 packing (qkv_dim % 64 == 0)")
+            tb[i].qkv_fc1, tb[i].proj, tb[i].fc2 = q8(pk["qkv_fc1"]), q8(pk["proj"]), q8(pk["fc2"])
+            tb[i].s_ln, tb[i].s_att, tb[i].s_ff = (sc(at[3 * i + j]) for j in range(3))
+        self._f8_text_blocks = tb
+        self._f8_text = _lib.MdTextF8(C.cast(tb, C.POINTER(_lib.MdTextBlockF8)), None)
+        self._f8_keep = keep
+        self.vit.f8 = C.pointer(self._f8_vit)
+        self.text.f8 = C.pointer(self._f8_text)
+        return {"vit_amax": av, "text_amax": at, "margin": margin}
+
+    def disable_f8(self) -> None:
+        self.vit.f8 = C.POINTER(_lib.MdVitF8)()
+        self.text.f8 = C.POINTER(_lib.MdTextF8)()
+        self._f8_vit = self._f8_text = self._f8_keep = None
+
+    def f8_enabled(self) -> bool:
+        return bool(self.vit.f8) and bool(self.vit.f8.contents.blocks)
 
     def param_bytes(self) -> int:
         total = 0

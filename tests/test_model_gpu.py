@@ -628,6 +628,52 @@ def fp8_decode_report(model, images, prompts, ids_bf16, ref_margins, label):
     assert sum(prefix) / len(prefix) >= 0.25 * n_tok, prefix
 
 
+def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3):
+    """The full fp8 mode (md_gemm_f8 for the ViT blocks, the projector and the prefill + the fp8 decode stream) against the
+    bf16 mode on the same inputs: projected image embeddings, K rows of the image prefix and first-token logits within the
+    tolerance of e4m3 operands (3 mantissa bits: a few percent per tensor, compounding over 27 + 24 blocks), token streams
+    mostly unchanged; switching the mode off restores the bf16 bits."""
+    n_tok = len(ids_bf16[0])
+    with torch.inference_mode():
+        emb_b = model._run_vision_encoder_batch(images[:2]).float().cpu()
+    enc_b = model.encode_image(images[0])
+    info = model.enable_fp8(images[:n_calib], prompts[0])
+    try:
+        assert model.w.f8_enabled()
+        with torch.inference_mode():
+            emb_8 = model._run_vision_encoder_batch(images[:2]).float().cpu()
+        enc_8 = model.encode_image(images[0])
+        ids_8 = model.batch_generate_ids(images, prompts, max_tokens=n_tok, ignore_eos=True)
+    finally:
+        model.enable_fp8(on=False)
+    assert not model.w.f8_enabled()
+    assert model.batch_generate_ids(images, prompts, max_tokens=n_tok, ignore_eos=True) == ids_bf16
+    rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    r_emb = rel(emb_8, emb_b)
+    L = model.config.text.n_layers
+    r_k0 = rel(enc_8.caches[0][0].float().cpu(), enc_b.caches[0][0].float().cpu())
+    r_kl = rel(enc_8.caches[L - 1][0].float().cpu(), enc_b.caches[L - 1][0].float().cpu())
+    same = sum(list(a) == list(b) for a, b in zip(ids_8, ids_bf16))
+    prefix = [next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(b)) for a, b in zip(ids_8, ids_bf16)]
+    print(f"fp8 full [{label}]: image embeddings rel-RMS {r_emb:.4f}, K rows layer 0 {r_k0:.4f} / last layer {r_kl:.4f} vs bf16; "
+          f"{same}/{len(ids_bf16)} sequences identical, mean matching prefix {sum(prefix) / len(prefix):.1f}/{n_tok}; activation ranges: "
+          f"vit max {max(info['vit_amax']):.1f}, text max {max(info['text_amax']):.1f}")
+    assert all(0 <= t < model.config.text.vocab_size for seq in ids_8 for t in seq)
+    assert torch.isfinite(emb_8).all()
+    assert r_emb <= 0.15 and r_k0 <= 0.15 and r_kl <= 0.25, (r_emb, r_k0, r_kl)
+    assert sum(prefix) / len(prefix) >= 0.25 * n_tok, prefix
+
+
+def test_fp8_full_mode_tiny(tiny):
+    g, cfg, sd, model = tiny
+    n_img = len(g["image_index"])
+    images = [golden_image(g, i) for i in range(n_img)]
+    prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(n_img)]
+    n = len(g["img0.cap.tokens"])
+    ids = model.batch_generate_ids(images, prompts, max_tokens=n, ignore_eos=True)
+    fp8_full_report(model, images, prompts, ids, "tiny")
+
+
 def test_fp8_decode_mode_tiny(tiny):
     g, cfg, sd, model = tiny
     n_img = len(g["image_index"])
@@ -773,3 +819,4 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     # opt-in FP8 weight stream for the decode steps of the same configuration (BASELINE configs[4]): a different
     # numerical mode, judged by tolerance against the bf16 path -- never by bit parity
     fp8_decode_report(model, imgs64, [pr] * 64, got64, gb["margins"], "2b B=64")
+    fp8_full_report(model, imgs64, [pr] * 64, got64, "2b B=64", n_calib=8)

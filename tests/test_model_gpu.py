@@ -628,7 +628,7 @@ def fp8_decode_report(model, images, prompts, ids_bf16, ref_margins, label):
     assert sum(prefix) / len(prefix) >= 0.25 * n_tok, prefix
 
 
-def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3):
+def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3, ref=None):
     """The full fp8 mode (md_gemm_f8 for the ViT blocks, the projector and the prefill + the fp8 decode stream) against the
     bf16 mode on the same inputs: projected image embeddings, K rows of the image prefix and first-token logits within the
     tolerance of e4m3 operands (3 mantissa bits: a few percent per tensor, compounding over 27 + 24 blocks), token streams
@@ -644,6 +644,13 @@ def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3):
             emb_8 = model._run_vision_encoder_batch(images[:2]).float().cpu()
         enc_8 = model.encode_image(images[0])
         ids_8 = model.batch_generate_ids(images, prompts, max_tokens=n_tok, ignore_eos=True)
+        if ref is not None:  # logit error of the fp8 mode, teacher-forced on the reference's ids (the parity instrument)
+            from moondream_amd import parity as P
+
+            st8 = P.logit_error_stats(model.teacher_forced_logits(images, prompts, ref["tokens"], ref["top8_idx"]).numpy(), ref["top8_val"])
+            print(f"fp8 full [{label}]: |logit error| vs the reference's top-8 logits over {st8['decisions']} decisions: max {st8['max']:.3f}, "
+                  f"p99 {st8['p99']:.3f}, mean {st8['mean']:.3f} (bf16 mode: max 0.31, p99 0.19)")
+            assert st8["p99"] <= 2.5 and st8["mean"] <= 0.75, st8
     finally:
         model.enable_fp8(on=False)
     assert not model.w.f8_enabled()
@@ -661,7 +668,9 @@ def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3):
     assert all(0 <= t < model.config.text.vocab_size for seq in ids_8 for t in seq)
     assert torch.isfinite(emb_8).all()
     assert r_emb <= 0.15 and r_k0 <= 0.15 and r_kl <= 0.25, (r_emb, r_k0, r_kl)
-    assert sum(prefix) / len(prefix) >= 0.25 * n_tok, prefix
+    # token streams: the unfiltered 2B bench images decide most tokens at reference margins of 0 .. 0.5 logits (fixture), well
+    # inside an e4m3 mode's logit error, so their streams part early; the wide-margin tiny goldens mostly survive
+    assert sum(prefix) / len(prefix) >= (0.5 if ref is None else 0.1) * n_tok, prefix
 
 
 def test_fp8_full_mode_tiny(tiny):
@@ -819,4 +828,4 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     # opt-in FP8 weight stream for the decode steps of the same configuration (BASELINE configs[4]): a different
     # numerical mode, judged by tolerance against the bf16 path -- never by bit parity
     fp8_decode_report(model, imgs64, [pr] * 64, got64, gb["margins"], "2b B=64")
-    fp8_full_report(model, imgs64, [pr] * 64, got64, "2b B=64", n_calib=8)
+    fp8_full_report(model, imgs64, [pr] * 64, got64, "2b B=64", n_calib=8, ref=gb)

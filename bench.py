@@ -220,7 +220,7 @@ def check_parity(model, images, prompts, ids_per_image, cfg_name, seed, prompt_k
                            got_topk, g["top8_val"][:n, : t + 1], tokens=t, min_exact=(48 * n) // 64 if t == 32 else None)
 
 
-def detect13_leg(model, cfg, args, dev):
+def detect13_leg(model, cfg, args, dev, fp8=False):
     """BASELINE.json configs[4]'s WORKLOAD on one GPU (its fp8 arithmetic is a separate opt-in mode): seeded 768 x 1024
     images -> tiling (3, 4) = 13 crops each (image_crops.py:58-167), ``detect`` with a fixed ``max_objects``, 32 images per
     step.  Reported: images/s over whole steps (host tiling NOT hidden: one step after the other on one stream), the
@@ -237,6 +237,8 @@ def detect13_leg(model, cfg, args, dev):
     B2 = args.detect13_batch
     imgs = [synth.synthetic_image(i, args.seed, size) for i in range(B2)]
     st = {"max_objects": max_objects, "_run_all_objects": True}
+    if fp8:  # BASELINE configs[4] proper: fp8 MFMA for the ViT / projector / prefill linears + fp8 decode weights (region head bf16)
+        model.enable_fp8(imgs[:2])
     t_host = time.perf_counter()
     crops = [model._crop(im) for im in imgs[:4]]
     host_ms_per_image = (time.perf_counter() - t_host) / 4 * 1e3
@@ -268,6 +270,10 @@ def detect13_leg(model, cfg, args, dev):
                               "frac": fl / (phase["vision"] * 1e-3) / 1e12 / 2500.0}
     if g is not None:
         out["parity"] = P.detect_parity([r["objects"] for r in res], g)
+    if fp8:
+        model.enable_fp8(on=False)
+        out["workload"] = out["workload"].replace(" bf16 ", " FP8 (md_gemm_f8 for ViT / projector / prefill, e4m3 decode weights; region head bf16) ")
+        out["parity_note"] = ("objects vs the bf16 reference's: an fp8 mode is tolerance-judged; equal objects are reported, not required")
     return out
 
 
@@ -390,16 +396,16 @@ def main():
     # on itself: the algorithmic bytes beside it are live (this run's launches), the counter figure is the
     # committed pass of the same command.
     traffic = {"algorithmic_read_bytes_per_step": alg_rd.value, "algorithmic_written_bytes_per_step": alg_wr.value,
-               "measured": None, "note": "no profiles/r02_pmc_traffic.json"}
+               "measured": None, "note": "no profiles/r03_pmc_traffic.json"}
     try:
-        with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")) as f:
             tg = json.load(f)["tile_gemm"]
         rd, wr = 2.0 * tg["FETCH_SIZE_kb_sum"] * 1024.0, tg["WRITE_SIZE_kb_sum"] * 1024.0
         traffic.update({
             "measured": {"read_bytes_per_step": rd, "written_bytes_per_step": wr, "launches": tg["launches"]},
             "read_ratio": rd / alg_rd.value if alg_rd.value else None,
             "write_ratio": wr / alg_wr.value if alg_wr.value else None,
-            "note": "profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager B=64 step "
+            "note": "profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager B=64 step "
                     "(2 x FETCH_SIZE per the gfx950 note; L2-miss side, Infinity-Cache hits included)",
         })
     except (OSError, KeyError, ValueError, ZeroDivisionError):
@@ -519,6 +525,11 @@ def main():
     # BASELINE configs[4]'s workload shape (multi-crop + detect head) as its own leg
     if world == 1 and not args.no_detect13_leg and args.model == "2b":
         result["detect13"] = detect13_leg(model, cfg, args, dev)
+        if not args.no_fp8_full_leg:
+            try:
+                result["detect13_fp8"] = detect13_leg(model, cfg, args, dev, fp8=True)
+            finally:
+                model.enable_fp8(on=False)
 
     # auxiliary leg, NOT the headline: identical crops of an image encoded once (the bench's 378 x 378 images have
     # tiling (1, 1): their local crop is byte-identical to the global crop).  The reference encodes both, so `value`

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.md_abi_version() == 2
+    assert lib.md_abi_version() == _lib.ABI_VERSION == 3
     assert lib.md_status_string(0) == b"ok"
     assert b"workspace" in lib.md_status_string(3)
 
@@ -37,6 +37,15 @@ def test_argument_validation_needs_no_gpu():
     assert lib.md_gemm_bf16(ctypes.byref(args), None) == 1
     assert lib.md_gemm_bf16(None, None) == 1
     assert lib.md_vit_workspace_bytes(None, 4) == 0
+
+
+def test_fp8_entry_points_validate_on_the_host():
+    lib = _lib.load()
+    assert lib.md_gemm_f8(None, None) == 1
+    assert lib.md_gemm_f8(ctypes.byref(_lib.MdGemmF8Args()), None) == 1
+    assert lib.md_quantize_f8(None, 0, None, 0, 1, 8, 8, 1.0, None) == 1
+    assert lib.md_amax_bf16(None, 0, 1, 8, None, None) == 1
+    assert lib.md_decode_step_b1_supported(None, None) == 0
 
 
 def test_product_never_imports_the_oracle():

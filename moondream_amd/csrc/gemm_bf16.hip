@@ -750,7 +750,7 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.slabs = nullptr;
   k.tickets = nullptr;
   const bool forced = knobs().tile >= 0;
-  if (tile == 20 && a->epilogue == MD_EPI_RESIDUAL && k.n_pad > md_gemm_w4_residual_max_cols()) tile = 11;
+  if (tile == 20 && !md_gemm_w4_takes(k, a->epilogue)) tile = 11;
   if (tile == 11 && a->epilogue != MD_EPI_RESIDUAL && !forced) {
     // eight-wave baseline: bias / GELU layers with more tiles than CUs run its persistent tile loop
     const long tiles = (long)((k.M + 255) / 256) * ((k.n_store + 255) / 256);

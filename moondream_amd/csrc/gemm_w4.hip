@@ -444,82 +444,77 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       MD_PIN();
     });
     } else {
-    // this lane's 16 bias quads (column 32 j + 8 q + 4 hi .. + 3), once per tile
-    u32x2 bias_w[4][4];
-    if (bias_in_lds) {
+    // ---- bias / GELU layers: registers only, no trip through LDS --------------------------------------------------
+    // This lane's 64 bias values (column 32 j + 8 q + 4 hi + e), unpacked ONCE per tile from the LDS-resident vector (they
+    // are reused by the four row blocks: unpacking at every use cost 256 of the epilogue's ~1150 VALU instructions).
+    md_f32x2 bias_f[4][4][2];
+    {
+      u32x2 bw[4][4];
       static_for<0, 16>([&](auto jq) {
         constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
-        ds_read_b64_u32<(32 * j + 8 * q) * 2>(bias_w[j][q], bias_lds + (wn0 + 4 * hi) * 2);
+        ds_read_b64_u32<(32 * j + 8 * q) * 2>(bw[j][q], bias_lds + (wn0 + 4 * hi) * 2);
       });
-    } else {
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
+      wait_lgkm<0>();
+      MD_PIN();
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = wn0 + 32 * j + 8 * q + 4 * hi;
-          bias_w[j][q] = u32x2{0u, 0u};
-          if (p.bias != nullptr && n < p.n_pad) bias_w[j][q] = *(const u32x2*)(p.bias + n);
+          bias_f[j][q][0] = md_f32x2{lo_bf(bw[j][q][0]), hi_bf(bw[j][q][0])};
+          bias_f[j][q][1] = md_f32x2{lo_bf(bw[j][q][1]), hi_bf(bw[j][q][1])};
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
+    // Stores go through a buffer resource over C with num_records = M x ldc x 2 bytes: rows past M are dropped by the range
+    // check (no exec masking, no branch), the address is ONE 32-bit row offset per row block plus an immediate per piece
+    // (per-store 64-bit address arithmetic and an exec-mask branch were another ~320 instructions per tile).  Columns past
+    // n_store exist only in a layer's last column tile: there the offset of an out-of-range piece is pushed out of range.
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)min((uint64_t)p.M * (uint64_t)p.ldc * 2, (uint64_t)0xffffffffu), 0x00020000);
+    const bool full_cols = wn0 + 128 <= p.n_store;   // wave-uniform
     // Eight passes of 32 rows x 64 columns (row block i, column half jp).  Bias add + ONE bf16 rounding happen on the
     // accumulator layout (a lane: one row, quads of 4 consecutive columns; the two lane halves hold the two quads of an
     // 8-column group).  Two v_permlane32_swap per pair of groups hand every lane a full 16-byte row piece -- lanes
-    // 0-31 the even group, lanes 32-63 the odd one, adjacent in memory -- so GELU / residual and the global stores
-    // work on 16-byte pieces with no trip through LDS: piece t of a pass: row l31, columns 64 jp + 32 jj + 16 t + 8 hi.
-    auto load_residual = [&](int pass, u32x4 (&rv)[4]) {
-      const int i = pass >> 1, jp = pass & 1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int m = wm0 + 32 * i + l31, n = wn0 + 64 * jp + 16 * q + 8 * hi;
-        rv[q] = u32x4{0, 0, 0, 0};
-        if (m < p.M && n < p.n_store) {
-          const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
-          rv[q] = *(const u32x4*)(p.R + rrow * p.ldr + n);
-        }
-      }
-    };
-    u32x4 rres[2][4];
-    if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
-    wait_lgkm<0>();
-    MD_PIN();
+    // 0-31 the even group, lanes 32-63 the odd one, adjacent in memory -- so GELU and the global stores work on
+    // 16-byte pieces: piece t of a pass: row l31, columns 64 jp + 32 (t >> 1) + 16 (t & 1) + 8 hi.
+    auto store_tile = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;  // every column of this wave's 128 is inside n_store: no per-piece test
     static_for<0, 8>([&](auto pc) {
       constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
-      if constexpr (EPI == MD_EPI_RESIDUAL && PASS + 1 < 8) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
+      const uint32_t row_off = (uint32_t)(wm0 + 32 * i + l31) * (uint32_t)(p.ldc * 2) + (uint32_t)(wn0 + 8 * hi) * 2u;
       static_for<0, 4>([&](auto tc) {
         // piece t: groups q = 2 (t & 1) and q + 1 of column block j = 2 jp + (t >> 1)
         constexpr int T = decltype(tc)::value, j = 2 * jp + (T >> 1), q0 = 2 * (T & 1);
         constexpr int base0 = 16 * (4 * i + j) + 4 * q0, base1 = base0 + 4;
-        const uint32_t a0 = pack_bf16x2(acc_read<base0 + 0>() + lo_bf(bias_w[j][q0][0]), acc_read<base0 + 1>() + hi_bf(bias_w[j][q0][0]));
-        const uint32_t a1 = pack_bf16x2(acc_read<base0 + 2>() + lo_bf(bias_w[j][q0][1]), acc_read<base0 + 3>() + hi_bf(bias_w[j][q0][1]));
-        const uint32_t b0 = pack_bf16x2(acc_read<base1 + 0>() + lo_bf(bias_w[j][q0 + 1][0]), acc_read<base1 + 1>() + hi_bf(bias_w[j][q0 + 1][0]));
-        const uint32_t b1 = pack_bf16x2(acc_read<base1 + 2>() + lo_bf(bias_w[j][q0 + 1][1]), acc_read<base1 + 3>() + hi_bf(bias_w[j][q0 + 1][1]));
+        const md_f32x2 x0 = md_f32x2{acc_read<base0 + 0>(), acc_read<base0 + 1>()} + bias_f[j][q0][0];
+        const md_f32x2 x1 = md_f32x2{acc_read<base0 + 2>(), acc_read<base0 + 3>()} + bias_f[j][q0][1];
+        const md_f32x2 y0 = md_f32x2{acc_read<base1 + 0>(), acc_read<base1 + 1>()} + bias_f[j][q0 + 1][0];
+        const md_f32x2 y1 = md_f32x2{acc_read<base1 + 2>(), acc_read<base1 + 3>()} + bias_f[j][q0 + 1][1];
+        const uint32_t a0 = pack_bf16x2(x0[0], x0[1]), a1 = pack_bf16x2(x1[0], x1[1]);
+        const uint32_t b0 = pack_bf16x2(y0[0], y0[1]), b1 = pack_bf16x2(y1[0], y1[1]);
         // swap(x, y): x' = {x of lanes 0-31, y of lanes 0-31}, y' = {x of lanes 32-63, y of lanes 32-63}
         const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
         u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
-        const int m = wm0 + 32 * i + l31, n = wn0 + 32 * j + 8 * (q0 + hi);
-        if (m < p.M && n < p.n_store) {
-          if constexpr (EPI == MD_EPI_GELU) {
-            if (n >= p.gelu_from) {
+        if constexpr (EPI == MD_EPI_GELU) {
+          if (wn0 + 32 * j >= p.gelu_from) {  // wave-uniform: gelu_from is a multiple of 64 (fused [qkv | fc1] layers)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const md_f32x2 ge = gelu_tanh_f32x2(md_f32x2{lo_bf(v[e]), hi_bf(v[e])});
-                v[e] = pack_bf16x2(ge[0], ge[1]);
-              }
+            for (int e = 0; e < 4; ++e) {
+              const md_f32x2 ge = gelu_tanh_f32x2(md_f32x2{lo_bf(v[e]), hi_bf(v[e])});
+              v[e] = pack_bf16x2(ge[0], ge[1]);
             }
-          } else if constexpr (EPI == MD_EPI_RESIDUAL) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][T][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][T][e]) + hi_bf(v[e]));
           }
-          if constexpr (ABL & 128) __builtin_nontemporal_store(v, (u32x4*)(p.C + (int64_t)m * p.ldc + n));
-          else if constexpr (!(ABL & 16)) *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
-          else keep_alive(v);
         }
+        constexpr int col_off = (32 * j + 8 * q0) * 2;  // bytes from the row offset's column (wn0 + 8 hi)
+        uint32_t off = row_off;
+        if constexpr (!FULL) off = (wn0 + 32 * j + 8 * (q0 + hi) < p.n_store) ? row_off : 0xfffff000u;  // out of range: dropped
+        if constexpr (ABL & 128) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off + col_off, 0, 2);
+        else if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off + col_off, 0, 0);
+        else keep_alive(v);
       });
       MD_PIN();
     });
+    };
+    if (full_cols) store_tile(std::true_type{}); else store_tile(std::false_type{});
     }
     if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
@@ -553,17 +548,27 @@ md_status launch(const GemmK& k, hipStream_t stream) {
 }  // namespace
 
 int md_gemm_w4_residual_max_cols() { return bias_max_cols<MD_EPI_RESIDUAL>(); }
+int md_gemm_w4_max_cols(int epi) { return epi == MD_EPI_RESIDUAL ? bias_max_cols<MD_EPI_RESIDUAL>() : bias_max_cols<MD_EPI_BIAS>(); }
 
 void md_gemm_w4_set_variant(int v) { g_w4_variant = v; }
+
+bool md_gemm_w4_takes(const GemmK& k, int epi) {
+  if (k.K % 64 != 0 || k.M <= 0) return false;
+  if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32)) return false;
+  if (k.n_pad > md_gemm_w4_max_cols(epi)) return false;
+  if (epi != MD_EPI_RESIDUAL && (uint64_t)k.M * (uint64_t)k.ldc * 2 >= 0xfffff000ull) return false;
+  return true;
+}
 
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   if (k.K % 64 != 0 || k.M <= 0) return MD_ERR_INVALID_ARG;
   // 32-bit byte offsets into A and W
   if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32))
     return MD_ERR_UNSUPPORTED;
-  // the residual epilogue takes its bias from the LDS-resident vector only (md_gemm_bf16 sends wider residual
-  // layers to the eight-wave kernel)
-  if (epi == MD_EPI_RESIDUAL && k.n_pad > md_gemm_w4_residual_max_cols()) return MD_ERR_UNSUPPORTED;
+  // every epilogue takes its bias from the LDS-resident vector only (md_gemm_bf16 sends wider layers to the eight-wave
+  // kernel); the bias / GELU epilogues address C with 32-bit byte offsets
+  if (k.n_pad > md_gemm_w4_max_cols(epi)) return MD_ERR_UNSUPPORTED;
+  if (epi != MD_EPI_RESIDUAL && (uint64_t)k.M * (uint64_t)k.ldc * 2 >= 0xfffff000ull) return MD_ERR_UNSUPPORTED;
 #ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
   if (epi == MD_EPI_BIAS && g_w4_variant != 0) {
     switch (g_w4_variant) {

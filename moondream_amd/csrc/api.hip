@@ -2,7 +2,7 @@
 // reference (moondream.py:168-192) expressed as launch sequences of the kernels
 // in this library.  Nothing here allocates or synchronises; every buffer,
 // including the workspace, belongs to the caller.
-#include "md_common.hpp"
+#include "gemm_internal.hpp"
 #include <cstdlib>
 
 #include <algorithm>
@@ -114,6 +114,8 @@ md_status zero_if_padded(void* p, size_t rows, int ld, int width, hipStream_t s)
 
 struct TextWs {
   void *h, *qkv, *att, *ff, *pos_kv, *splitk;
+  float* rope_cs;      // prefill with the fused RoPE / KV-write epilogue: fp32 [M][32] + uint32 [M]
+  uint32_t* rope_kv;
   size_t splitk_bytes;
   // decode regime: fp32 partial products of proj / fc2 (launch-boundary split-K)
   float *part_a, *part_b;
@@ -137,6 +139,12 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
   }
   w.att = a.take(M * m->blocks[0].proj.k_pad * 2);
   w.pos_kv = a.take((size_t)batch * 4);
+  w.rope_cs = nullptr;
+  w.rope_kv = nullptr;
+  if (M > 64 && q_len > 1 && m->rot_dim == 32) {
+    w.rope_cs = (float*)a.take(M * 32 * sizeof(float));
+    w.rope_kv = (uint32_t*)a.take(M * sizeof(uint32_t));
+  }
   // decode regime: split-K scratch shared by the layer's four linears (stream-ordered)
   size_t sk = 0;
   if (M <= 64) {
@@ -158,6 +166,17 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
   }
   w.total = a.off;
   return w;
+}
+
+// per token row of a prefill: the (cos, sin) row of its position and its byte offset in a layer's K / V slab -- what the fused
+// RoPE / KV-write epilogue of the qkv GEMM (MD_EPI_QKV_ROPE) needs per row, computed once per forward for all layers
+__global__ __launch_bounds__(256) void rope_rowinfo_kernel(const int32_t* __restrict__ pos0, const float* __restrict__ freqs, float* __restrict__ row_cs,
+                                                           uint32_t* __restrict__ row_kv, int q_len, int rows, int64_t slab_bs, int hd, int half2) {
+  const int m = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  if (m >= rows) return;
+  const int b = m / q_len, t = m - b * q_len, pos = pos0[b] + t;
+  if (l < half2) row_cs[(int64_t)m * half2 + l] = freqs[(int64_t)pos * half2 + l];
+  if (l == 0) row_kv[m] = (uint32_t)(((int64_t)b * slab_bs + (int64_t)pos * hd) * 2);
 }
 
 __global__ void kv_len_kernel(const int32_t* pos0, int32_t* kv_len, int q_len, int n) {
@@ -398,11 +417,21 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
   const bool tail_fused = tail_allowed && M <= 64 && D % 8 == 0 && m->blocks[0].proj.b && m->blocks[0].fc2.b &&
                           m->blocks[0].proj.n == D && m->blocks[0].fc2.n == D;
 
+  // Prefill: RoPE + KV write in the epilogue of the fused qkv|fc1 GEMM (MD_EPI_QKV_ROPE) when the four-wave kernel takes the
+  // shape: MHA, head_dim 64, rot_dim 32, slab offsets in 32 bits.  Per-row positions / slab offsets once per forward.
+  const uint64_t slab_bytes = (uint64_t)kv->layer_stride * 2;
+  bool rope_in_gemm = w.rope_cs != nullptr && q_len > 1 && M > 64 && m->n_kv_heads == m->n_heads && hd == 64 && m->rot_dim == 32 &&
+                      m->blocks[0].qkv_fc1.w != nullptr && slab_bytes < 0xfffff000ull && kv->layer_stride >= (int64_t)batch * kv->batch_stride;
+  if (rope_in_gemm)
+    hipLaunchKernelGGL(rope_rowinfo_kernel, dim3((M + 7) / 8), dim3(256), 0, s, pos0, m->freqs, w.rope_cs, w.rope_kv, q_len, M,
+                       kv->batch_stride, hd, m->rot_dim);
+  bool rope_done = false;  // set per block when the fused launch took it
+
   // rope(q), rope(k), cache update (text.py:42-46) and attention over the slab (text.py:48-51) of block l
   auto rope_and_attention = [&](int l, int64_t qld, bool fuse_rope) -> md_status {
     bf16_t* kl = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
     bf16_t* vl = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
-    if (!fuse_rope)
+    if (!fuse_rope && !rope_done)
       MD_TRY(md_rope_kv_write(w.qkv, qld, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
                               q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
     // attention over the slab                                   (text.py:48-51)
@@ -486,7 +515,19 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       g.a = w.h; g.lda = Dp; g.lin = b.qkv_fc1; g.c = w.qkv; g.ldc = qld; g.r = nullptr; g.ldr = 0;
       g.res_row_mod = 0; g.m = M; g.epilogue = MD_EPI_GELU; g.store_pad_cols = 1; g.gelu_from_col = qkv_w;
       g.splitk_ws = w.splitk; g.splitk_ws_bytes = w.splitk_bytes;
-      MD_TRY(md_gemm_bf16(&g, s));
+      rope_done = false;
+      if (rope_in_gemm) {
+        md_rope_fuse rf;
+        rf.row_cs = w.rope_cs; rf.row_kv = w.rope_kv;
+        rf.kslab = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
+        rf.vslab = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
+        rf.slab_bytes = slab_bytes; rf.n_heads = m->n_heads; rf.ctx = kv->ctx;
+        const md_status fs = md_gemm_qkv_rope(&g, &rf, s);
+        if (fs == MD_OK) rope_done = true;
+        else if (fs == MD_ERR_UNSUPPORTED) rope_in_gemm = false;  // a function of the shape: the same answer for every block
+        else return fs;
+      }
+      if (!rope_done) MD_TRY(md_gemm_bf16(&g, s));
     } else {
       MD_TRY(gemm(w.h, Dp, b.qkv, w.qkv, qkv_w, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s, w.splitk, w.splitk_bytes));
     }

@@ -644,8 +644,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
       const float re = bf2f(hp[j]), im = bf2f(hp[half + j]);
       const float cs = freqs[((int64_t)pos * half + j) * 2], sn = freqs[((int64_t)pos * half + j) * 2 + 1];
       // separately rounded mul, mul, sub / add, as torch evaluates them; interleaved output
-      newrow[which][2 * j] = f2bf(__fsub_rn(__fmul_rn(re, cs), __fmul_rn(im, sn)));
-      newrow[which][2 * j + 1] = f2bf(__fadd_rn(__fmul_rn(re, sn), __fmul_rn(im, cs)));
+      float o_re, o_im;
+      md_rope_pair(re, im, cs, sn, o_re, o_im);
+      newrow[which][2 * j] = f2bf(o_re);
+      newrow[which][2 * j + 1] = f2bf(o_im);
     } else if (tid >= 64 && tid < 64 + 2 * (64 - rot)) {  // pass-through features of q and k
       const int t2 = tid - 64, which = t2 / (64 - rot), i = rot + t2 % (64 - rot);
       newrow[which][i] = row[(which ? (n_heads + h) : h) * 64 + i];

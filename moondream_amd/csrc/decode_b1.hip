@@ -407,8 +407,10 @@ __global__ __launch_bounds__(64 * NWV) void decode_b1_kernel(const B1Args p) {
           const int base = (which ? (p.n_heads + h) : h) * 64;
           const float re = act_at(base + j), im = act_at(base + hr + j);
           const float cs = p.freqs[((int64_t)pos * hr + j) * 2], sn = p.freqs[((int64_t)pos * hr + j) * 2 + 1];
-          newrow[which][2 * j] = f2bf(__fsub_rn(__fmul_rn(re, cs), __fmul_rn(im, sn)));
-          newrow[which][2 * j + 1] = f2bf(__fadd_rn(__fmul_rn(re, sn), __fmul_rn(im, cs)));
+          float o_re, o_im;
+          md_rope_pair(re, im, cs, sn, o_re, o_im);
+          newrow[which][2 * j] = f2bf(o_re);
+          newrow[which][2 * j + 1] = f2bf(o_im);
         } else if (tid >= 64 && tid < 64 + 2 * (64 - p.rot)) {
           const int t2 = tid - 64, which = t2 / (64 - p.rot), i = p.rot + t2 % (64 - p.rot);
           newrow[which][i] = f2bf(act_at((which ? (p.n_heads + h) : h) * 64 + i));

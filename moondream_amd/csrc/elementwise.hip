@@ -258,8 +258,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(bf16_t* __restrict__ qkv, 
     const float re = bf2f(hp[j]), im = bf2f(hp[half + j]);
     const float c = fr[2 * j], s = fr[2 * j + 1];
     // separate fp32 roundings, as torch evaluates mul, mul, sub / add
-    o_re[u] = __fsub_rn(__fmul_rn(re, c), __fmul_rn(im, s));
-    o_im[u] = __fadd_rn(__fmul_rn(re, s), __fmul_rn(im, c));
+    md_rope_pair(re, im, c, s, o_re[u], o_im[u]);
   }
   __syncthreads();
 

@@ -55,6 +55,7 @@ struct Knobs {
   int nt = 0;          // MD_DECODE_NT=1: stream decode-regime weights non-temporally
   int decode_cfg = 16; // MD_DECODE_CFG: d / 6 = alternatives to the 64x64 + helper-waves config
   int decode_slices = 0;  // MD_DECODE_SLICES
+  int rope_fuse = 1;      // MD_ROPE_FUSE=0: prefill RoPE + KV write as their own kernel again (A/B, tests)
   Knobs() {
     auto geti = [](const char* n, int d) { const char* e = getenv(n); return (e && *e) ? atoi(e) : d; };
     tile = geti("MD_GEMM_TILE", -1);
@@ -63,6 +64,7 @@ struct Knobs {
     persist = geti("MD_GEMM_PERSIST", 1);
     nt = geti("MD_DECODE_NT", 0);
     decode_slices = geti("MD_DECODE_SLICES", 0);
+    rope_fuse = geti("MD_ROPE_FUSE", 1);
     if (const char* dc = getenv("MD_DECODE_CFG")) {
       if (dc[0] == 'd') decode_cfg = 3;
       else if (dc[0] == '6') decode_cfg = 10;
@@ -713,7 +715,17 @@ int pick_tile(int M, int n_store, int K) {
 
 }  // namespace
 
-extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
+namespace {
+md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse* rf);
+}
+extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) { return gemm_dispatch(a, stream, nullptr); }
+md_status md_gemm_qkv_rope(const md_gemm_args* a, const md_rope_fuse* rf, hipStream_t stream) {
+  MD_CHECK_ARG(rf && rf->row_cs && rf->row_kv && rf->kslab && rf->vslab && rf->n_heads > 0 && rf->ctx > 0);
+  if (!knobs().rope_fuse) return MD_ERR_UNSUPPORTED;
+  return gemm_dispatch(a, (void*)stream, rf);
+}
+namespace {
+md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse* rf) {
   MD_CHECK_ARG(a && a->a && a->c && a->lin.w);
   MD_CHECK_ARG(a->m > 0 && a->lin.n > 0 && a->lin.k > 0);
   MD_CHECK_ARG(a->lin.k_pad % BK == 0 && a->lin.k_pad >= a->lin.k);
@@ -751,6 +763,21 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   k.tickets = nullptr;
   const bool forced = knobs().tile >= 0;
   if (tile == 20 && !md_gemm_w4_takes(k, a->epilogue)) tile = 11;
+  if (rf != nullptr) {
+    // RoPE + KV write in the epilogue: four-wave kernel only, [q | k | v] sections of n_heads x 64 columns ending where the
+    // GELU columns start, slab offsets in 32 bits
+    const int D = rf->n_heads * 64;
+    if (tile != 20 || a->epilogue != MD_EPI_GELU || a->gelu_from_col != 3 * D || D % 128 != 0 || a->m <= 64 ||
+        rf->slab_bytes >= 0xfffff000ull)
+      return MD_ERR_UNSUPPORTED;
+    k.rope_cs = rf->row_cs;
+    k.rope_kv = rf->row_kv;
+    k.kslab = (bf16_t*)rf->kslab;
+    k.vslab = (bf16_t*)rf->vslab;
+    k.slab_bytes = (uint32_t)rf->slab_bytes;
+    k.rope_d = D;
+    k.rope_ctx = rf->ctx;
+  }
   if (tile == 11 && a->epilogue != MD_EPI_RESIDUAL && !forced) {
     // eight-wave baseline: bias / GELU layers with more tiles than CUs run its persistent tile loop
     const long tiles = (long)((k.M + 255) / 256) * ((k.n_store + 255) / 256);
@@ -784,7 +811,7 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   md_status st;
   switch (a->epilogue) {
     case MD_EPI_BIAS: st = launch_epi<MD_EPI_BIAS>(k, tile, s); break;
-    case MD_EPI_GELU: st = launch_epi<MD_EPI_GELU>(k, tile, s); break;
+    case MD_EPI_GELU: st = rf ? md_gemm_w4_launch(k, MD_EPI_QKV_ROPE, s) : launch_epi<MD_EPI_GELU>(k, tile, s); break;
     case MD_EPI_RESIDUAL: st = launch_epi<MD_EPI_RESIDUAL>(k, tile, s); break;
     default: st = MD_ERR_INVALID_ARG;
   }
@@ -794,6 +821,7 @@ extern "C" md_status md_gemm_bf16(const md_gemm_args* a, void* stream) {
   }
   return st;
 }
+}  // namespace
 
 // Launch-boundary split-K (decode regime, m <= 64): S = md_gemm_partial_slices() workgroups per
 // 64-column tile, each over a contiguous range of K, store fp32 partial products
@@ -928,6 +956,7 @@ extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   else if (s == "decode_cfg") k.decode_cfg = value;
   else if (s == "decode_slices") k.decode_slices = value;
   else if (s == "w4_variant") md_gemm_w4_set_variant(value);
+  else if (s == "rope_fuse") k.rope_fuse = value;
   else return MD_ERR_INVALID_ARG;
   return MD_OK;
 }

@@ -24,7 +24,29 @@ struct GemmK {
   int slices;
   float* slabs;
   unsigned* tickets;
+  // MD_EPI_QKV_ROPE (four-wave kernel only): the decoder prefill's fused [q | k | v | gelu(fc1)] layer with the partial RoPE
+  // (rope.py:20-48) and the KV-cache update (text.py:45-46, moondream.py:74-78) applied in the epilogue
+  const float* rope_cs = nullptr;      // fp32 [M][32]: (cos, sin) of the row's position for the 16 rotated pairs
+  const uint32_t* rope_kv = nullptr;   // [M]: byte offset of (slot, position) in a layer's K / V slab
+  bf16_t* kslab = nullptr;
+  bf16_t* vslab = nullptr;
+  uint32_t slab_bytes = 0;             // bytes of one layer's K (= V) slab
+  int rope_d = 0;                      // n_heads * 64: width of each of the q, k, v sections
+  int rope_ctx = 0;                    // cache positions per head
 };
+constexpr int MD_EPI_QKV_ROPE = 3;     // internal to the library (md_gemm_qkv_rope)
+
+// The fused layer of a decoder block at prefill with RoPE + KV write in its epilogue, when the four-wave kernel takes the
+// shape (MD_ERR_UNSUPPORTED otherwise: the caller runs md_gemm_bf16 + md_rope_kv_write).  MHA, head_dim 64, rot_dim 32.
+struct md_rope_fuse {
+  const float* row_cs;
+  const uint32_t* row_kv;
+  void* kslab;
+  void* vslab;
+  uint64_t slab_bytes;
+  int n_heads, ctx;
+};
+md_status md_gemm_qkv_rope(const md_gemm_args* a, const md_rope_fuse* rf, hipStream_t stream);
 
 // gemm_w4.hip: the 256x256 tile kernel with one wave per SIMD (4 waves x 128x128), persistent.
 // epi = MD_EPI_*.  Fills tiles_m / tiles_n itself.

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
         u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
-        if constexpr (EPI == MD_EPI_GELU) {
+        if constexpr (EPI == MD_EPI_GELU || EPI == MD_EPI_QKV_ROPE) {
           if (wn0 + 32 * j >= p.gelu_from) {  // wave-uniform: gelu_from is a multiple of 64 (fused [qkv | fc1] layers)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -514,7 +514,111 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       MD_PIN();
     });
     };
-    if (full_cols) store_tile(std::true_type{}); else store_tile(std::false_type{});
+    // ---- MD_EPI_QKV_ROPE: the q / k / v sections of the decoder's fused layer at prefill ------------------------------
+    // A wave's 128 columns are two heads of ONE section (sections are n_heads x 64 wide, a multiple of 128).  Per head the
+    // first 32 features are rotated: the reference reads them half-split (re = x[d], im = x[16 + d]) and writes them
+    // interleaved (rope.py:37-46).  In the accumulator layout a lane holds quads q = 0..3 of column block j, i.e. features
+    // 8 q + 4 hi + e: re (q = 0, 1) and im (q + 2) of a pair sit in the SAME lane, and the rotated pairs of quad q are the 8
+    // consecutive output features 16 q + 8 hi ..: a 16-byte piece with no lane exchange.  fp32 arithmetic on the bf16-rounded
+    // layer output with separately rounded mul, mul, sub / add, as torch evaluates it (bit-equal to rope_kv_kernel).
+    // q stays in the activation (rotated), k and v go straight to the KV slab (text.py:45-46): one pass over the bytes
+    // instead of the GEMM's stores + rope_kv_kernel's load and store of every q / k / v element.
+    auto rope_tile = [&]() {
+      const int sec = wn0 / p.rope_d;               // 0 q, 1 k, 2 v   (wave-uniform)
+      const int head0 = (wn0 - sec * p.rope_d) >> 6;
+      bf16_t* slab = (sec == 1) ? p.kslab : p.vslab;
+      const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (int)p.slab_bytes, 0x00020000);
+      static_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = wm0 + 32 * i + l31, mc = min(m, p.M - 1);
+        const uint32_t row_off = (uint32_t)m * (uint32_t)(p.ldc * 2) + (uint32_t)(wn0 + 8 * hi) * 2u;
+        uint32_t kv_off = 0xfffff000u;  // rows past M: dropped by the range check
+        if (sec != 0 && m < p.M) kv_off = p.rope_kv[mc] + (uint32_t)hi * 16u;
+        f32x4 cs[4];  // (cos, sin) of features 4 hi + {0,1}, {2,3}, 8 + 4 hi + {0,1}, {2,3}
+        if (sec != 2) {
+          const f32x4* cp = (const f32x4*)(p.rope_cs + (int64_t)mc * 32);
+          cs[0] = cp[2 * hi];
+          cs[1] = cp[2 * hi + 1];
+          cs[2] = cp[4 + 2 * hi];
+          cs[3] = cp[4 + 2 * hi + 1];
+        }
+        static_for<0, 2>([&](auto jc) {
+          constexpr int jp = decltype(jc)::value;
+          const uint32_t head_off = (uint32_t)(head0 + jp) * (uint32_t)p.rope_ctx * 128u;  // slab: [head][position][64] bf16
+          auto put = [&](const u32x4& v, int col_in_head_bytes) {  // col_in_head_bytes: immediate-sized constant
+            if (sec == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, row_off + 128 * jp + col_in_head_bytes, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_s, kv_off + col_in_head_bytes, head_off, 0);
+          };
+          // features 0..31 of the head: column block j = 2 jp
+          {
+            constexpr int j = 2 * jp, base = 16 * (4 * i + j);
+            float x[4][4];
+            static_for<0, 4>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              const md_f32x2 u0 = md_f32x2{acc_read<base + 4 * q + 0>(), acc_read<base + 4 * q + 1>()} + bias_f[j][q][0];
+              const md_f32x2 u1 = md_f32x2{acc_read<base + 4 * q + 2>(), acc_read<base + 4 * q + 3>()} + bias_f[j][q][1];
+              const uint32_t w0 = pack_bf16x2(u0[0], u0[1]), w1 = pack_bf16x2(u1[0], u1[1]);  // the layer's bf16 output
+              x[q][0] = lo_bf(w0); x[q][1] = hi_bf(w0); x[q][2] = lo_bf(w1); x[q][3] = hi_bf(w1);
+            });
+            if (sec != 2) {
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                u32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float re = x[q][e], im = x[q + 2][e];
+                  const float c = cs[2 * q + (e >> 1)][2 * (e & 1)], sn = cs[2 * q + (e >> 1)][2 * (e & 1) + 1];
+                  float o_re, o_im;
+                  md_rope_pair(re, im, c, sn, o_re, o_im);
+                  v[e] = pack_bf16x2(o_re, o_im);
+                }
+                put(v, q * 32);  // features 16 q + 8 hi .. + 7 (the 8 hi is part of row_off / kv_off)
+              }
+            } else {
+              // v: no rotation; the standard 16-byte pieces (quads q0, q0 + 1 of the two lane halves side by side)
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const uint32_t a0 = pack_bf16x2(x[2 * t][0], x[2 * t][1]), a1 = pack_bf16x2(x[2 * t][2], x[2 * t][3]);
+                const uint32_t b0 = pack_bf16x2(x[2 * t + 1][0], x[2 * t + 1][1]), b1 = pack_bf16x2(x[2 * t + 1][2], x[2 * t + 1][3]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                put(u32x4{s0[0], s1[0], s0[1], s1[1]}, t * 32);
+              }
+            }
+          }
+          // features 32..63: column block j = 2 jp + 1, never rotated (rot_dim 32)
+          {
+            constexpr int j = 2 * jp + 1, base = 16 * (4 * i + j);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              uint32_t w[4];
+              static_for<0, 2>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;  // quads 2 t and 2 t + 1
+                auto rd = [&](auto tt) {
+                  constexpr int q = 2 * decltype(tt)::value + hq;
+                  const md_f32x2 u0 = md_f32x2{acc_read<base + 4 * q + 0>(), acc_read<base + 4 * q + 1>()} + bias_f[j][q][0];
+                  const md_f32x2 u1 = md_f32x2{acc_read<base + 4 * q + 2>(), acc_read<base + 4 * q + 3>()} + bias_f[j][q][1];
+                  w[2 * hq] = pack_bf16x2(u0[0], u0[1]);
+                  w[2 * hq + 1] = pack_bf16x2(u1[0], u1[1]);
+                };
+                if (t == 0) rd(std::integral_constant<int, 0>{}); else rd(std::integral_constant<int, 1>{});
+              });
+              const auto s0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+              put(u32x4{s0[0], s1[0], s0[1], s1[1]}, 64 + t * 32);
+            }
+          }
+        });
+        MD_PIN();
+      });
+    };
+    if constexpr (EPI == MD_EPI_QKV_ROPE) {
+      if (wn0 < 3 * p.rope_d) rope_tile();
+      else if (full_cols) store_tile(std::true_type{});
+      else store_tile(std::false_type{});
+    } else {
+      if (full_cols) store_tile(std::true_type{}); else store_tile(std::false_type{});
+    }
     }
     if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
@@ -590,6 +694,7 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
     case MD_EPI_BIAS: return launch<MD_EPI_BIAS>(k, stream);
     case MD_EPI_GELU: return launch<MD_EPI_GELU>(k, stream);
     case MD_EPI_RESIDUAL: return launch<MD_EPI_RESIDUAL>(k, stream);
+    case MD_EPI_QKV_ROPE: return launch<MD_EPI_QKV_ROPE>(k, stream);
     default: return MD_ERR_INVALID_ARG;
   }
 }

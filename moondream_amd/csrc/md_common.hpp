@@ -65,6 +65,22 @@ __device__ __forceinline__ md_f32x2 gelu_tanh_f32x2(md_f32x2 x) {
   return x * r;
 }
 
+// One RoPE pair exactly as torch evaluates it (rope.py:40-45: xq_r * cos - xq_i * sin, xq_r * sin + xq_i * cos, each an
+// elementwise fp32 op): FOUR separately rounded products, then one subtraction and one addition.  The files are built
+// with -ffp-contract=fast, and __fmul_rn / __fsub_rn do not stop hipcc from contracting a product into the add (round 3
+// found v_pk_fma_f32 in every RoPE site: one rounding fewer than the reference, visible as rare last-bit flips after the
+// bf16 rounding); the empty asm makes each product a value of its own.
+__device__ __forceinline__ float md_mul_rounded(float a, float b) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+__device__ __forceinline__ void md_rope_pair(float re, float im, float cs, float sn, float& o_re, float& o_im) {
+  const float a = md_mul_rounded(re, cs), b = md_mul_rounded(im, sn), c = md_mul_rounded(re, sn), d = md_mul_rounded(im, cs);
+  o_re = a - b;
+  o_im = c + d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -72,6 +72,12 @@ def parity_report(got_ids, ref_ids, margins, got_topk: Optional[np.ndarray], ref
         thr, err_ok = 0.5, True  # no logits available: the flat round-2 licence
         rep["parity_threshold"] = thr
     bad = [d for d in div if d[4] > thr]
+    # sequences that MUST be identical: every decision's reference margin above the licence (enforced by `bad` above); the
+    # others may tip either way -- the bench fixture has 9 sequences with an exact tie (margin 0) and only 12 whose smallest
+    # margin exceeds 0.25, so the COUNT of identical sequences is a noisy statistic (46..52 of 64 across builds that differ in
+    # a handful of last-bit roundings).  `min_exact` is therefore a sanity floor, not the parity criterion.
+    mm = np.asarray(margins)[:n, : (tokens if tokens is not None else np.asarray(margins).shape[1])]
+    rep["parity_must_match"] = int((mm.min(axis=1) > thr).sum())
     ok = err_ok and not bad and (min_exact is None or exact >= min_exact)
     rep["parity_ok"] = bool(ok)
     rep["parity_note"] = (

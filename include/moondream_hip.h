@@ -483,7 +483,22 @@ typedef struct {
   void* v;
   int64_t layer_stride, batch_stride; /* elements */
   int32_t ctx;
+  /* Optional e4m3fn copy of the cache for the decode steps of the fp8 mode (NULL: bf16 only): slabs of the same shape with
+   * one byte per element and ONE static scale per layer (HOST arrays of n_layers floats: value ~= scale * fp8).  When
+   * set, md_text_forward keeps both copies current (prefill rows are quantised after the bf16 rows are written, a
+   * decode step writes the new row into both) and the decode attention reads the e4m3 copy -- half the bytes of the
+   * step's dominant stream.  MHA with head_dim 64 only; md_text_forward_lora and md_decode_step_b1 ignore it. */
+  void* k8;
+  void* v8;
+  const float* k_scale;
+  const float* v_scale;
 } md_kv_cache;
+
+/* (Re)build the e4m3 copy from the bf16 slabs for positions pos .. pos + n_pos - 1 of `batch` slots, every layer and
+ * head (pos = pos0[b], device int32, or pos_fixed when pos0 is NULL): after bf16 rows were written by something other
+ * than md_text_forward (load_encoded_image's copy). */
+md_status md_kv_quantize_f8(const md_kv_cache* kv, int32_t n_layers, int32_t batch, int32_t n_heads, const int32_t* pos0,
+                            int32_t pos_fixed, int32_t n_pos, void* stream);
 
 size_t md_text_workspace_bytes(const md_text_model* m, int32_t batch, int32_t q_len);
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "gemm_f8.hip", "quant_f8.hip", "decode_b1.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "gemm_f8.hip", "quant_f8.hip", "attention_f8kv.hip", "decode_b1.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
 ABI_VERSION = 3  # include/moondream_hip.h MD_ABI_VERSION
@@ -138,7 +138,8 @@ class MdTextBlockLora(C.Structure):
 
 
 class MdKvCache(C.Structure):
-    _fields_ = [("k", c_void_p), ("v", c_void_p), ("layer_stride", c_int64), ("batch_stride", c_int64), ("ctx", c_int32)]
+    _fields_ = [("k", c_void_p), ("v", c_void_p), ("layer_stride", c_int64), ("batch_stride", c_int64), ("ctx", c_int32),
+                ("k8", c_void_p), ("v8", c_void_p), ("k_scale", c_void_p), ("v_scale", c_void_p)]
 
 
 # name -> (restype, argtypes): every symbol include/moondream_hip.h declares
@@ -162,6 +163,7 @@ SIGNATURES = {
     "md_quantize_f8": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "md_layernorm_f8": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "md_amax_bf16": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "md_kv_quantize_f8": (C.c_int, [P(MdKvCache), c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "md_gemm_set_tuning": (C.c_int, [C.c_char_p, c_int32]),
     "md_profile_gemm": (None, [c_int32]),
     "md_profile_gemm_read": (C.c_int, [c_int32, P(C.c_double), P(C.c_double), P(c_int64)]),

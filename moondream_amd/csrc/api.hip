@@ -368,6 +368,13 @@ extern "C" size_t md_text_workspace_bytes(const md_text_model* m, int32_t batch,
   return need;
 }
 
+md_status md_kv_quantize_f8_layer(const md_kv_cache* kv, int layer, const int32_t* pos0, int pos_fixed, int batch, int n_heads, int n_pos,
+                                  hipStream_t s);
+md_status md_attention_decode_rope_f8_launch(const void* qkv, int64_t ld, void* o, int64_t ldo, const float* freqs, void* k_slab, void* v_slab,
+                                             void* k8_slab, void* v8_slab, int64_t slab_batch_stride, int32_t ctx, const int32_t* kv_len,
+                                             int32_t batch, int32_t n_heads, int32_t rot_dim, float scale, float k_scale, float v_scale,
+                                             hipStream_t s);
+
 // reference: text.py:128-160 (text_decoder) with text.py:16-60 (attn)
 extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, void* hidden,
                                      int32_t batch, int32_t q_len, const int32_t* pos0,
@@ -435,7 +442,13 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       MD_TRY(md_rope_kv_write(w.qkv, qld, m->freqs, pos0, kl, vl, kv->batch_stride, kv->ctx, batch,
                               q_len, m->n_heads, m->n_kv_heads, hd, m->rot_dim, s));
     // attention over the slab                                   (text.py:48-51)
-    if (fuse_rope) {
+    const bool kv8 = kv->k8 && kv->v8 && kv->k_scale && kv->v_scale && m->n_kv_heads == m->n_heads && hd == 64;
+    if (fuse_rope && kv8) {
+      // fp8 mode: the step attends over the e4m3 copy of the cache and writes the new row into both copies
+      MD_TRY(md_attention_decode_rope_f8_launch(w.qkv, qld, w.att, Dp, m->freqs, kl, vl, (uint8_t*)kv->k8 + (int64_t)l * kv->layer_stride,
+                                                (uint8_t*)kv->v8 + (int64_t)l * kv->layer_stride, kv->batch_stride, kv->ctx, kv_len, batch,
+                                                m->n_heads, m->rot_dim, scale, kv->k_scale[l], kv->v_scale[l], s));
+    } else if (fuse_rope) {
       MD_TRY(md_attention_decode_rope(w.qkv, qld, w.att, Dp, m->freqs, kl, vl, kv->batch_stride, kv->ctx, kv_len,
                                       batch, m->n_heads, hd, m->rot_dim, scale, s));
     } else if (q_len == 1) {
@@ -468,6 +481,8 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       a.scale = scale;
       MD_TRY(md_attention_prefill(&a, s));
     }
+    // fp8 mode: the rows this pass wrote (bf16) also go into the e4m3 copy the decode steps read
+    if (kv8 && !fuse_rope) MD_TRY(md_kv_quantize_f8_layer(kv, l, pos0, 0, batch, m->n_heads, q_len, s));
     return MD_OK;
   };
 

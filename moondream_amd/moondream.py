@@ -118,6 +118,8 @@ class MoondreamModel:
         self._arenas: Dict[int, torch.Tensor] = {}
         self._max_batch = 0
         self._kv_k = self._kv_v = None
+        self._kv_k8 = self._kv_v8 = None   # fp8 mode: e4m3 copy of the cache for the decode steps
+        self._kv8_scales = None            # (ctypes float[L] for K, for V) when that copy is in use
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = False
         self.collect_timing = False
@@ -161,10 +163,17 @@ class MoondreamModel:
         with torch.inference_mode(False):
             self._kv_k = torch.zeros(t.n_layers, b, t.n_kv_heads, t.max_context, t.head_dim, dtype=BF16, device=self._device)
             self._kv_v = torch.zeros_like(self._kv_k)
+            old_k8, old_v8 = self._kv_k8, self._kv_v8
+            if self._kv8_scales is not None:  # fp8 mode: the e4m3 copy the decode steps read
+                self._kv_k8 = torch.zeros(self._kv_k.shape, dtype=torch.uint8, device=self._device)
+                self._kv_v8 = torch.zeros_like(self._kv_k8)
             if old_k is not None:  # slots loaded earlier (load_encoded_image) survive the growth
                 keep = min(b, old_k.shape[1])
                 self._kv_k[:, :keep] = old_k[:, :keep]
                 self._kv_v[:, :keep] = old_v[:, :keep]
+                if old_k8 is not None and self._kv_k8 is not None:
+                    self._kv_k8[:, :keep] = old_k8[:, :keep]
+                    self._kv_v8[:, :keep] = old_v8[:, :keep]
         self._max_batch = b
         self._graphs.clear()
 
@@ -176,9 +185,15 @@ class MoondreamModel:
         t = self.config.text
         bs = t.n_kv_heads * t.max_context * t.head_dim
         off = slot0 * bs * 2
-        return _lib.MdKvCache(
+        kv = _lib.MdKvCache(
             self._kv_k.data_ptr() + off, self._kv_v.data_ptr() + off, self._max_batch * bs, bs, t.max_context
         )
+        if self._kv8_scales is not None and self._kv_k8 is not None:
+            off8 = slot0 * bs
+            kv.k8, kv.v8 = self._kv_k8.data_ptr() + off8, self._kv_v8.data_ptr() + off8
+            kv.k_scale = C.cast(self._kv8_scales[0], C.c_void_p)
+            kv.v_scale = C.cast(self._kv8_scales[1], C.c_void_p)
+        return kv
 
     def _workspace(self, nbytes: int, which: int = 0) -> torch.Tensor:
         """Caller-owned arenas for the C ABI.  0: encode-side stages, 1: lm_head of the
@@ -228,13 +243,16 @@ class MoondreamModel:
         self._graphs.clear()  # captured decode steps baked the other launches in
 
     def enable_fp8(self, calibration_images: Optional[Sequence[Image.Image]] = None, prompt: Optional[Sequence[int]] = None,
-                   on: bool = True, decode_weights: bool = True, margin: float = 1.5) -> Optional[dict]:
+                   on: bool = True, decode_weights: bool = True, margin: float = 1.5, kv_cache: bool = True) -> Optional[dict]:
         """Opt-in FP8 mode of the whole hot path (BASELINE configs[4] "fp8 weights, CDNA4 fp8 MFMA"): every MFMA-bound
         linear of the ViT blocks, the projector and the decoder prefill runs on ``md_gemm_f8`` (e4m3 operands,
         v_mfma_f32_32x32x64_f8f6f4 at twice the bf16 matrix rate, fp32 accumulation) with per-channel weight scales and ONE
         static scale per quantised activation tensor; ``decode_weights`` also streams e4m3 weights in the decode steps
         (``enable_fp8_decode``).  Patch embedding, layer-norm statistics, attention, RoPE, the KV cache, the residual
-        stream, lm_head at prefill and the region head stay bf16 / fp32.
+        stream, lm_head at prefill and the region head stay bf16 / fp32.  ``kv_cache`` (needs ``decode_weights``, MHA,
+        head_dim 64) additionally keeps an e4m3 COPY of the KV cache, one static scale per layer for K and for V, that the
+        decode steps attend over instead of the bf16 slabs -- half the bytes of the step's dominant stream; prefill
+        attention, ``EncodedImage`` snapshots and the reference-compatible views keep using the bf16 slabs.
 
         The activation scales are CALIBRATED: ``calibration_images`` (a handful is enough) are run through the bf16
         path once with range recording on (vision + image / prompt prefill), then the e4m3 weight copies are built.
@@ -245,6 +263,9 @@ class MoondreamModel:
             self.w.disable_f8()
             if decode_weights:
                 self.enable_fp8_decode(False)
+            torch.cuda.synchronize(self._device)
+            self._kv8_scales = None
+            self._kv_k8 = self._kv_v8 = None
             return None
         if not calibration_images:
             raise ValueError("enable_fp8 needs a few calibration images (PIL) to size the activation scales")
@@ -256,7 +277,18 @@ class MoondreamModel:
                 n = len(calibration_images)
                 self._prepare_sequences(list(calibration_images), [prompt] * n, None, None, fuse=True)
                 torch.cuda.synchronize(self._device)
+                t = self.config.text
+                p1 = t.prefix_attn + len(prompt)
+                if kv_cache and decode_weights and t.n_heads == t.n_kv_heads and t.head_dim == 64:
+                    # K / V ranges of the calibration batch per layer (rows 0 .. p1 - 1 of its slots: the prefill just written)
+                    ka = self._kv_k[:, :n, :, :p1].float().abs().amax(dim=(1, 2, 3, 4)).cpu().tolist()
+                    va = self._kv_v[:, :n, :, :p1].float().abs().amax(dim=(1, 2, 3, 4)).cpu().tolist()
+                    sc = lambda a: (a * margin / 448.0) if a > 0 else 1.0
+                    self._kv8_scales = ((C.c_float * t.n_layers)(*[sc(a) for a in ka]), (C.c_float * t.n_layers)(*[sc(a) for a in va]))
+                    self._kv_k8 = torch.zeros(self._kv_k.shape, dtype=torch.uint8, device=self._device)
+                    self._kv_v8 = torch.zeros_like(self._kv_k8)
             info = self.w.finish_f8_calibration(margin)
+            info["kv_cache_fp8"] = self._kv8_scales is not None
         except Exception:
             self.w.disable_f8()
             raise
@@ -631,6 +663,11 @@ class MoondreamModel:
             for l, (k, v) in enumerate(encoded_image.caches):
                 self._kv_k[l, slot : slot + 1, :, : k.size(2), :] = k
                 self._kv_v[l, slot : slot + 1, :, : v.size(2), :] = v
+            if self._kv8_scales is not None:  # fp8 mode: rebuild the e4m3 copy of the rows just loaded
+                kv = self._kv_struct(slot)
+                t = self.config.text
+                _lib.check(self.lib.md_kv_quantize_f8(C.byref(kv), t.n_layers, 1, t.n_kv_heads, None, 0, int(encoded_image.pos), self._stream()),
+                           "md_kv_quantize_f8")
 
     # --------------------------------------------------------------- sampling
     def _apply_top_p(self, probs: torch.Tensor, top_p: float) -> torch.Tensor:

@@ -655,7 +655,7 @@ def fp8_decode_report(model, images, prompts, ids_bf16, ref_margins, label):
     assert sum(prefix) / len(prefix) >= 0.25 * n_tok, prefix
 
 
-def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3, ref=None):
+def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3, ref=None, kv_cache=True):
     """The full fp8 mode (md_gemm_f8 for the ViT blocks, the projector and the prefill + the fp8 decode stream) against the
     bf16 mode on the same inputs: projected image embeddings, K rows of the image prefix and first-token logits within the
     tolerance of e4m3 operands (3 mantissa bits: a few percent per tensor, compounding over 27 + 24 blocks), token streams
@@ -664,9 +664,10 @@ def fp8_full_report(model, images, prompts, ids_bf16, label, n_calib=3, ref=None
     with torch.inference_mode():
         emb_b = model._run_vision_encoder_batch(images[:2]).float().cpu()
     enc_b = model.encode_image(images[0])
-    info = model.enable_fp8(images[:n_calib], prompts[0])
+    info = model.enable_fp8(images[:n_calib], prompts[0], kv_cache=kv_cache)
+    label = f"{label}, e4m3 KV cache {'on' if kv_cache else 'off'}"
     try:
-        assert model.w.f8_enabled()
+        assert model.w.f8_enabled() and info["kv_cache_fp8"] == kv_cache
         with torch.inference_mode():
             emb_8 = model._run_vision_encoder_batch(images[:2]).float().cpu()
         enc_8 = model.encode_image(images[0])
@@ -709,7 +710,20 @@ def test_fp8_full_mode_tiny(tiny):
     prompts = [g[f"img{i}.cap.prompt"].tolist() for i in range(n_img)]
     n = len(g["img0.cap.tokens"])
     ids = model.batch_generate_ids(images, prompts, max_tokens=n, ignore_eos=True)
-    fp8_full_report(model, images, prompts, ids, "tiny")
+    fp8_full_report(model, images, prompts, ids, "tiny", kv_cache=False)
+    fp8_full_report(model, images, prompts, ids, "tiny", kv_cache=True)
+    # an EncodedImage loaded into a slot gets its e4m3 copy rebuilt (load_encoded_image): same ids as the raw image
+    enc = model.encode_image(images[0])
+    model.enable_fp8(images, prompts[0])
+    try:
+        a = model.batch_generate_ids([images[0]], [prompts[0]], max_tokens=8, ignore_eos=True)
+        model.fused_prefill = False  # raw image through the same two passes as the EncodedImage
+        b = model.batch_generate_ids([images[0]], [prompts[0]], max_tokens=8, ignore_eos=True)
+        c = model.batch_generate_ids([model.encode_image(images[0])], [prompts[0]], max_tokens=8, ignore_eos=True)
+        assert b == c, (a, b, c)
+    finally:
+        model.fused_prefill = True
+        model.enable_fp8(on=False)
 
 
 def test_fp8_decode_mode_tiny(tiny):
@@ -857,4 +871,5 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     # opt-in FP8 weight stream for the decode steps of the same configuration (BASELINE configs[4]): a different
     # numerical mode, judged by tolerance against the bf16 path -- never by bit parity
     fp8_decode_report(model, imgs64, [pr] * 64, got64, gb["margins"], "2b B=64")
-    fp8_full_report(model, imgs64, [pr] * 64, got64, "2b B=64", n_calib=8, ref=gb)
+    fp8_full_report(model, imgs64, [pr] * 64, got64, "2b B=64", n_calib=8, ref=gb, kv_cache=False)
+    fp8_full_report(model, imgs64, [pr] * 64, got64, "2b B=64", n_calib=8, ref=gb, kv_cache=True)

@@ -494,6 +494,15 @@ typedef struct {
   const float* v_scale;
 } md_kv_cache;
 
+/* md_attention_decode_rope over the e4m3 copy of ONE layer's slabs (k8 / v8: that layer's e4m3 K / V slab, k_scale /
+ * v_scale its scales): RoPE of the new token's q / k, the new K / V row written into BOTH copies, attention of every
+ * (sequence, head) over keys [0, kv_len[b]) of the e4m3 copy with the new row taken as the cache will hold it
+ * (quantised, dequantised).  head_dim 64, MHA.  Tolerance-judged against md_attention_decode_rope. */
+md_status md_attention_decode_rope_f8(const void* qkv, int64_t ld, void* o, int64_t ldo, const float* freqs, void* k_slab,
+                                      void* v_slab, void* k8_slab, void* v8_slab, int64_t slab_batch_stride, int32_t ctx,
+                                      const int32_t* kv_len, int32_t batch, int32_t n_heads, int32_t rot_dim, float scale,
+                                      float k_scale, float v_scale, void* stream);
+
 /* (Re)build the e4m3 copy from the bf16 slabs for positions pos .. pos + n_pos - 1 of `batch` slots, every layer and
  * head (pos = pos0[b], device int32, or pos_fixed when pos0 is NULL): after bf16 rows were written by something other
  * than md_text_forward (load_encoded_image's copy). */

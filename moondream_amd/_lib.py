@@ -163,6 +163,8 @@ SIGNATURES = {
     "md_quantize_f8": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "md_layernorm_f8": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, P(MdLayerNorm), c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "md_amax_bf16": (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "md_attention_decode_rope_f8": (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                              c_int32, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p]),
     "md_kv_quantize_f8": (C.c_int, [P(MdKvCache), c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "md_gemm_set_tuning": (C.c_int, [C.c_char_p, c_int32]),
     "md_profile_gemm": (None, [c_int32]),

@@ -246,3 +246,11 @@ md_status md_attention_decode_rope_f8_launch(const void* qkv, int64_t ld, void* 
                      scale * 1.4426950408889634f, rot_dim, k_scale, v_scale);
   return md_launch_status();
 }
+
+extern "C" md_status md_attention_decode_rope_f8(const void* qkv, int64_t ld, void* o, int64_t ldo, const float* freqs, void* k_slab,
+                                                 void* v_slab, void* k8_slab, void* v8_slab, int64_t slab_batch_stride, int32_t ctx,
+                                                 const int32_t* kv_len, int32_t batch, int32_t n_heads, int32_t rot_dim, float scale,
+                                                 float k_scale, float v_scale, void* stream) {
+  return md_attention_decode_rope_f8_launch(qkv, ld, o, ldo, freqs, k_slab, v_slab, k8_slab, v8_slab, slab_batch_stride, ctx, kv_len, batch,
+                                            n_heads, rot_dim, scale, k_scale, v_scale, (hipStream_t)stream);
+}

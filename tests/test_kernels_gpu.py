@@ -838,3 +838,45 @@ def test_quantize_layernorm_amax_f8(lib):
     _lib.check(lib.md_amax_bf16(x.data_ptr(), x.stride(0), rows, dim, am.data_ptr(), stream()))
     torch.cuda.synchronize()
     assert float(am[0]) == 1000.0
+
+
+def test_decode_attention_over_e4m3_kv_cache(lib):
+    """md_attention_decode_rope_f8 / md_kv_quantize_f8: the e4m3 copy equals torch's conversion of the bf16 slab / scale, the
+    new token's row lands in BOTH copies (bf16 rows bit-equal to the bf16 kernel's), and the attention output equals -- to
+    fp32 summation order -- the softmax attention computed in torch over the DEQUANTISED cache with the same bf16
+    probabilities."""
+    b, h, hd, ctx, rot = 5, 4, 64, 2048, 32
+    qkv = randn(b, 3 * h * hd + 64, seed=80)
+    ld = qkv.stride(0)
+    freqs = rope_table(rot, ctx).cuda()
+    pos0 = torch.tensor([730, 0, 1, 2047, 915], dtype=torch.int32, device="cuda")
+    lens = pos0 + 1
+    k0, v0 = randn(b, h, ctx, hd, scale=2.0, seed=81), randn(b, h, ctx, hd, scale=0.5, seed=82)
+    ks, vs = float(k0.float().abs().max()) * 1.5 / 448.0, float(v0.float().abs().max()) * 1.5 / 448.0
+    k8, v8 = torch.zeros(b, h, ctx, hd, dtype=torch.uint8, device="cuda"), torch.zeros(b, h, ctx, hd, dtype=torch.uint8, device="cuda")
+    scales = ((C.c_float * 1)(ks), (C.c_float * 1)(vs))
+    kv = _lib.MdKvCache(k0.data_ptr(), v0.data_ptr(), b * h * ctx * hd, h * ctx * hd, ctx, k8.data_ptr(), v8.data_ptr(),
+                        C.cast(scales[0], C.c_void_p), C.cast(scales[1], C.c_void_p))
+    _lib.check(lib.md_kv_quantize_f8(C.byref(kv), 1, b, h, None, 0, ctx, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(k8, quant_rows(k0, ks).view(torch.uint8)) and torch.equal(v8, quant_rows(v0, vs).view(torch.uint8))
+    # reference of the bf16 kernel for the new rows
+    qa, ka, va = qkv.clone(), k0.clone(), v0.clone()
+    _lib.check(lib.md_rope_kv_write(qa.data_ptr(), ld, freqs.data_ptr(), pos0.data_ptr(), ka.data_ptr(), va.data_ptr(),
+                                    h * ctx * hd, ctx, b, 1, h, h, hd, rot, stream()))
+    o = torch.zeros(b, h * hd, dtype=BF16, device="cuda")
+    _lib.check(lib.md_attention_decode_rope_f8(qkv.data_ptr(), ld, o.data_ptr(), h * hd, freqs.data_ptr(), k0.data_ptr(), v0.data_ptr(),
+                                               k8.data_ptr(), v8.data_ptr(), h * ctx * hd, ctx, lens.data_ptr(), b, h, rot, 0.125, ks, vs, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(k0, ka) and torch.equal(v0, va)  # the bf16 copy got the same new rows as the bf16 path writes
+    for bi in range(b):
+        p = int(pos0[bi])
+        assert torch.equal(k8[bi, :, p], quant_rows(ka[bi, :, p], ks).view(torch.uint8)) and torch.equal(v8[bi, :, p], quant_rows(va[bi, :, p], vs).view(torch.uint8))
+        n = p + 1
+        kd = k8[bi, :, :n].view(F8).float() * ks
+        vd = v8[bi, :, :n].view(F8).float() * vs
+        q = qa[bi, : h * hd].view(h, hd).float()  # rotated q, as the bf16 path leaves it in the activation
+        s = torch.einsum("hd,hnd->hn", q, kd) * 0.125
+        pr = torch.exp(s - s.amax(dim=1, keepdim=True))
+        want = (torch.einsum("hn,hnd->hd", pr.to(BF16).float(), vd) / pr.sum(dim=1, keepdim=True)).to(BF16)
+        compare(f"decode attention over the e4m3 cache, len {n}", o[bi].view(h, hd), want, 6e-3, 4e-2)

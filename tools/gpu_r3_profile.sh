@@ -19,7 +19,7 @@ guarded() {  # guarded <seconds> <log> <command...>
 LEGS="--no-cpu-baseline --no-vqa-leg --no-fp8-leg --no-dedup-leg --no-detect13-leg --no-fp8-full-leg --latency-runs 0"
 guarded 150 $O/trace.log rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py $LEGS --steps 3 --warmup 1
 f=$(find $O/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && head -12 "$f" | cut -c1-150
-tail -1 $O/trace.log | cut -c1-400 > $O/bench_traced.json
+grep '^{"metric"' $O/trace.log | tail -1 > $O/bench_traced.json
 ONE="python $R/bench.py $LEGS --steps 1 --warmup 0 --tokens 1 --batch 64 --no-graphs --no-pipeline --only-timed-steps"
 for c in FETCH_SIZE WRITE_SIZE; do
   guarded 150 $O/$c.log rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -o r1 -- $ONE
@@ -57,7 +57,7 @@ if cc and kt:
         d = dur.get(row["Dispatch_Id"])
         if not d: continue
         k = d[1]
-        fam = ("w4 GEMM bias" if "gemm_w4_kernel<0" in k else "w4 GEMM gelu" if "gemm_w4_kernel<1" in k else "w4 GEMM residual" if "gemm_w4_kernel<2" in k
+        fam = ("w4 GEMM bias" if "gemm_w4_kernel<0" in k else "w4 GEMM gelu" if "gemm_w4_kernel<1" in k else "w4 GEMM residual" if "gemm_w4_kernel<2" in k else "w4 GEMM qkv|fc1 + rope + KV write" if "gemm_w4_kernel<3" in k
                else "prefill attention hd72" if "attn_prefill_dma_kernel<72" in k else "prefill attention hd64" if "attn_prefill_dma_kernel<64" in k else None)
         if fam is None or d[0] < 20000: continue
         a = agg[fam]
@@ -69,7 +69,7 @@ if cc and kt:
             clk = gui / ns / 8 if ns else 0.0          # GHz: GRBM_GUI_ACTIVE is summed over the 8 XCDs
             # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs: 256 CUs x 4 SIMDs x (kernel cycles) is 100 %
             busy = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024) if gui else 0.0
-            line = (f"{fam:26s} launches {int(a['n']):4d}  time {ns / 1e6:8.2f} ms  clock {clk:.3f} GHz  MFMA-busy {100 * busy:5.1f} % of SIMD-cycles "
+            line = (f"{fam:34s} launches {int(a['n']):4d}  time {ns / 1e6:8.2f} ms  clock {clk:.3f} GHz  MFMA-busy {100 * busy:5.1f} % of SIMD-cycles "
                     f"-> {busy * clk / 2.4 * 100:5.1f} % of the 2.4 GHz peak")
             print(line); fo.write(line + "\n")
 PY

@@ -73,4 +73,4 @@ if cc and kt:
                     f"-> {busy * clk / 2.4 * 100:5.1f} % of the 2.4 GHz peak")
             print(line); fo.write(line + "\n")
 PY
-find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete; du -sh $O | cut -f1
+find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +30M -delete; du -sh $O | cut -f1

@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-vqa-leg", action="store_true", help="skip the auxiliary 32-token-prompt measurement")
     ap.add_argument("--no-detect13-leg", action="store_true", help="skip the BASELINE configs[4]-shaped leg (768x1024 -> 13 crops, detect)")
     ap.add_argument("--detect13-batch", type=int, default=32, help="images per step of that leg (configs[4]: 256 over 8 GPUs)")
+    ap.add_argument("--w4-grid", type=int, default=0,
+                    help="persistent workgroups of the four-wave tile GEMM in the pipelined timed region (0 = one per CU): fewer leave "
+                         "whole CUs to the decode stream's kernels")
     ap.add_argument("--only-timed-steps", action="store_true",
                     help="exit after the timed region (rocprofv3 --pmc passes: exactly --steps steps of kernels in the trace)")
     ap.add_argument("--selftest-dist", action="store_true",
@@ -339,6 +342,8 @@ def main():
             outs = [finish(ids) for ids in gen]
         return outs
 
+    if args.w4_grid and not args.no_pipeline:
+        _lib.check(lib.md_gemm_set_tuning(b"w4_grid", args.w4_grid))
     if args.warmup:
         # pipelined mode alternates two KV slot groups: warm both (graph capture) before timing
         run_steps(args.warmup if args.no_pipeline else max(2, args.warmup))
@@ -349,6 +354,7 @@ def main():
     torch.cuda.synchronize()
     mdist.barrier()
     elapsed = time.perf_counter() - t0
+    _lib.check(lib.md_gemm_set_tuning(b"w4_grid", 0))
     per_rank_ms = mdist.gather_floats(elapsed / args.steps * 1e3, dev)  # every rank's own clock, on rank 0
     elapsed = mdist.max_over_ranks(elapsed, dev)
     ranks_seen = mdist.ranks_seen(dev)  # an RCCL all-reduce of ones: the ranks that really took part

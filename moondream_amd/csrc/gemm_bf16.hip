@@ -957,6 +957,7 @@ extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   else if (s == "decode_slices") k.decode_slices = value;
   else if (s == "w4_variant") md_gemm_w4_set_variant(value);
   else if (s == "rope_fuse") k.rope_fuse = value;
+  else if (s == "w4_grid") md_gemm_w4_set_grid(value);
   else return MD_ERR_INVALID_ARG;
   return MD_OK;
 }

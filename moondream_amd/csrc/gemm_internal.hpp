@@ -54,4 +54,5 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream);
 int md_gemm_w4_residual_max_cols();   // widest residual layer the four-wave kernel takes (its bias vector lives in LDS)
 int md_gemm_w4_max_cols(int epi);     // the same per epilogue kind (bias / GELU layers: 14336 columns)
 bool md_gemm_w4_takes(const GemmK& k, int epi);  // shape limits of the four-wave kernel for this launch
+void md_gemm_w4_set_grid(int v);     // persistent workgroups per launch of the four-wave kernel (0 = one per CU)
 void md_gemm_w4_set_variant(int v);  // measurement hook: schedule / ablation variant of the bias-epilogue kernel

@@ -373,18 +373,34 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     // eight passes of 32 rows x 64 columns (row block i, column half jp): bias add + ONE bf16 rounding on the
     // accumulator layout, transposition through the wave's 4 KiB LDS tile, then GELU / residual and the global
     // stores on whole 16-byte row pieces.  Piece q of this lane: row (q*64 + lane) >> 3, chunk (q*64 + lane) & 7.
+    // Piece q of this lane in pass (i, jp): row 32 i + 8 q + (lane >> 3), columns 64 jp + 8 (lane & 7) .. + 7.  Residual
+    // loads and result stores go through buffer resources over R and C (num_records = M rows): rows past M read as zero /
+    // are dropped by the range check, the address is one 32-bit offset per (i, q) -- a scalar multiple of the 8-row step
+    // added to the lane's base -- and the column half is an immediate (the per-piece m / n tests, 64-bit address arithmetic
+    // and exec-mask branches were ~600 of this epilogue's VALU instructions per tile).
+    const int lane_row = lane >> 3, lane_col = (lane & 7) * 8;
+    const __amdgpu_buffer_rsrc_t rsrc_cr = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)min((uint64_t)p.M * (uint64_t)p.ldc * 2, (uint64_t)0xffffffffu), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)p.R, 0, (int)min((uint64_t)(p.res_row_mod ? p.res_row_mod : p.M) * (uint64_t)p.ldr * 2, (uint64_t)0xffffffffu), 0x00020000);
+    const bool col_ok0 = wn0 + lane_col < p.n_store, col_ok1 = wn0 + 64 + lane_col < p.n_store;
+    const uint32_t col_bytes = (uint32_t)(wn0 + lane_col) * 2u;
+    const uint32_t c_base = (uint32_t)(wm0 + lane_row) * (uint32_t)(p.ldc * 2) + col_bytes;
+    const uint32_t c_step = (uint32_t)p.ldc * 16u;  // 8 rows
+    // residual row of this lane's first piece; a broadcast residual wraps at res_row_mod (>= 256: at most one wrap per tile)
+    const uint32_t wrap = p.res_row_mod ? (uint32_t)p.res_row_mod : 0x7fffffffu;
+    const uint32_t r_row0 = (uint32_t)(wm0 + lane_row) % wrap;
     auto load_residual = [&](int pass, u32x4 (&rv)[4]) {
       const int i = pass >> 1, jp = pass & 1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
-        const int m = wm0 + 32 * i + row, n = wn0 + 64 * jp + ch * 8;
-        rv[q] = u32x4{0, 0, 0, 0};
-        if (m < p.M && n < p.n_store) {
-          const int64_t rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
-          rv[q] = *(const u32x4*)(p.R + rrow * p.ldr + n);
-        }
+        uint32_t row = r_row0 + 8u * (uint32_t)(4 * i + q);
+        row -= (row >= wrap) ? wrap : 0u;
+        const uint32_t off = (jp ? col_ok1 : col_ok0) ? row * (uint32_t)(p.ldr * 2) + col_bytes : 0xfffff000u;
+        rv[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off + 128 * jp, 0, 0));
       }
+    };
+    auto store_off = [&](int i, int q, int jp) -> uint32_t {
+      const uint32_t off = c_base + (uint32_t)(4 * i + q) * c_step;
+      return ((jp ? col_ok1 : col_ok0) ? off : 0xfffff000u) + 128 * jp;  // columns past n_store (last column tile): out of range
     };
     u32x4 rres[2][4];
     if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
@@ -419,27 +435,16 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       MD_PIN();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
-        const int m = wm0 + 32 * i + row, n = wn0 + 64 * jp + ch * 8;
         u32x4 v = tv[q];
-        if (m < p.M && n < p.n_store) {
-          if constexpr (EPI == MD_EPI_GELU) {
-            if (n >= p.gelu_from) {
+        if constexpr (EPI == MD_EPI_RESIDUAL) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const md_f32x2 ge = gelu_tanh_f32x2(md_f32x2{lo_bf(v[e]), hi_bf(v[e])});
-                v[e] = pack_bf16x2(ge[0], ge[1]);
-              }
-            }
-          } else if constexpr (EPI == MD_EPI_RESIDUAL) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][q][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][q][e]) + hi_bf(v[e]));
-          }
-          if constexpr (ABL & 128) __builtin_nontemporal_store(v, (u32x4*)(p.C + (int64_t)m * p.ldc + n));
-          else if constexpr (!(ABL & 16)) *(u32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
-          else keep_alive(v);
+          for (int e = 0; e < 4; ++e)
+            v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][q][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][q][e]) + hi_bf(v[e]));
         }
+        const uint32_t off = store_off(i, q, jp);
+        if constexpr (ABL & 128) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_cr, off, 0, 2);
+        else if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_cr, off, 0, 0);
+        else keep_alive(v);
       }
       MD_PIN();
     });
@@ -629,6 +634,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   }
 }
 
+int g_w4_grid = 0;     // md_gemm_set_tuning "w4_grid": persistent workgroups per launch (0 = one per CU); a multiple of 8
 int g_w4_variant = 0;  // measurement hook (md_gemm_set_tuning "w4_variant"): 16 * ABL, bias epilogue only
 
 template <int EPI, int ABL = 0>
@@ -644,7 +650,9 @@ md_status launch(const GemmK& k, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? (n / 8) * 8 : 256;  // a multiple of 8 keeps (sequence number % 8) == XCD for the tile-order remap
   }();
-  const int gx = std::min(nwg, n_cu);  // one persistent workgroup per CU
+  // one persistent workgroup per CU -- or fewer ("w4_grid"): a workgroup owns its CU (156 KiB of LDS, the whole register file),
+  // so a smaller grid leaves whole CUs to kernels of another stream (the pipelined engine's decode steps)
+  const int gx = std::min(nwg, g_w4_grid > 0 ? std::min(g_w4_grid, n_cu) : n_cu);
   hipLaunchKernelGGL(fn, dim3(gx), dim3(256), LDS_BYTES, stream, kk);
   return md_launch_status();
 }
@@ -655,24 +663,28 @@ int md_gemm_w4_residual_max_cols() { return bias_max_cols<MD_EPI_RESIDUAL>(); }
 int md_gemm_w4_max_cols(int epi) { return epi == MD_EPI_RESIDUAL ? bias_max_cols<MD_EPI_RESIDUAL>() : bias_max_cols<MD_EPI_BIAS>(); }
 
 void md_gemm_w4_set_variant(int v) { g_w4_variant = v; }
+void md_gemm_w4_set_grid(int v) { g_w4_grid = v > 0 ? std::max(8, v / 8 * 8) : 0; }
 
 bool md_gemm_w4_takes(const GemmK& k, int epi) {
   if (k.K % 64 != 0 || k.M <= 0) return false;
+  // 32-bit byte offsets into A and W
   if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32)) return false;
+  // every epilogue takes its bias from the LDS-resident vector only (md_gemm_bf16 sends wider layers to the eight-wave kernel)
   if (k.n_pad > md_gemm_w4_max_cols(epi)) return false;
-  if (epi != MD_EPI_RESIDUAL && (uint64_t)k.M * (uint64_t)k.ldc * 2 >= 0xfffff000ull) return false;
+  // C (and a residual R) are addressed through buffer resources with 32-bit byte offsets: the rows of the last, partial
+  // row tile must stay below the out-of-range sentinel without wrapping
+  const uint64_t lim = 0xfffff000ull, rows = (uint64_t)k.M + 256;
+  if (rows * (uint64_t)k.ldc * 2 >= lim) return false;
+  if (epi == MD_EPI_RESIDUAL) {
+    if (k.res_row_mod != 0 && k.res_row_mod < 256) return false;  // a broadcast residual wraps at most once inside a tile
+    if ((k.res_row_mod ? (uint64_t)k.res_row_mod : rows) * (uint64_t)k.ldr * 2 >= lim) return false;
+  }
   return true;
 }
 
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   if (k.K % 64 != 0 || k.M <= 0) return MD_ERR_INVALID_ARG;
-  // 32-bit byte offsets into A and W
-  if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32))
-    return MD_ERR_UNSUPPORTED;
-  // every epilogue takes its bias from the LDS-resident vector only (md_gemm_bf16 sends wider layers to the eight-wave
-  // kernel); the bias / GELU epilogues address C with 32-bit byte offsets
-  if (k.n_pad > md_gemm_w4_max_cols(epi)) return MD_ERR_UNSUPPORTED;
-  if (epi != MD_EPI_RESIDUAL && (uint64_t)k.M * (uint64_t)k.ldc * 2 >= 0xfffff000ull) return MD_ERR_UNSUPPORTED;
+  if (!md_gemm_w4_takes(k, epi)) return MD_ERR_UNSUPPORTED;
 #ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
   if (epi == MD_EPI_BIAS && g_w4_variant != 0) {
     switch (g_w4_variant) {

@@ -842,6 +842,10 @@ def main():
         gen_bench64()
     if "detect13" in which:
         gen_detect13()
+    if "lora2b" in which:      # the side paths at the 2B shapes (tests/test_model_gpu.py::test_2b_lora_and_reasoning_vs_reference)
+        gen_lora("md2b_lora", "2b", n_cases=2, max_tokens=8, min_margin=0.7)
+    if "reasoning2b" in which:
+        gen_reasoning("md2b_reasoning", "2b", n_cases=2, max_tokens=6, min_margin=0.7)
     if "2b" in which:
         gen_model_case("md2b_seed1", "2b", 1, [(378, 378)], 32, False, n_images=3, min_margin=0.5)
 

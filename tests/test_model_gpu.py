@@ -764,6 +764,34 @@ def detect13_vs_reference(model, golden_dir):
     assert one["objects"][:k] == res[3]["objects"][:k]
 
 
+def side_paths_2b_vs_reference(model, cfg, golden_dir):
+    """The LoRA variant side path and query(..., reasoning=True) at the 2B shapes (tests/golden/md2b_lora.npz,
+    md2b_reasoning.npz: recorded from the reference's public API, every decision's reference margin >= 0.7, i.e. above
+    the measured-noise licence of the bench fixture): ids identical."""
+    g = load_golden(golden_dir, "md2b_lora.npz")
+    model.register_variant("synthetic", synth.synthetic_lora(cfg, seed=int(g["seed"]), rank=int(g["rank"]), device="cuda"))
+    images = []
+    for i in range(int(g["n_cases"])):
+        img = Image.fromarray(synth.synthetic_image_array(int(g[f"case{i}.image_index"]), int(g["seed"]), (378, 378)), "RGB")
+        images.append(img)
+        want = g[f"case{i}.tokens"].tolist()
+        got = model.caption(img, settings={"temperature": 0, "max_tokens": len(want), "variant": "synthetic"})["caption"]
+        assert [int(t) for t in got.split()] == want, (i, got, want, g[f"case{i}.margins"].min())
+    prompt = cfg.tokenizer.templates["caption"]["normal"]
+    n = len(g["case0.tokens"])
+    got = model.batch_generate_ids(images, [prompt] * len(images), max_tokens=n, variant="synthetic")
+    assert got == [g[f"case{i}.tokens"].tolist() for i in range(len(images))]
+    print(f"2b LoRA variant: {len(images)} captions x {n} tokens identical to the reference's (caption() and the batched engine)")
+    g = load_golden(golden_dir, "md2b_reasoning.npz")
+    for i in range(int(g["n_cases"])):
+        img = Image.fromarray(synth.synthetic_image_array(int(g[f"case{i}.image_index"]), int(g["seed"]), (378, 378)), "RGB")
+        res = model.query(img, "11 12 13", reasoning=True, settings={"temperature": 0, "max_tokens": int(g["max_tokens"])})
+        assert [int(t) for t in res["reasoning"]["text"].split()] == g[f"case{i}.reasoning_tokens"].tolist()
+        assert [int(t) for t in res["answer"].split()] == g[f"case{i}.answer_tokens"].tolist()
+        assert len(res["reasoning"]["grounding"]) == int(g[f"case{i}.n_grounding"])
+    print(f"2b reasoning query: {int(g['n_cases'])} cases identical to the reference's")
+
+
 def batch_equals_sequential_unfiltered(model, imgs64, prompt, got64_default, ref_ids, ref_margins, thr):
     """test_batch_equals_sequential_unfiltered (run inside the 2B test: one 2B model per session).  The 64 UNFILTERED bench
     images, Moondream-2B, 32 greedy tokens.
@@ -868,6 +896,7 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
             assert got64[i] == gb["tokens"][i].tolist(), i
     batch_equals_sequential_unfiltered(model, imgs64, pr, got64, ref_ids, gb["margins"], rep["parity_threshold"])
     detect13_vs_reference(model, golden_dir)
+    side_paths_2b_vs_reference(model, cfg, golden_dir)
     # opt-in FP8 weight stream for the decode steps of the same configuration (BASELINE configs[4]): a different
     # numerical mode, judged by tolerance against the bf16 path -- never by bit parity
     fp8_decode_report(model, imgs64, [pr] * 64, got64, gb["margins"], "2b B=64")

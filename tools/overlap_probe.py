@@ -25,25 +25,29 @@ def run_b(st, reps):
 def wall(fn):
     torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize(); return (time.perf_counter() - t) * 1e3
 RA, RB = 60, 1200
+GRIDS = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 run_a(E, 3); run_b(D, 10)
-ta = wall(lambda: run_a(E, RA)); tb = wall(lambda: run_b(D, RB))
-def both():
-    run_b(D, RB); run_a(E, RA)
-tab = wall(both)
-print(f"GEMM stream alone {ta:.1f} ms | decode-attn stream alone {tb:.1f} ms | both streams {tab:.1f} ms (serial sum {ta+tb:.1f}, perfect overlap {max(ta,tb):.1f})")
-# same with a hipGraph of the decode-like work (graph launch on D)
-g = torch.cuda.CUDAGraph()
-with torch.cuda.stream(D):
-    run_b(D, 5)
-torch.cuda.synchronize()
-with torch.cuda.graph(g):
-    cur = torch.cuda.current_stream()
-    for _ in range(100):
-        _lib.check(lib.md_attention_decode(q.data_ptr(), q.stride(0), o.data_ptr(), h * 64, kk.data_ptr(), vv.data_ptr(), h * ctx * 64, ctx, lens.data_ptr(), b, h, h, 64, 0.125, C.c_void_p(cur.cuda_stream)))
-def gboth():
+for grid in GRIDS:
+    lib.md_gemm_set_tuning(b"w4_grid", grid)
+    print(f"-- four-wave GEMM grid = {grid or 'one per CU'}")
+    ta = wall(lambda: run_a(E, RA)); tb = wall(lambda: run_b(D, RB))
+    def both():
+        run_b(D, RB); run_a(E, RA)
+    tab = wall(both)
+    print(f"GEMM stream alone {ta:.1f} ms | decode-attn stream alone {tb:.1f} ms | both streams {tab:.1f} ms (serial sum {ta+tb:.1f}, perfect overlap {max(ta,tb):.1f})")
+    # same with a hipGraph of the decode-like work (graph launch on D)
+    g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(D):
-        for _ in range(RB // 100): g.replay()
-    run_a(E, RA)
-tg = wall(lambda: [g.replay() for _ in range(RB // 100)])
-tgb = wall(gboth)
-print(f"graph(decode-attn) alone {tg:.1f} ms | graph on D + GEMMs on E {tgb:.1f} ms")
+        run_b(D, 5)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        cur = torch.cuda.current_stream()
+        for _ in range(100):
+            _lib.check(lib.md_attention_decode(q.data_ptr(), q.stride(0), o.data_ptr(), h * 64, kk.data_ptr(), vv.data_ptr(), h * ctx * 64, ctx, lens.data_ptr(), b, h, h, 64, 0.125, C.c_void_p(cur.cuda_stream)))
+    def gboth():
+        with torch.cuda.stream(D):
+            for _ in range(RB // 100): g.replay()
+        run_a(E, RA)
+    tg = wall(lambda: [g.replay() for _ in range(RB // 100)])
+    tgb = wall(gboth)
+    print(f"graph(decode-attn) alone {tg:.1f} ms | graph on D + GEMMs on E {tgb:.1f} ms")

@@ -4,7 +4,7 @@ GPU, ViT in groups of 128 crops) and on square problems, random operands.  Every
 `rounds` times in ONE process, round-robin, and the median is printed (run-to-run noise of a single
 timing is ~3 %, cdna guide 5.4 rule 24).
 
-    python tools/sweep_gemm.py [tiles=20,11,15] [rounds=3] [zero=0]
+    python tools/sweep_gemm.py [tiles=20,11,15] [rounds=3] [zero=0] [epi=2]
 """
 import ctypes as C
 import math
@@ -24,6 +24,7 @@ opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 TILES = [int(t) for t in opts.get("tiles", "20,11,15").split(",")]
 ROUNDS = int(opts.get("rounds", "3"))
 ZERO = opts.get("zero", "0") == "1"
+ONLY_EPI = int(opts["epi"]) if "epi" in opts else None  # epi=2: residual layers only
 
 # (m, k, n, epilogue, label): the layers of one B=64 step
 SHAPES = [
@@ -55,6 +56,8 @@ def timeit(fn, iters=6, warm=2):
 def main():
     total = {t: [0.0, 0.0] for t in TILES}
     for m, k, n, epi, label in SHAPES:
+        if ONLY_EPI is not None and epi != ONLY_EPI:
+            continue
         kp = (k + 63) // 64 * 64
         a = (torch.randn(m, kp, device="cuda") * 0.5).to(BF16)
         if kp > k:

@@ -604,7 +604,17 @@ constexpr int DEC_MAX_CTX = 2048;
 // rotated k and v at slot pos = kv_len - 1 of the slab (moondream.py:74-78) and treats
 // that newest key from LDS -- one launch instead of rope_kv_kernel + attention, same
 // arithmetic (bf16-rounded rotated values), MHA only.
-template <bool FUSED, int NW>
+// NT: the K / V rows are requested with non-temporal loads.  A large batch's step reads every live cache row exactly once
+// and nothing of it again before ~10 GB of other traffic has passed, so keeping the rows in the caches only evicts what
+// could be reused; tools/probes/hbm_read_probe.hip: a 2048-workgroup streaming read runs at 5.7 TB/s with plain loads (this
+// kernel: 5.6) and at 6.3 TB/s with non-temporal ones.  MHA only (with grouped heads a row is read by several workgroups).
+template <bool NT>
+__device__ __forceinline__ u32x4 load_kv_row(const bf16_t* p) {
+  if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)p);
+  else return *(const u32x4*)p;
+}
+
+template <bool FUSED, int NW, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                               bf16_t* __restrict__ o, int64_t ldo,
                                                               bf16_t* __restrict__ kslab,
@@ -681,14 +691,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
 #pragma unroll
       for (int u = 0; u < CPT; ++u) {
         const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
-        kq[r][u] = *(const u32x4*)(kb + (int64_t)min(j, pos) * 64 + c * 8);
+        kq[r][u] = load_kv_row<NT>(kb + (int64_t)min(j, pos) * 64 + c * 8);
       }
     if constexpr (VPRE > 0) {
       if (i0 == 0) {
 #pragma unroll
         for (int r = 0; r < VPRE; ++r) {
           const int j = 128 * r + 32 * u0 + res;
-          vpre[r] = *(const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 8);
+          vpre[r] = load_kv_row<NT>(vb + (int64_t)min(j, pos) * 64 + c * 8);
         }
       }
     }
@@ -738,7 +748,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
           const int j = 128 * (i0 + r) + 32 * (u0 + u) + res;
-          vq[r][u] = *(const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 8);
+          vq[r][u] = load_kv_row<NT>(vb + (int64_t)min(j, pos) * 64 + c * 8);
         }
     }
 #pragma unroll
@@ -788,6 +798,10 @@ int decode_attn_waves(int batch, int n_heads) {
   static const int forced = [] { const char* e = getenv("MD_ATTN_DECODE_NW"); return e ? atoi(e) : 0; }();
   if (forced == 4 || forced == 16) return forced;
   return ((long)batch * n_heads <= 512) ? 16 : 4;
+}
+bool decode_attn_nt() {  // MD_ATTN_DECODE_NT=0: plain loads (A/B)
+  static const bool on = [] { const char* e = getenv("MD_ATTN_DECODE_NT"); return !e || atoi(e) != 0; }();
+  return on;
 }
 
 }  // namespace
@@ -862,6 +876,10 @@ extern "C" md_status md_attention_decode(const void* q, int64_t ldq, void* o, in
                        (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
                        slab_batch_stride, ctx, kv_len, n_heads, n_heads / n_kv_heads,
                        scale * 1.4426950408889634f, (const float*)nullptr, 0);
+  else if (n_heads == n_kv_heads && decode_attn_nt())
+    hipLaunchKernelGGL((attn_decode_kernel<false, 4, true>), dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                       slab_batch_stride, ctx, kv_len, n_heads, 1, scale * 1.4426950408889634f, (const float*)nullptr, 0);
   else
     hipLaunchKernelGGL((attn_decode_kernel<false, 4>), dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)q, ldq, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
@@ -881,6 +899,10 @@ extern "C" md_status md_attention_decode_rope(const void* qkv, int64_t ld, void*
   MD_CHECK_ARG(ld >= 3 * n_heads * 64 && ldo >= n_heads * 64);
   if (decode_attn_waves(batch, n_heads) == 16)
     hipLaunchKernelGGL((attn_decode_kernel<true, 16>), dim3(n_heads, batch), dim3(1024), 0, (hipStream_t)stream,
+                       (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
+                       slab_batch_stride, ctx, kv_len, n_heads, 1, scale * 1.4426950408889634f, freqs, rot_dim);
+  else if (decode_attn_nt())
+    hipLaunchKernelGGL((attn_decode_kernel<true, 4, true>), dim3(n_heads, batch), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, (bf16_t*)k_slab, (bf16_t*)v_slab,
                        slab_batch_stride, ctx, kv_len, n_heads, 1, scale * 1.4426950408889634f, freqs, rot_dim);
   else

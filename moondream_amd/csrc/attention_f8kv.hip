@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_decode_f8_kernel(const bf16_t* __res
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = 64 * (i0 + u) + 16 * wave + g;
-      kq[u] = *(const u32x4*)(kb + (int64_t)min(j, pos) * 64 + c * 16);
+      kq[u] = __builtin_nontemporal_load((const u32x4*)(kb + (int64_t)min(j, pos) * 64 + c * 16));  // read once per step (attention.hip: NT)
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_decode_f8_kernel(const bf16_t* __res
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = 64 * (i0 + u) + 16 * wave + g;
-      vq[u] = *(const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 16);
+      vq[u] = __builtin_nontemporal_load((const u32x4*)(vb + (int64_t)min(j, pos) * 64 + c * 16));
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {

@@ -1,0 +1,88 @@
+// Probe: what read bandwidth does HBM deliver to a plain streaming kernel on this box?  The ceiling the decode-step
+// attention (5.6 TB/s) and the decode-regime weight streams are judged against.  A 4 GiB buffer (16x the Infinity Cache)
+// is read once per launch with 16-byte loads, U loads in flight per thread, in three launch shapes.
+// Build: hipcc --offload-arch=gfx950 -O3 hbm_read_probe.hip -o hbm_read_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// MODE 0: plain loads, 1: non-temporal loads
+template <int U, int MODE>
+__global__ __launch_bounds__(256) void stream_read(const u32x4* __restrict__ src, size_t n16, unsigned* sink) {
+  u32x4 acc = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (U - 1) * stride < n16; i += U * stride) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = MODE ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= v[u];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
+// contiguous chunk per workgroup (what the attention kernel's (sequence, head) slabs look like): each workgroup streams
+// its own `chunk16` 16-byte pieces front to back
+template <int U>
+__global__ __launch_bounds__(256) void chunk_read(const u32x4* __restrict__ src, size_t chunk16, unsigned* sink) {
+  u32x4 acc = {0, 0, 0, 0};
+  const u32x4* p = src + (size_t)blockIdx.x * chunk16;
+  for (size_t i = threadIdx.x; i + (U - 1) * 256 < chunk16; i += U * 256) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = p[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= v[u];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
+template <class F>
+static double time_ms(F&& launch, int reps) {
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  launch(); hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int r = 0; r < reps; ++r) launch();
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms = 0; hipEventElapsedTime(&ms, a, b);
+  return ms / reps;
+}
+
+int main() {
+  const size_t bytes = 4ull << 30, n16 = bytes / 16;
+  u32x4* src; unsigned* sink;
+  if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipMemset(src, 1, bytes); hipDeviceSynchronize();
+  auto run = [&](const char* label, auto&& launch) {
+    double ms = time_ms(launch, 5);
+    printf("%-58s %8.3f ms  %6.2f TB/s\n", label, ms, bytes / ms / 1e9);
+  };
+  for (int wgs : {256 * 4, 256 * 8, 256 * 16, 256 * 64}) {
+    char l[96];
+    snprintf(l, 96, "grid-stride, %5d workgroups, 4 loads in flight", wgs);
+    run(l, [&] { hipLaunchKernelGGL((stream_read<4, 0>), dim3(wgs), dim3(256), 0, 0, src, n16, sink); });
+    snprintf(l, 96, "grid-stride, %5d workgroups, 8 loads in flight", wgs);
+    run(l, [&] { hipLaunchKernelGGL((stream_read<8, 0>), dim3(wgs), dim3(256), 0, 0, src, n16, sink); });
+    snprintf(l, 96, "grid-stride, %5d workgroups, 8 non-temporal loads", wgs);
+    run(l, [&] { hipLaunchKernelGGL((stream_read<8, 1>), dim3(wgs), dim3(256), 0, 0, src, n16, sink); });
+  }
+  // chunked: chunk sizes like one (sequence, head) K or V slab at ~750 positions (96 KiB) and larger
+  for (size_t chunk : {96ull << 10, 384ull << 10, 2048ull << 10}) {
+    const int wgs = (int)(bytes / chunk);
+    char l[96];
+    snprintf(l, 96, "contiguous %4zu KiB per workgroup (%6d wgs), 4 in flight", chunk >> 10, wgs);
+    run(l, [&] { hipLaunchKernelGGL((chunk_read<4>), dim3(wgs), dim3(256), 0, 0, src, chunk / 16, sink); });
+    snprintf(l, 96, "contiguous %4zu KiB per workgroup (%6d wgs), 8 in flight", chunk >> 10, wgs);
+    run(l, [&] { hipLaunchKernelGGL((chunk_read<8>), dim3(wgs), dim3(256), 0, 0, src, chunk / 16, sink); });
+  }
+  // short launches of the size of one decode-attention launch (394 MB): launch ramp included
+  {
+    const size_t small = 394ull << 20;
+    double ms = time_ms([&] { hipLaunchKernelGGL((stream_read<8, 0>), dim3(256 * 16), dim3(256), 0, 0, src, small / 16, sink); }, 20);
+    printf("%-58s %8.3f ms  %6.2f TB/s\n", "394 MiB per launch (one decode-attention launch's bytes)", ms, small / ms / 1e9);
+  }
+  return 0;
+}

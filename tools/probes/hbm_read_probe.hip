@@ -78,11 +78,20 @@ int main() {
     snprintf(l, 96, "contiguous %4zu KiB per workgroup (%6d wgs), 8 in flight", chunk >> 10, wgs);
     run(l, [&] { hipLaunchKernelGGL((chunk_read<8>), dim3(wgs), dim3(256), 0, 0, src, chunk / 16, sink); });
   }
-  // short launches of the size of one decode-attention launch (394 MB): launch ramp included
-  {
-    const size_t small = 394ull << 20;
-    double ms = time_ms([&] { hipLaunchKernelGGL((stream_read<8, 0>), dim3(256 * 16), dim3(256), 0, 0, src, small / 16, sink); }, 20);
-    printf("%-58s %8.3f ms  %6.2f TB/s\n", "394 MiB per launch (one decode-attention launch's bytes)", ms, small / ms / 1e9);
+  // short launches: the bytes of one decode-attention launch (394 MB) and of the decode step's weight streams (qkv|fc1
+  // 58.7 MB, proj+fc2 41.9 MB, lm_head 210 MB), back to back on one stream: launch ramp and drain included.  A rotating
+  // offset keeps every launch out of the Infinity Cache.
+  for (size_t small : {394ull << 20, 210ull << 20, 59ull << 20, 42ull << 20}) {
+    for (int wgs : {256, 512, 1024, 2048, 4096}) {
+      size_t off = 0;
+      auto launch_nt = [&] {
+        hipLaunchKernelGGL((stream_read<8, 1>), dim3(wgs), dim3(256), 0, 0, src + off / 16, small / 16, sink);
+        off = (off + small) % (bytes - small);
+        off &= ~(size_t)4095;
+      };
+      double ms = time_ms(launch_nt, 40);
+      printf("%4zu MiB per launch, %5d workgroups, 8 non-temporal loads:  %7.1f us  %6.2f TB/s\n", small >> 20, wgs, ms * 1e3, small / ms / 1e9);
+    }
   }
   return 0;
 }

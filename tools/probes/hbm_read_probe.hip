@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256) void chunk_read(const u32x4* __restrict__ src,
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
 
+// one panel per workgroup, `stride16` pieces apart, `panel16` pieces long, read front to back with U non-temporal loads in flight
+template <int U>
+__global__ __launch_bounds__(256) void panel_read(const u32x4* __restrict__ src, size_t stride16, size_t panel16, unsigned* sink) {
+  u32x4 acc = {0, 0, 0, 0};
+  const u32x4* p = src + (size_t)blockIdx.x * stride16;
+  for (size_t i = threadIdx.x; i + (U - 1) * 256 < panel16; i += U * 256) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= v[u];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
 template <class F>
 static double time_ms(F&& launch, int reps) {
   hipEvent_t a, b;
@@ -91,6 +106,22 @@ int main() {
       };
       double ms = time_ms(launch_nt, 40);
       printf("%4zu MiB per launch, %5d workgroups, 8 non-temporal loads:  %7.1f us  %6.2f TB/s\n", small >> 20, wgs, ms * 1e3, small / ms / 1e9);
+    }
+  }
+  // the decode-regime weight stream's shape: 224 workgroups, each streaming its own panel front to back, panels 2^18 bytes
+  // apart (64 columns x 2048 k x 2 B) -- against the same with padded / odd panel strides: channel aliasing of lockstep streams?
+  for (size_t stride : {262144ull, 262144ull + 256, 262144ull + 1024, 262144ull + 4096, 262144ull + 16384 + 256, 1048576ull, 1048576ull + 4352}) {
+    for (int wgs : {224, 448}) {
+      const size_t panel = (stride >= 1048576ull ? 1048576ull : 262144ull) * 224 / wgs;  // bytes each workgroup reads
+      size_t off = 0;
+      const size_t span = stride * wgs;
+      auto launch_p = [&] {
+        hipLaunchKernelGGL((panel_read<8>), dim3(wgs), dim3(256), 0, 0, src + off / 16, stride / 16, panel / 16, sink);
+        off = (off + span + 4096) % (bytes - span - 4096);
+        off &= ~(size_t)4095;
+      };
+      double ms = time_ms(launch_p, 40);
+      printf("panel stream: %4d workgroups x %4zu KiB, panel stride %8zu B:  %7.1f us  %6.2f TB/s\n", wgs, panel >> 10, stride, ms * 1e3, panel * wgs / ms / 1e9);
     }
   }
   return 0;

@@ -485,30 +485,10 @@ class MoondreamModel:
         crop bytes on the host."""
         v = self.config.vision
         n_img = len(images)
-        pool = self._crop_pool()
-        per_chunk = max(1, self.vit_chunk_crops // 2)  # images per ViT launch group (2 crops each at 378 x 378; more for large images)
-        counts = [crop_count(im.size[1], im.size[0], v.overlap_margin, v.max_crops, (v.crop_size, v.crop_size), v.enc_patch_size)
-                  for im in images]
+        pre = getattr(self, "_prefetched_crops", {}).pop(tuple(id(im) for im in images), None)
+        chunks, staged = pre[1] if pre is not None else self._stage_crops(images)
         cropped: List[Tuple[np.ndarray, Tuple[int, int]]] = []
         feat_parts = []
-        # chunks: consecutive images whose crops total <= vit_chunk_crops (at least one image)
-        chunks, i0 = [], 0
-        while i0 < n_img:
-            i1, tot = i0, 0
-            while i1 < n_img and (i1 == i0 or (tot + counts[i1][0] <= max(self.vit_chunk_crops, 1) and i1 - i0 < per_chunk * 8)):
-                tot += counts[i1][0]
-                i1 += 1
-            chunks.append((i0, i1, tot))
-            i0 = i1
-        staged = []
-        for (c0, c1, tot) in chunks:  # all host work is queued up front; the GPU side follows chunk by chunk
-            host, token = self._pinned_crops(tot, (v.crop_size, v.crop_size, 3))
-            futs, off = [], 0
-            for i in range(c0, c1):
-                n = counts[i][0]
-                futs.append(pool.submit(self._crop_into, images[i], host[off : off + n]))
-                off += n
-            staged.append((host, token, futs))
         for ci, ((c0, c1, tot), (host, token, futs)) in enumerate(zip(chunks, staged)):
             part = [f.result() for f in futs]
             if mark is not None and ci == 0:
@@ -569,6 +549,74 @@ class MoondreamModel:
                 out[torch.tensor(idxs, device=self._device)] = o
         return out
 
+    def _stage_crops(self, images: Sequence[Image.Image], pool=None):
+        """Queue the host tiling of a batch on the thread pool, chunk by chunk, each image cutting its crops into its
+        slice of a pinned staging buffer.  Returns (chunks, staged) for ``_run_vision_encoder_batch``."""
+        v = self.config.vision
+        n_img = len(images)
+        pool = pool or self._crop_pool()
+        per_chunk = max(1, self.vit_chunk_crops // 2)  # images per ViT launch group (2 crops each at 378 x 378; more for large images)
+        counts = [crop_count(im.size[1], im.size[0], v.overlap_margin, v.max_crops, (v.crop_size, v.crop_size), v.enc_patch_size)
+                  for im in images]
+        # chunks: consecutive images whose crops total <= vit_chunk_crops (at least one image)
+        chunks, i0 = [], 0
+        while i0 < n_img:
+            i1, tot = i0, 0
+            while i1 < n_img and (i1 == i0 or (tot + counts[i1][0] <= max(self.vit_chunk_crops, 1) and i1 - i0 < per_chunk * 8)):
+                tot += counts[i1][0]
+                i1 += 1
+            chunks.append((i0, i1, tot))
+            i0 = i1
+        staged = []
+        for (c0, c1, tot) in chunks:  # all host work is queued up front; the GPU side follows chunk by chunk
+            host, token = self._pinned_crops(tot, (v.crop_size, v.crop_size, 3))
+            futs, off = [], 0
+            for i in range(c0, c1):
+                n = counts[i][0]
+                futs.append(pool.submit(self._crop_into, images[i], host[off : off + n]))
+                off += n
+            staged.append((host, token, futs))
+        return chunks, staged
+
+    def prefetch_crops(self, images: Sequence[Image.Image]) -> None:
+        """Start the host tiling of a batch NOW (thread pool, pinned staging buffers) so that a later call that encodes
+        exactly these image objects -- ``batch_detect``, ``batch_generate_ids``, ... -- finds its crops cut: a serving
+        loop calls this for batch k+1 before it runs batch k, which hides the PIL resize of large images behind the
+        GPU (the pipelined caption engine does the same by construction).  Results are identical."""
+        if not hasattr(self, "_prefetched_crops"):
+            self._prefetched_crops = {}
+        images = list(images)  # (kept alive with the entry: the key is made of object identities)
+        key = tuple(id(im) for im in images)
+        if key in self._prefetched_crops:
+            return
+        while len(self._prefetched_crops) >= 2:  # the batch about to run + one ahead
+            self.discard_prefetched_crops(next(iter(self._prefetched_crops)))
+        # a FEW background workers: the step that is running needs the host for its own launches, and the tiling of one
+        # batch (tens of ms of CPU per large image) has a whole step's GPU time to finish
+        pool = getattr(self, "_prefetch_pool", None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            pool = self._prefetch_pool = ThreadPoolExecutor(max_workers=max(1, int(self.prefetch_workers)))
+        self._prefetched_crops[key] = (images, self._stage_crops(images, pool))
+
+    def wait_prefetched_crops(self) -> None:
+        """Block until every prefetched batch's crops are cut (tests, benchmarks: a steady-state serving loop never waits)."""
+        for _, (_, staged) in getattr(self, "_prefetched_crops", {}).values():
+            for _, _, futs in staged:
+                for f in futs:
+                    f.result()
+
+    def discard_prefetched_crops(self, key=None) -> None:
+        """Drop prefetched batches that were never encoded (waits for their workers, returns the pinned buffers)."""
+        d = getattr(self, "_prefetched_crops", {})
+        for k in ([key] if key is not None else list(d)):
+            _, (_, staged) = d.pop(k)
+            for host, token, futs in staged:
+                for f in futs:
+                    f.result()
+                self._release_pinned(token)
+
     def _crop_into(self, image: Image.Image, out: np.ndarray):
         v = self.config.vision
         arr = np.asarray(image.convert("RGB"))
@@ -615,6 +663,8 @@ class MoondreamModel:
 
     def _release_pinned(self, token: int):
         self._pinned["busy"][token] = False
+
+    prefetch_workers = 4
 
     def _crop_pool(self):
         pool = getattr(self, "_pool", None)

@@ -512,6 +512,28 @@ def test_batch_generate_strings_ragged_equals_sequential(tiny):
     assert caps == model.batch_caption(images[:3], "normal", {"max_tokens": 8})
 
 
+def test_prefetched_crops_are_used_and_identical(tiny):
+    """prefetch_crops: the host tiling of a batch started ahead of the call that encodes it -- same ids, the entry is
+    consumed, at most two batches are held, unused ones can be dropped."""
+    g, cfg, sd, model = tiny
+    images = [golden_image(g, i) for i in range(3)]
+    prompts = [cfg.tokenizer.templates["caption"]["normal"]] * 3
+    base = model.batch_generate_ids(images, prompts, max_tokens=6)
+    model.prefetch_crops(images)
+    assert len(model._prefetched_crops) == 1
+    assert model.batch_generate_ids(images, prompts, max_tokens=6) == base
+    assert not model._prefetched_crops
+    model.prefetch_crops(images)
+    model.prefetch_crops(list(images))  # the same image objects: one entry
+    assert len(model._prefetched_crops) == 1
+    for _ in range(3):
+        model.prefetch_crops([im.copy() for im in images])
+    assert len(model._prefetched_crops) == 2
+    model.discard_prefetched_crops()
+    assert not model._prefetched_crops
+    assert model.batch_generate_ids(images, prompts, max_tokens=6) == base
+
+
 def test_mixed_encoded_and_raw_images_in_one_batch(tiny):
     """an EncodedImage next to raw PIL images must keep its own KV slot."""
     g, cfg, sd, model = tiny

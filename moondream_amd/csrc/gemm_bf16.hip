@@ -129,7 +129,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
   constexpr int KSTEPS = BKT / 16;            // MFMA K-steps per slice
   static_assert(BKT == 64 || BKT == 32, "slice width");
   constexpr int CT = WM * WN * 64;       // threads that compute
-  constexpr int NT = CT + XW * 64;       // threads that move data
+  constexpr int NT = XW > 0 ? XW * 64 : CT;  // threads that move data: the helper waves when there are any (round 3: the compute
+                                             // waves' share of the LDS-DMA issue, ~40 cycles per K-step, sat on their MFMA chain while the
+                                             // helpers idled ~400 cycles per slice at the barrier), else every wave
   static_assert(XW == 0 || PP == 0, "helper waves: lockstep schedule only");
   constexpr int TM = BM / WM, TN = BN / WN;
   static_assert(TN == 64, "epilogue transposes 32 x 64 wave tiles");
@@ -145,6 +147,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_compute = (XW == 0) || wave < WM * WN;  // wave-uniform
+  const bool is_dma = (XW == 0) || !is_compute;
+  const int dtid = XW > 0 ? max(tid - CT, 0) : tid;      // index among the data-moving threads
+  const int dwave = XW > 0 ? max(wave - WM * WN, 0) : wave;
   const int wm = wave / WN, wn = wave % WN;
   const int hi = lane >> 5, l31 = lane & 31;
 
@@ -171,13 +176,13 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
     n0 = tn * BN;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
+      const int slot = j * NT + dtid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
       const int64_t row = min(m0 + r, p.M - 1);
       a_src[j] = (const char*)(p.A + row * p.lda + c * 8);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int slot = j * NT + tid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
+      const int slot = j * NT + dtid, r = slot >> CH_SHIFT, c = (slot & (CH - 1)) ^ ((r >> (4 - CH_SHIFT)) & (CH - 1));
       const int64_t row = min(n0 + r, p.n_pad - 1);
       b_src[j] = (const char*)(p.W + row * p.ldw + c * 8);
     }
@@ -190,20 +195,17 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
   // one 16-byte-per-lane LDS-DMA piece (1 KiB per wave) of slice `stage`
   auto issue_piece = [&](auto piece_c, int stage) {
     constexpr int P = decltype(piece_c)::value;
-    char* base = smem + stage * STAGE + wave * (64 * 16);
+    char* base = smem + stage * STAGE + dwave * (64 * 16);
     if constexpr (P < NA) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_src[P],
                                        (__attribute__((address_space(3))) void*)(base + P * NT * 16), 16, 0, 0);
       a_src[P] += ROW_BYTES;
     } else {
       constexpr int Q = P - NA;
-      if (BM == 64 && p.nt) {  // decode regime: every weight byte is read once by one CU
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[Q],
-                                         (__attribute__((address_space(3))) void*)(base + A_BYTES + Q * NT * 16), 16, 0, 2);
-      } else {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[Q],
-                                         (__attribute__((address_space(3))) void*)(base + A_BYTES + Q * NT * 16), 16, 0, 0);
-      }
+      // (a non-temporal policy on the decode regime's weight stream was a runtime choice until round 3: it never changed
+      // a step time, and the branch per piece sat in the loop)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[Q],
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + Q * NT * 16), 16, 0, 0);
       b_src[Q] += ROW_BYTES;
     }
   };
@@ -325,14 +327,21 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
     // prologue: slices 0 .. STAGES-2 in flight
     static_for<0, STAGES - 1>([&](auto sc) {
       constexpr int SL = decltype(sc)::value;
-      if (SL < nk) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, SL); });
+      if (SL < nk && is_dma) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, SL); });
     });
-    for (int t = 0; t < nk; ++t) {
+    // One iteration of the ring.  STEADY (compile time): slice t + STAGES - 1 exists and STAGES - 2 younger slices are in
+    // flight -- no per-piece "is there a next slice" test, one fixed vmcnt: the steady-state loop carries no scalar branches
+    // (a taken branch costs a wave ~16-20 cycles; the general form has ~15 of them per 64-wide slice, which at 8 MFMAs per
+    // slice was a third of the decode-regime kernels' loop time).
+    auto ring_iteration = [&](int t, auto steady_c) {
+      constexpr bool STEADY = decltype(steady_c)::value;
       // slice t has landed: own DMA by a COUNTED vmcnt (the min(STAGES-2, nk-1-t)
       // younger slices stay in flight), everybody's by the barrier, which also fences
       // the previous iteration's reads of the ring slot refilled during this one
       if constexpr (STAGES == 2) {
         wait_vm<0>();
+      } else if constexpr (STEADY) {
+        wait_vm<(STAGES - 2) * (NA + NB)>();
       } else {
         const int ahead = min(STAGES - 2, nk - 1 - t);
         static_for<0, STAGES - 1>([&](auto ac) {
@@ -345,12 +354,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const bool has_next = t + STAGES - 1 < nk;
+      const bool has_next = STEADY || (t + STAGES - 1 < nk);
       const int nstage = (t + STAGES - 1) % STAGES;
       if constexpr (XW > 0) {
         if (!is_compute) {  // DMA-only wave: its pieces of slice t+STAGES-1, then the next barrier
           if (has_next) static_for<0, NA + NB>([&](auto pc) { issue_piece(pc, nstage); });
-          continue;
+          return;
         }
       }
       // LDS -> register fragments, software pipelined by hand: the six ds_read_b128 of
@@ -391,7 +400,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
           static_for<0, PPS>([&](auto qc) {
             constexpr int Q = decltype(qc)::value, P = S + KSTEPS * Q;
             // slot Q of this step sits behind MFMA number Q * (MI*NI) / PPS
-            if constexpr ((Q * MI * NI) / PPS == Mx && P < NA + NB) {
+            if constexpr (XW == 0 && (Q * MI * NI) / PPS == Mx && P < NA + NB) {  // (with helper waves the compute waves move nothing)
               __builtin_amdgcn_sched_barrier(0);
               if (has_next) issue_piece(std::integral_constant<int, P>{}, nstage);
               __builtin_amdgcn_sched_barrier(0);
@@ -400,7 +409,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
         });
         __builtin_amdgcn_sched_barrier(0);
       });
-    }
+    };
+    const int n_steady = max(0, nk - (STAGES - 1));
+    for (int t = 0; t < n_steady; ++t) ring_iteration(t, std::true_type{});
+    for (int t = n_steady; t < nk; ++t) ring_iteration(t, std::false_type{});
   }
 
   if constexpr (SPLITK) {

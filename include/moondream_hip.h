@@ -278,6 +278,12 @@ typedef struct {
   const int32_t* kv_len;
   int32_t prefix_len; /* bidirectional prefix; >= kv_len disables the causal rule */
   float scale;        /* 1/sqrt(head_dim) */
+  /* opt-in FP8 mode (md_gemm_f8's A operand), trailing since ABI 3: when o8 != NULL the output row is ALSO written as OCP
+   * e4m3 bytes -- element (b, t, h, d) at o8 + b * o8_bs + t * o8_ts + h * head_dim + d, the value being the bf16-rounded
+   * output times o8_inv_scale, exactly what md_quantize_f8 makes of the bf16 output -- and o may then be NULL */
+  void* o8;
+  int64_t o8_bs, o8_ts; /* bytes */
+  float o8_inv_scale;
 } md_attn_args;
 
 md_status md_attention_prefill(const md_attn_args* args, void* stream);

@@ -52,6 +52,7 @@ class MdAttnArgs(C.Structure):
         ("batch", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32),
         ("q_len", c_int32), ("kv_len_all", c_int32), ("q_pos0", c_void_p), ("kv_len", c_void_p),
         ("prefix_len", c_int32), ("scale", c_float),
+        ("o8", c_void_p), ("o8_bs", c_int64), ("o8_ts", c_int64), ("o8_inv_scale", c_float),
     ]
 
 

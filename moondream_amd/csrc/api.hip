@@ -241,7 +241,7 @@ extern "C" md_status md_vit_encode(const md_vit_model* m, const void* crops, int
   if (use_f8) MD_CHECK_ARG(m->blocks[0].fc1.n_pad >= Dp);
   for (int l = 0; l < m->n_layers; ++l) {
     const md_vit_block& b = m->blocks[l];
-    md_attn_args a;
+    md_attn_args a = {};
     const bf16_t* qkv = (const bf16_t*)w.qkv;
     a.q = qkv;
     a.k = qkv + D;
@@ -267,8 +267,18 @@ extern "C" md_status md_vit_encode(const md_vit_model* m, const void* crops, int
       MD_CHECK_ARG(f8_scales_ok(q.s_ln1, q.s_att, q.s_ln2, q.s_ff) && q.fc2.k_pad == q.fc1.n_pad && q.qkv.k_pad == Dp);
       MD_TRY(md_layernorm_f8(w.x, D, h8, Dp, &b.ln1, M, D, Dp, 1e-5f, 1.0f / q.s_ln1, s));
       MD_TRY(gemm_f8(h8, Dp, q.s_ln1, q.qkv, w.qkv, 3 * D, M, MD_EPI_BIAS, nullptr, 0, 0, 0, s));
-      MD_TRY(md_attention_prefill(&a, s));
-      MD_TRY(md_quantize_f8(w.h, Dp, h8, Dp, M, D, Dp, 1.0f / q.s_att, s));
+      if (Dp == D) {  // the attention epilogue writes proj's e4m3 operand itself (h8 holds ln1's output until the qkv GEMM has read it)
+        md_attn_args a8 = a;
+        a8.o = nullptr;
+        a8.o8 = h8;
+        a8.o8_bs = (int64_t)T * Dp;
+        a8.o8_ts = Dp;
+        a8.o8_inv_scale = 1.0f / q.s_att;
+        MD_TRY(md_attention_prefill(&a8, s));
+      } else {
+        MD_TRY(md_attention_prefill(&a, s));
+        MD_TRY(md_quantize_f8(w.h, Dp, h8, Dp, M, D, Dp, 1.0f / q.s_att, s));
+      }
       MD_TRY(gemm_f8(h8, Dp, q.s_att, q.proj, w.x, D, M, MD_EPI_RESIDUAL, w.x, D, 0, 0, s));
       MD_TRY(md_layernorm_f8(w.x, D, h8, Dp, &b.ln2, M, D, Dp, 1e-5f, 1.0f / q.s_ln2, s));
       MD_TRY(gemm_f8(h8, Dp, q.s_ln2, q.fc1, nullptr, 0, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, ff8, q.fc1.n_pad, q.s_ff, 0, 0));
@@ -435,7 +445,7 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
   bool rope_done = false;  // set per block when the fused launch took it
 
   // rope(q), rope(k), cache update (text.py:42-46) and attention over the slab (text.py:48-51) of block l
-  auto rope_and_attention = [&](int l, int64_t qld, bool fuse_rope) -> md_status {
+  auto rope_and_attention = [&](int l, int64_t qld, bool fuse_rope, uint8_t* att8 = nullptr, float att8_inv_scale = 0.f) -> md_status {
     bf16_t* kl = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
     bf16_t* vl = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
     if (!fuse_rope && !rope_done)
@@ -455,7 +465,7 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       MD_TRY(md_attention_decode(w.qkv, qld, w.att, Dp, kl, vl, kv->batch_stride, kv->ctx, kv_len, batch,
                                  m->n_heads, m->n_kv_heads, hd, scale, s));
     } else {
-      md_attn_args a;
+      md_attn_args a = {};
       a.q = w.qkv;
       a.q_bs = (int64_t)q_len * qld;
       a.q_ts = qld;
@@ -479,6 +489,13 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       a.kv_len = kv_len;
       a.prefix_len = m->prefix_len;
       a.scale = scale;
+      if (att8 != nullptr) {  // fp8 mode: proj reads e4m3 rows only -- written by the attention epilogue, no bf16 copy, no quantise pass
+        a.o = nullptr;
+        a.o8 = att8;
+        a.o8_bs = (int64_t)q_len * Dp;
+        a.o8_ts = Dp;
+        a.o8_inv_scale = att8_inv_scale;
+      }
       MD_TRY(md_attention_prefill(&a, s));
     }
     // fp8 mode: the rows this pass wrote (bf16) also go into the e4m3 copy the decode steps read
@@ -504,8 +521,12 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       uint8_t* ff8 = (uint8_t*)w.qkv + (size_t)qkv_w * 2;
       MD_TRY(md_layernorm_f8(x, D, h8, Dp, &b.ln, M, D, Dp, 1e-5f, 1.0f / q.s_ln, s));
       MD_TRY(gemm_f8(h8, Dp, q.s_ln, q.qkv_fc1, w.qkv, qld, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, ff8, qld * 2, q.s_ff, qkv_w, qkv_w));
-      MD_TRY(rope_and_attention(l, qld, false));
-      MD_TRY(md_quantize_f8(w.att, Dp, h8, Dp, M, D, Dp, 1.0f / q.s_att, s));
+      if (q_len > 1 && Dp == D) {
+        MD_TRY(rope_and_attention(l, qld, false, h8, 1.0f / q.s_att));
+      } else {
+        MD_TRY(rope_and_attention(l, qld, false));
+        MD_TRY(md_quantize_f8(w.att, Dp, h8, Dp, M, D, Dp, 1.0f / q.s_att, s));
+      }
       MD_TRY(gemm_f8(h8, Dp, q.s_att, q.proj, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
       MD_TRY(gemm_f8(ff8, qld * 2, q.s_ff, q.fc2, x, D, M, MD_EPI_RESIDUAL, x, D, 0, 0, s));
       continue;
@@ -653,7 +674,7 @@ extern "C" md_status md_text_forward_lora(const md_text_model* m, const md_text_
       MD_TRY(md_attention_decode(w.qkv, qkv_w, w.att, D, kl, vl, kv->batch_stride, kv->ctx, kv_len, batch, m->n_heads,
                                  m->n_kv_heads, hd, scale, s));
     } else {
-      md_attn_args a;
+      md_attn_args a = {};
       a.q = w.qkv; a.q_bs = (int64_t)q_len * qkv_w; a.q_ts = qkv_w; a.q_hs = hd;
       a.k = kl; a.v = vl; a.k_bs = a.v_bs = kv->batch_stride; a.k_ts = a.v_ts = hd; a.k_hs = a.v_hs = (int64_t)kv->ctx * hd;
       a.o = w.att; a.o_bs = (int64_t)q_len * D; a.o_ts = D; a.o_hs = hd;

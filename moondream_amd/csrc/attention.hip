@@ -40,6 +40,10 @@ struct AttnK {
   const int32_t* kv_len;
   float scale_log2;  // scale * log2(e)
   int n_qblk, n_bh, n_heads;  // XCD-aware 1-D grid of the LDS-DMA kernels
+  uint8_t* o8;                // opt-in FP8 mode: the output row as e4m3 bytes as well (md_attn_args.o8), or nullptr
+  int64_t o8_bs, o8_ts;
+  float o8_inv_scale;
+  int head_dim;
 };
 
 template <int HD>
@@ -272,11 +276,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnK p) {
       }
     }
   bf16_t* obase = p.o + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs;
+  uint8_t* o8base = p.o8 + (int64_t)b * p.o8_bs + (int64_t)h * HD;
   for (int idx = lane; idx < 32 * C::CPR; idx += 64) {
     const int row = idx / C::CPR, ch = idx % C::CPR;
     if (q_row0 + row < p.q_len) {
       const u32x4 v = *(const u32x4*)(ot + row * C::KSTR * 2 + ch * 16);
-      *(u32x4*)(obase + (int64_t)(q_row0 + row) * p.o_ts + ch * 8) = v;
+      if (p.o != nullptr) *(u32x4*)(obase + (int64_t)(q_row0 + row) * p.o_ts + ch * 8) = v;
+      if (p.o8 != nullptr) *(u32x2*)(o8base + (int64_t)(q_row0 + row) * p.o8_ts + ch * 8) = quant8(v, p.o8_inv_scale);
     }
   }
 }
@@ -574,11 +580,13 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
       }
     }
   bf16_t* obase = p.o + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs;
+  uint8_t* o8base = p.o8 + (int64_t)b * p.o8_bs + (int64_t)h * HD;
   for (int idx = lane; idx < 32 * C::CPR; idx += 64) {
     const int row = idx / C::CPR, ch = idx % C::CPR;
     if (q_row0 + row < p.q_len) {
       const u32x4 v = *(const u32x4*)(ot + row * C::OSTR * 2 + ch * 16);
-      *(u32x4*)(obase + (int64_t)(q_row0 + row) * p.o_ts + ch * 8) = v;
+      if (p.o != nullptr) *(u32x4*)(obase + (int64_t)(q_row0 + row) * p.o_ts + ch * 8) = v;
+      if (p.o8 != nullptr) *(u32x2*)(o8base + (int64_t)(q_row0 + row) * p.o8_ts + ch * 8) = quant8(v, p.o8_inv_scale);
     }
   }
 }
@@ -807,7 +815,7 @@ bool decode_attn_nt() {  // MD_ATTN_DECODE_NT=0: plain loads (A/B)
 }  // namespace
 
 extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
-  MD_CHECK_ARG(a && a->q && a->k && a->v && a->o);
+  MD_CHECK_ARG(a && a->q && a->k && a->v && (a->o || a->o8));
   MD_CHECK_ARG(a->batch > 0 && a->n_heads > 0 && a->n_kv_heads > 0 && a->q_len > 0);
   MD_CHECK_ARG(a->n_heads % a->n_kv_heads == 0);
   MD_CHECK_ARG(a->head_dim == 64 || a->head_dim == 72);
@@ -815,6 +823,9 @@ extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
                              a->v_bs, a->v_ts, a->v_hs, a->o_bs, a->o_ts, a->o_hs};
   for (int64_t s : strides) MD_CHECK_ARG(s % 8 == 0);
   MD_CHECK_ARG((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o) & 15) == 0);
+  if (a->o8 != nullptr)
+    MD_CHECK_ARG(((uintptr_t)a->o8 & 7) == 0 && a->o8_bs % 8 == 0 && a->o8_ts % 8 == 0 && a->o8_ts >= (int64_t)a->n_heads * a->head_dim &&
+                 a->o8_inv_scale > 0.f);
   AttnK k;
   k.q = (const bf16_t*)a->q;
   k.k = (const bf16_t*)a->k;
@@ -831,6 +842,11 @@ extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
   k.q_pos0 = a->q_pos0;
   k.kv_len = a->kv_len;
   k.scale_log2 = a->scale * 1.4426950408889634f;
+  k.o8 = (uint8_t*)a->o8;
+  k.o8_bs = a->o8_bs;
+  k.o8_ts = a->o8_ts;
+  k.o8_inv_scale = a->o8_inv_scale;
+  k.head_dim = a->head_dim;
   dim3 grid((a->q_len + 127) / 128, a->n_heads, a->batch);
   k.n_qblk = (a->q_len + 127) / 128;
   k.n_bh = a->batch * a->n_heads;

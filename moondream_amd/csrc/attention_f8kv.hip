@@ -19,16 +19,6 @@ namespace {
 
 constexpr int F8_MAX_CTX = 2048;
 
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-  const float lim = 448.0f;
-  a = __builtin_amdgcn_fmed3f(a, -lim, lim);
-  b = __builtin_amdgcn_fmed3f(b, -lim, lim);
-  c = __builtin_amdgcn_fmed3f(c, -lim, lim);
-  d = __builtin_amdgcn_fmed3f(d, -lim, lim);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (uint32_t)w;
-}
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 // 16 e4m3 bytes -> 16 floats
 __device__ __forceinline__ void unpack16(const u32x4& w, float (&f)[16]) {

@@ -82,16 +82,6 @@ __device__ __forceinline__ i32x8 join(const u32x4& lo, const u32x4& hi) {
   return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 }
 // 8 bf16 (as fp32 pairs) -> 8 e4m3fn bytes, saturating at +-448
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-  const float lim = 448.0f;
-  a = __builtin_amdgcn_fmed3f(a, -lim, lim);
-  b = __builtin_amdgcn_fmed3f(b, -lim, lim);
-  c = __builtin_amdgcn_fmed3f(c, -lim, lim);
-  d = __builtin_amdgcn_fmed3f(d, -lim, lim);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (uint32_t)w;
-}
 
 template <int EPI>
 __global__ __launch_bounds__(NT) void gemm_f8_kernel(const F8K p) {

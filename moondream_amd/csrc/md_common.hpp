@@ -92,6 +92,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// bf16 -> OCP e4m3 (the opt-in FP8 mode's activation producers: quant_f8.hip, the prefill attention's fp8 output)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  const float lim = 448.0f;  // e4m3fn's largest finite value; saturate instead of producing NaN
+  a = __builtin_amdgcn_fmed3f(a, -lim, lim);
+  b = __builtin_amdgcn_fmed3f(b, -lim, lim);
+  c = __builtin_amdgcn_fmed3f(c, -lim, lim);
+  d = __builtin_amdgcn_fmed3f(d, -lim, lim);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+__device__ __forceinline__ u32x2 quant8(const u32x4& q, float s) {
+  u32x2 o;
+  o[0] = pack_fp8x4(lo_bf(q[0]) * s, hi_bf(q[0]) * s, lo_bf(q[1]) * s, hi_bf(q[1]) * s);
+  o[1] = pack_fp8x4(lo_bf(q[2]) * s, hi_bf(q[2]) * s, lo_bf(q[3]) * s, hi_bf(q[3]) * s);
+  return o;
+}
+
 // XCD-aware remap of a linear workgroup id: hardware places block b on XCD b % 8,
 // so give every XCD a contiguous chunk of the logical tile sequence (neighbouring
 // tiles share operand panels -> hit the same private L2).  Bijective for any n.

@@ -7,23 +7,6 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-  const float lim = 448.0f;  // e4m3fn's largest finite value; saturate instead of producing NaN
-  a = __builtin_amdgcn_fmed3f(a, -lim, lim);
-  b = __builtin_amdgcn_fmed3f(b, -lim, lim);
-  c = __builtin_amdgcn_fmed3f(c, -lim, lim);
-  d = __builtin_amdgcn_fmed3f(d, -lim, lim);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (uint32_t)w;
-}
-__device__ __forceinline__ u32x2 quant8(const u32x4& q, float s) {
-  u32x2 o;
-  o[0] = pack_fp8x4(lo_bf(q[0]) * s, hi_bf(q[0]) * s, lo_bf(q[1]) * s, hi_bf(q[1]) * s);
-  o[1] = pack_fp8x4(lo_bf(q[2]) * s, hi_bf(q[2]) * s, lo_bf(q[3]) * s, hi_bf(q[3]) * s);
-  return o;
-}
-
 // one 8-element chunk (16 B in, 8 B out) per thread, grid-stride over rows x chunks
 __global__ __launch_bounds__(256) void quantize_f8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ y, int64_t ldy,
                                                           int rows, int nch, int nch_pad, float inv_scale) {

@@ -426,16 +426,18 @@ def ref_attention(q, k, v, allowed, scale):
     return ((p.to(BF16).float() @ v.float()) / l).to(BF16)
 
 
-def run_prefill(lib, q, k, v, q_len, kv_len, prefix, pos0=None, kv_lens=None):
-    """q [B,Tq,H,d]; k,v [B,H,Tk,d] (slab layout)."""
+def run_prefill(lib, q, k, v, q_len, kv_len, prefix, pos0=None, kv_lens=None, o8=None, o8_inv_scale=1.0, bf16_out=True):
+    """q [B,Tq,H,d]; k,v [B,H,Tk,d] (slab layout).  o8: uint8 [B,Tq,H*d] for the e4m3 copy of the output."""
     b, tq, h, d = q.shape
     tk = k.shape[2]
     o = torch.full((b, tq, h * d), float("nan"), dtype=BF16, device="cuda")
     a = _lib.MdAttnArgs()
+    if o8 is not None:
+        a.o8, a.o8_bs, a.o8_ts, a.o8_inv_scale = o8.data_ptr(), tq * h * d, h * d, o8_inv_scale
     a.q, a.q_bs, a.q_ts, a.q_hs = q.data_ptr(), tq * h * d, h * d, d
     a.k, a.k_bs, a.k_ts, a.k_hs = k.data_ptr(), h * tk * d, d, tk * d
     a.v, a.v_bs, a.v_ts, a.v_hs = v.data_ptr(), h * tk * d, d, tk * d
-    a.o, a.o_bs, a.o_ts, a.o_hs = o.data_ptr(), tq * h * d, h * d, d
+    a.o, a.o_bs, a.o_ts, a.o_hs = (o.data_ptr() if bf16_out else None), tq * h * d, h * d, d
     a.batch, a.n_heads, a.n_kv_heads, a.head_dim = b, h, h, d
     a.q_len, a.kv_len_all = q_len, kv_len
     a.q_pos0 = pos0.data_ptr() if pos0 is not None else None
@@ -453,6 +455,26 @@ def test_attention_no_mask(lib, hd, t):
     o = run_prefill(lib, q, k, v, t, t, prefix=t)
     ref = ref_attention(q.permute(0, 2, 1, 3), k, v, None, 1 / math.sqrt(hd)).permute(0, 2, 1, 3)
     compare(f"attn hd{hd} t{t}", o, ref, 6e-3, 4e-2)
+
+
+@pytest.mark.parametrize("hd,t", [(72, 729), (64, 730), (64, 77)])
+def test_attention_prefill_e4m3_output_equals_quantise_pass(lib, hd, t):
+    """md_attn_args.o8 (opt-in FP8 mode): the e4m3 copy written by the attention epilogue is bit-identical to md_quantize_f8
+    of the bf16 output, with and without the bf16 output itself."""
+    b, h = 2, 4
+    q, k, v = randn(b, t, h, hd, seed=20), randn(b, h, t, hd, seed=21), randn(b, h, t, hd, seed=22)
+    inv = 1.0 / 0.013
+    o = run_prefill(lib, q, k, v, t, t, prefix=t)
+    want = torch.zeros(b * t, h * hd, dtype=torch.uint8, device="cuda")
+    o2 = o.reshape(b * t, h * hd)
+    _lib.check(lib.md_quantize_f8(o2.data_ptr(), h * hd, want.data_ptr(), h * hd, b * t, h * hd, h * hd, inv, stream()))
+    for bf16_out in (True, False):
+        got = torch.full((b, t, h * hd), 0x7F, dtype=torch.uint8, device="cuda")
+        o_b = run_prefill(lib, q, k, v, t, t, prefix=t, o8=got, o8_inv_scale=inv, bf16_out=bf16_out)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(b * t, h * hd), want), bf16_out
+        if bf16_out:
+            assert torch.equal(o_b, o)
 
 
 def test_attention_spiky_scores_force_rescale(lib):

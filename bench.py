@@ -664,7 +664,7 @@ def main():
                 "calibration": {"images": 8, "margin": info["margin"], "vit_amax_max": max(info["vit_amax"]), "text_amax_max": max(info["text_amax"])},
                 "note": "md_gemm_f8: OCP e4m3 operands on v_mfma_f32_32x32x64_f8f6f4, fp32 accumulation, per-channel weight scales, one "
                         "static scale per activation tensor; LN -> fp8, GELU epilogue -> fp8, attention epilogue -> fp8 (md_attn_args.o8); "
-                        "patch embedding, prefill attention, RoPE, residual stream and lm_head at prefill stay bf16; decode "
+                        "RoPE + K/V (bf16 and e4m3) written by the qkv GEMM epilogue; patch embedding, prefill attention, residual stream and lm_head at prefill stay bf16; decode "
                         "steps stream e4m3 weights (the fp8_decode leg's mode) and attend over an e4m3 copy of the KV cache (one static "
                         "scale per layer for K and V; the bf16 slabs stay for prefill attention and EncodedImage snapshots)",
             }

@@ -443,6 +443,7 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
     hipLaunchKernelGGL(rope_rowinfo_kernel, dim3((M + 7) / 8), dim3(256), 0, s, pos0, m->freqs, w.rope_cs, w.rope_kv, q_len, M,
                        kv->batch_stride, hd, m->rot_dim);
   bool rope_done = false;  // set per block when the fused launch took it
+  bool rope_done_kv8 = false;  // ... and also wrote the e4m3 copy of the rows (fp8 mode)
 
   // rope(q), rope(k), cache update (text.py:42-46) and attention over the slab (text.py:48-51) of block l
   auto rope_and_attention = [&](int l, int64_t qld, bool fuse_rope, uint8_t* att8 = nullptr, float att8_inv_scale = 0.f) -> md_status {
@@ -499,7 +500,7 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       MD_TRY(md_attention_prefill(&a, s));
     }
     // fp8 mode: the rows this pass wrote (bf16) also go into the e4m3 copy the decode steps read
-    if (kv8 && !fuse_rope) MD_TRY(md_kv_quantize_f8_layer(kv, l, pos0, 0, batch, m->n_heads, q_len, s));
+    if (kv8 && !fuse_rope && !rope_done_kv8) MD_TRY(md_kv_quantize_f8_layer(kv, l, pos0, 0, batch, m->n_heads, q_len, s));
     return MD_OK;
   };
 
@@ -520,7 +521,37 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       uint8_t* h8 = (uint8_t*)w.h;
       uint8_t* ff8 = (uint8_t*)w.qkv + (size_t)qkv_w * 2;
       MD_TRY(md_layernorm_f8(x, D, h8, Dp, &b.ln, M, D, Dp, 1e-5f, 1.0f / q.s_ln, s));
-      MD_TRY(gemm_f8(h8, Dp, q.s_ln, q.qkv_fc1, w.qkv, qld, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, ff8, qld * 2, q.s_ff, qkv_w, qkv_w));
+      // [qkv | gelu(fc1) -> e4m3]; with per-row positions at hand the epilogue also rotates q / k and writes k / v to the
+      // slab and to its e4m3 copy (MD_EPI_QKV_ROPE, as the bf16 kernel does): no rope_kv_kernel, no kv-quantise pass
+      rope_done = rope_done_kv8 = false;
+      if (rope_in_gemm) {
+        md_gemm_f8_args g;
+        g.a = h8; g.lda = Dp; g.a_scale = q.s_ln; g.lin = q.qkv_fc1; g.c = w.qkv; g.ldc = qld;
+        g.c8 = ff8; g.ldc8 = qld * 2; g.c8_inv_scale = 1.0f / q.s_ff; g.f8_from_col = qkv_w;
+        g.r = nullptr; g.ldr = 0; g.res_row_mod = 0; g.m = M; g.epilogue = MD_EPI_GELU; g.store_pad_cols = 1; g.gelu_from_col = qkv_w;
+        md_rope_fuse rf;
+        rf.row_cs = w.rope_cs; rf.row_kv = w.rope_kv;
+        rf.kslab = (bf16_t*)kv->k + (int64_t)l * kv->layer_stride;
+        rf.vslab = (bf16_t*)kv->v + (int64_t)l * kv->layer_stride;
+        rf.slab_bytes = slab_bytes; rf.n_heads = m->n_heads; rf.ctx = kv->ctx;
+        md_rope_fuse_f8 rf8 = {nullptr, nullptr, 1.f, 1.f};
+        const bool has8 = kv->k8 && kv->v8 && kv->k_scale && kv->v_scale;
+        if (has8) {
+          rf8.k8slab = (uint8_t*)kv->k8 + (int64_t)l * kv->layer_stride;
+          rf8.v8slab = (uint8_t*)kv->v8 + (int64_t)l * kv->layer_stride;
+          rf8.k_scale = kv->k_scale[l];
+          rf8.v_scale = kv->v_scale[l];
+        }
+        const md_status fs = md_gemm_f8_qkv_rope(&g, &rf, &rf8, s);
+        if (fs == MD_OK) {
+          rope_done = true;
+          rope_done_kv8 = has8;
+        } else if (fs != MD_ERR_UNSUPPORTED) {
+          return fs;
+        }
+      }
+      if (!rope_done)
+        MD_TRY(gemm_f8(h8, Dp, q.s_ln, q.qkv_fc1, w.qkv, qld, M, MD_EPI_GELU, nullptr, 0, 0, 1, s, ff8, qld * 2, q.s_ff, qkv_w, qkv_w));
       if (q_len > 1 && Dp == D) {
         MD_TRY(rope_and_attention(l, qld, false, h8, 1.0f / q.s_att));
       } else {

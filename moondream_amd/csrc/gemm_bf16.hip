@@ -956,6 +956,8 @@ extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32
   return TICKET_BYTES + tiles * sl * decode_slab_floats() * sizeof(float);
 }
 
+bool md_gemm_knob_rope_fuse() { return knobs().rope_fuse != 0; }
+
 extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   MD_CHECK_ARG(key != nullptr);
   Knobs& k = knobs();

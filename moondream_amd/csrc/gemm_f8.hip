@@ -21,7 +21,7 @@
 //     residual on 16-byte row pieces; columns >= f8_from_col can be stored as fp8 (the next GEMM's operand) instead.
 // At full matrix rate a CU would need 64 B / clk of operands through its vector-memory path (twice the bf16
 // kernel's demand for the same tile): this kernel is bound by data movement, not by the matrix pipe.
-#include "md_common.hpp"
+#include "gemm_internal.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -51,6 +51,14 @@ struct F8K {
   float a_scale, c8_inv_scale;
   int M, n_store, n_pad, K;
   int tiles_m, tiles_n, res_row_mod, group_m, gelu_from, f8_from;
+  // MD_EPI_QKV_ROPE (the decoder's fused [q | k | v | fc1] layer at prefill): per-row (cos, sin) rows and slab byte offsets
+  // (rope_rowinfo_kernel), the layer's bf16 K / V slabs and -- optionally -- their e4m3 copies with the layer's inverse scales
+  const float* rope_cs;
+  const uint32_t* rope_kv;
+  bf16_t *kslab, *vslab;
+  uint8_t *k8slab, *v8slab;
+  float k8_inv, v8_inv;
+  int rope_d, rope_ctx;
 };
 
 template <int I, int N, class F>
@@ -69,6 +77,9 @@ __device__ __forceinline__ void ds_write_b64_asm(uint32_t addr, u32x2 v) {
 }
 __device__ __forceinline__ void ds_read_b128_plain(u32x4& dst, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void ds_read_b64_plain(u32x2& dst, uint32_t addr) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_lgkm() {
@@ -266,6 +277,59 @@ __global__ __launch_bounds__(NT) void gemm_f8_kernel(const F8K p) {
           const int ch = 4 * j + g;
           ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, w);
         }
+      if constexpr (EPI == MD_EPI_QKV_ROPE) {
+        // q / k / v sections: a wave's 64 columns are ONE head.  Features 0..31 are rotated: the reference reads them
+        // half-split (re = x[d], im = x[16 + d]) and writes them interleaved (rope.py:37-46), so output chunk ch < 4 (features
+        // 8 ch .. 8 ch + 7 = pairs d = 4 ch .. 4 ch + 3) needs the two 8-byte halves x[4 ch ..] and x[16 + 4 ch ..] of the
+        // transposed row -- two ds_read_b64 instead of one b128; chunks 4..7 and the v section pass through.  fp32 arithmetic on
+        // the bf16-rounded layer output with separately rounded products (md_rope_pair), bit-equal to rope_kv_kernel.  q
+        // stays in the activation, k / v go to the bf16 slab and, when the cache has one, to its e4m3 copy (text.py:45-46).
+        const int sec = wn0 / p.rope_d;  // 0 q, 1 k, 2 v, >= 3: fc1 columns   (wave-uniform)
+        if (sec < 3) {
+          const int head = (wn0 - sec * p.rope_d) >> 6;
+          u32x2 ta[4], tb[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+            const bool rot = sec != 2 && ch < 4;
+            const int ca = rot ? (ch >> 1) : ch, cb = rot ? 2 + (ch >> 1) : ch;
+            const int ha = rot ? (ch & 1) : 0, hb = rot ? (ch & 1) : 1;
+            ds_read_b64_plain(ta[q], tile_lds + row * 128 + ((ca ^ (row & 7)) * 16) + ha * 8);
+            ds_read_b64_plain(tb[q], tile_lds + row * 128 + ((cb ^ (row & 7)) * 16) + hb * 8);
+          }
+          wait_lgkm<0>();
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+            const int m = m0c + wm * TM + 32 * i + row;
+            if (m >= p.M) continue;
+            u32x4 v = {ta[q][0], ta[q][1], tb[q][0], tb[q][1]};
+            if (sec != 2 && ch < 4) {
+              const f32x4* cp = (const f32x4*)(p.rope_cs + (int64_t)m * 32 + 8 * ch);  // (cos, sin) of pairs 4 ch .. 4 ch + 3
+              const f32x4 c0 = cp[0], c1 = cp[1];
+              const float re[4] = {lo_bf(ta[q][0]), hi_bf(ta[q][0]), lo_bf(ta[q][1]), hi_bf(ta[q][1])};
+              const float im[4] = {lo_bf(tb[q][0]), hi_bf(tb[q][0]), lo_bf(tb[q][1]), hi_bf(tb[q][1])};
+              const float cs[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {c0[1], c0[3], c1[1], c1[3]};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float o_re, o_im;
+                md_rope_pair(re[e], im[e], cs[e], sn[e], o_re, o_im);
+                v[e] = pack_bf16x2(o_re, o_im);
+              }
+            }
+            if (sec == 0) {
+              *(u32x4*)(p.C + (int64_t)m * p.ldc + wn0 + ch * 8) = v;
+            } else {
+              const uint32_t off = p.rope_kv[m] + (uint32_t)head * (uint32_t)p.rope_ctx * 128u + (uint32_t)ch * 16u;  // bytes in the bf16 slab
+              *(u32x4*)((char*)(sec == 1 ? p.kslab : p.vslab) + off) = v;
+              uint8_t* s8 = sec == 1 ? p.k8slab : p.v8slab;
+              if (s8 != nullptr) *(u32x2*)(s8 + (off >> 1)) = quant8(v, sec == 1 ? p.k8_inv : p.v8_inv);
+            }
+          }
+          continue;
+        }
+      }
       u32x4 tv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {  // same-wave LDS operations execute in order: the reads see the writes above
@@ -281,7 +345,7 @@ __global__ __launch_bounds__(NT) void gemm_f8_kernel(const F8K p) {
         const int m = m0c + wm * TM + 32 * i + row;
         const int n = wn0 + ch * 8;
         if (m < p.M && n < p.n_store) {
-          if constexpr (EPI == MD_EPI_GELU) {
+          if constexpr (EPI == MD_EPI_GELU || EPI == MD_EPI_QKV_ROPE) {
             if (n >= p.gelu_from) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -329,7 +393,8 @@ md_status launch(const F8K& k, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" md_status md_gemm_f8(const md_gemm_f8_args* a, void* stream) {
+namespace {
+md_status gemm_f8_dispatch(const md_gemm_f8_args* a, void* stream, const md_rope_fuse* rf, const md_rope_fuse_f8* rf8) {
   MD_CHECK_ARG(a && a->a && a->lin.w && a->lin.scale && a->m > 0 && a->lin.n > 0 && a->lin.k > 0);
   MD_CHECK_ARG(a->lin.k_pad % 64 == 0 && a->lin.k_pad >= a->lin.k && a->lin.n_pad % 64 == 0 && a->lin.n_pad >= a->lin.n);
   MD_CHECK_ARG(a->lda % 16 == 0 && a->lda >= a->lin.k_pad);
@@ -368,7 +433,26 @@ extern "C" md_status md_gemm_f8(const md_gemm_f8_args* a, void* stream) {
   k.group_m = 8;
   k.gelu_from = a->gelu_from_col;
   k.f8_from = a->c8 ? a->f8_from_col : 0;
+  k.rope_cs = nullptr; k.rope_kv = nullptr; k.kslab = k.vslab = nullptr; k.k8slab = k.v8slab = nullptr;
+  k.k8_inv = k.v8_inv = 1.f; k.rope_d = 1 << 30; k.rope_ctx = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (rf != nullptr) {
+    if (!md_gemm_knob_rope_fuse()) return MD_ERR_UNSUPPORTED;
+    // RoPE + KV write in the epilogue: [q | k | v] sections of n_heads x 64 columns ending where the GELU (= fp8) columns start
+    const int D = rf->n_heads * 64;
+    if (a->epilogue != MD_EPI_GELU || a->gelu_from_col != 3 * D || a->c == nullptr || a->c8 == nullptr || a->f8_from_col != 3 * D ||
+        rf->slab_bytes >= 0xfffff000ull)
+      return MD_ERR_UNSUPPORTED;
+    k.rope_cs = rf->row_cs; k.rope_kv = rf->row_kv;
+    k.kslab = (bf16_t*)rf->kslab; k.vslab = (bf16_t*)rf->vslab;
+    k.rope_d = D; k.rope_ctx = rf->ctx;
+    if (rf8 != nullptr && rf8->k8slab != nullptr) {
+      if (!(rf8->k_scale > 0.f && rf8->v_scale > 0.f)) return MD_ERR_INVALID_ARG;
+      k.k8slab = (uint8_t*)rf8->k8slab; k.v8slab = (uint8_t*)rf8->v8slab;
+      k.k8_inv = 1.0f / rf8->k_scale; k.v8_inv = 1.0f / rf8->v_scale;
+    }
+    return launch<MD_EPI_QKV_ROPE>(k, s);
+  }
   switch (a->epilogue) {
     case MD_EPI_BIAS: return launch<MD_EPI_BIAS>(k, s);
     case MD_EPI_GELU: return launch<MD_EPI_GELU>(k, s);
@@ -377,4 +461,12 @@ extern "C" md_status md_gemm_f8(const md_gemm_f8_args* a, void* stream) {
       return launch<MD_EPI_RESIDUAL>(k, s);
     default: return MD_ERR_INVALID_ARG;
   }
+}
+}  // namespace
+
+extern "C" md_status md_gemm_f8(const md_gemm_f8_args* a, void* stream) { return gemm_f8_dispatch(a, stream, nullptr, nullptr); }
+
+md_status md_gemm_f8_qkv_rope(const md_gemm_f8_args* a, const md_rope_fuse* rf, const md_rope_fuse_f8* rf8, hipStream_t stream) {
+  if (rf == nullptr) return MD_ERR_INVALID_ARG;
+  return gemm_f8_dispatch(a, (void*)stream, rf, rf8);
 }

@@ -47,6 +47,14 @@ struct md_rope_fuse {
   int n_heads, ctx;
 };
 md_status md_gemm_qkv_rope(const md_gemm_args* a, const md_rope_fuse* rf, hipStream_t stream);
+// the same for the opt-in FP8 mode's tile GEMM (gemm_f8.hip); rf8 (or its slabs) may be null: no e4m3 copy of the cache
+struct md_rope_fuse_f8 {
+  void* k8slab;
+  void* v8slab;
+  float k_scale, v_scale;
+};
+bool md_gemm_knob_rope_fuse();  // MD_ROPE_FUSE / md_gemm_set_tuning("rope_fuse"): A/B and tests
+md_status md_gemm_f8_qkv_rope(const md_gemm_f8_args* a, const md_rope_fuse* rf, const md_rope_fuse_f8* rf8, hipStream_t stream);
 
 // gemm_w4.hip: the 256x256 tile kernel with one wave per SIMD (4 waves x 128x128), persistent.
 // epi = MD_EPI_*.  Fills tiles_m / tiles_n itself.

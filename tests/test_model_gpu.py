@@ -165,6 +165,34 @@ def test_rope_kv_write_in_gemm_epilogue_is_bit_identical(tiny):
         assert torch.equal(a, b), name
 
 
+def test_fp8_mode_rope_kv_write_in_gemm_epilogue_is_bit_identical(tiny):
+    """The same for the FP8 mode's tile GEMM (gemm_f8_kernel<MD_EPI_QKV_ROPE>): hidden states, the bf16 K / V rows AND their
+    e4m3 copies equal the three-kernel path's (GEMM, rope_kv_kernel, kv-quantise pass) bit for bit."""
+    g, cfg, sd, model = tiny
+    t = cfg.text
+    gen = torch.Generator().manual_seed(12)
+    x = (torch.randn(5, 735, t.dim, generator=gen) * 0.7).to(BF16).cuda()
+    model._ensure_batch(8)
+    model.enable_fp8([golden_image(g, i) for i in range(3)], kv_cache=True)
+    outs = []
+    try:
+        for fuse in (0, 1):
+            model.lib.md_gemm_set_tuning(b"rope_fuse", fuse)
+            with torch.inference_mode():
+                for buf in (model._kv_k, model._kv_v, model._kv_k8, model._kv_v8):
+                    buf[:, 2:7].zero_()
+                h = model._text_forward(x, [0, 3, 0, 1, 0], 2)
+                torch.cuda.synchronize()
+                outs.append((h.clone(), model._kv_k[:, 2:7, :, :740].clone(), model._kv_v[:, 2:7, :, :740].clone(),
+                             model._kv_k8[:, 2:7, :, :740].clone(), model._kv_v8[:, 2:7, :, :740].clone()))
+    finally:
+        model.lib.md_gemm_set_tuning(b"rope_fuse", 1)
+        model.enable_fp8(on=False)
+    assert float(outs[0][1].float().abs().sum()) > 0 and int((outs[0][3] != 0).sum()) > 0
+    for a, b, name in zip(outs[0], outs[1], ("hidden", "K slab", "V slab", "e4m3 K slab", "e4m3 V slab")):
+        assert torch.equal(a, b), name
+
+
 def test_dedup_identical_crops_is_bit_identical(tiny):
     """An image that fits one crop has a local crop equal to its global crop; with dedup_identical_crops the encoder
     runs once per distinct crop.  The projected embeddings must be the same bits as with both crops encoded, in a batch

@@ -158,8 +158,17 @@ def cpu_baseline(cfg, sd, seed, T, budget_s=25.0):
         t_pblock = timed(lambda: O.text_decoder(xp, w, cfg1, kv1, torch.arange(P), cos, sin, None, True))
         log(f"decoder block over the {P}-token prefill {t_pblock:.3f}s")
         xd = torch.randn(1, t.dim, generator=g).to(torch.bfloat16)
-        t_dblock = timed(lambda: O.text_decoder(xd, w, cfg1, kv1, torch.tensor([P + 5]), cos, sin, None, True), reps=4)
-        log(f"decoder block per decode step {t_dblock * 1e3:.1f}ms")
+        # the one-row decode step wants FEWER threads than the 1458-row ViT block (on a 256-core host 64 threads made a token
+        # 8x slower than the single-block prediction): its own probe
+        best_d = None
+        for nthreads in sorted({min(cores, c, threads) for c in (4, 8, 16, 32, 64)}):
+            torch.set_num_threads(nthreads)
+            td = timed(lambda: O.text_decoder(xd, w, cfg1, kv1, torch.tensor([P + 5]), cos, sin, None, True), reps=4)
+            log(f"decoder block per decode step, {nthreads} threads: {td * 1e3:.2f}ms")
+            if best_d is None or td < best_d[0]:
+                best_d = (td, nthreads)
+        t_dblock, dec_threads = best_d
+        torch.set_num_threads(threads)
     flop_vblock = 2 * (2 * v.n_patches * v.enc_dim * 3 * v.enc_dim + 2 * v.n_patches * v.enc_dim ** 2 + 4 * v.n_patches * v.enc_dim * v.enc_ff_dim)
     rate = flop_vblock / t_vblock  # GEMM rate of this host, for the three stand-alone linears below
     t_misc = (2 * v.n_patches * (2 * v.enc_dim * v.proj_inner_dim + v.proj_inner_dim * v.proj_out_dim) + 4 * v.n_patches * v.patch_dim * v.enc_dim) / rate
@@ -188,6 +197,7 @@ def cpu_baseline(cfg, sd, seed, T, budget_s=25.0):
             logits, _, pos = orc.prefill_prompt(prompt, pos, kv)
             t_prompt = time.perf_counter() - t0
             tok, steps = int(torch.argmax(logits.float())), []
+            torch.set_num_threads(dec_threads)
             for i in range(6):
                 t0 = time.perf_counter()
                 logits, _ = orc.decode_token(orc.embed([tok]), pos, kv)
@@ -196,7 +206,8 @@ def cpu_baseline(cfg, sd, seed, T, budget_s=25.0):
         t_enc, t_tok = enc[1], float(np.median(steps[1:]))
         est_total = t_enc + t_prompt + T * t_tok
         note = (f"WHOLE phases, B=1: encode_image {t_enc:.2f}s (2nd of 2 runs), {len(prompt)}-token prompt prefill {t_prompt:.2f}s, "
-                f"decode {t_tok * 1e3:.0f}ms/token (median of {len(steps) - 1}); images/s = 1 / (encode + prompt + {T} x token).  "
+                f"decode {t_tok * 1e3:.0f}ms/token (median of {len(steps) - 1}, {dec_threads} threads: the one-row step has its own "
+                f"thread-count probe); images/s = 1 / (encode + prompt + {T} x token).  "
                 f"[single-block prediction was: encode {est_enc:.2f}s, {est_tok * 1e3:.0f}ms/token]")
     else:
         log(f"whole phases would take ~{whole:.0f}s: reporting the per-block prediction")

@@ -1,0 +1,107 @@
+"""Host-side parity logic (moondream_amd/parity.py): the measured-noise licence for greedy ids and the margin-aware
+comparison of detect objects, on constructed cases and on the committed reference fixtures themselves."""
+import os
+
+import numpy as np
+
+from moondream_amd import parity as P
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _case(n=4, t=6, k=8, seed=0):
+    rng = np.random.default_rng(seed)
+    ref_ids = rng.integers(10, 1000, size=(n, t)).tolist()
+    margins = np.full((n, t + 1), 2.0, dtype=np.float32)
+    ref_topk = rng.normal(12.0, 2.0, size=(n, t + 1, k)).astype(np.float32)
+    return ref_ids, margins, ref_topk
+
+
+def test_identical_ids_and_small_logit_error_pass():
+    ref_ids, margins, ref_topk = _case()
+    got_topk = ref_topk + 0.0625
+    rep = P.parity_report([list(r) for r in ref_ids], ref_ids, margins, got_topk, ref_topk, tokens=6, min_exact=4)
+    assert rep["parity_ok"] and rep["parity_exact"] == 4 and rep["parity_max_divergence_margin"] == 0.0
+    assert abs(rep["parity_max_logit_err"] - 0.0625) < 1e-6 and abs(rep["parity_threshold"] - 0.125) < 1e-6
+    assert rep["parity_decisions"] == 4 * 7 and rep["parity_must_match"] == 4
+
+
+def test_divergence_is_licensed_only_below_twice_the_measured_error():
+    ref_ids, margins, ref_topk = _case()
+    got = [list(r) for r in ref_ids]
+    got[1][3] += 1                      # sequence 1 leaves the reference's stream at decision 3
+    got_topk = ref_topk.copy()
+    got_topk[0, 0, 0] += 0.25           # measured max |logit error| 0.25 -> licence 0.5
+    margins[1, 3] = 0.375               # ... and the reference decided that token by 0.375: allowed
+    rep = P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6)
+    assert rep["parity_ok"] and rep["parity_exact"] == 3 and abs(rep["parity_max_divergence_margin"] - 0.375) < 1e-6
+    assert rep["parity_must_match"] == 3  # sequence 1 has a decision inside the licence
+    margins[1, 3] = 0.75                # decided by more than the licence: a real disagreement
+    rep = P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6)
+    assert not rep["parity_ok"] and "VIOLATIONS" in rep["parity_note"]
+    # only the FIRST difference of a sequence counts: what follows is a different context
+    margins[1, 3], margins[1, 4] = 0.375, 5.0
+    got[1][4] += 1
+    assert P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6)["parity_ok"]
+
+
+def test_a_broken_kernel_cannot_buy_itself_a_wide_licence():
+    ref_ids, margins, ref_topk = _case()
+    got = [list(r) for r in ref_ids]
+    got[2][0] += 1
+    margins[2, 0] = 1.5
+    got_topk = ref_topk + 1.0           # error 1.0 would license margins up to 2.0 -- but it is above the cap
+    rep = P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6, max_err_cap=0.75)
+    assert not rep["parity_ok"] and "LOGIT ERROR ABOVE CAP" in rep["parity_note"]
+
+
+def test_exact_count_floor_and_flat_licence_without_logits():
+    ref_ids, margins, ref_topk = _case()
+    got = [list(r) for r in ref_ids]
+    for i in (0, 1, 2):
+        got[i][1] += 1
+        margins[i, 1] = 0.0             # ties: always licensed
+    rep = P.parity_report(got, ref_ids, margins, ref_topk, ref_topk + 0.01, tokens=6, min_exact=2)
+    assert not rep["parity_ok"] and rep["parity_exact"] == 1
+    assert P.parity_report(got, ref_ids, margins, ref_topk, ref_topk + 0.01, tokens=6, min_exact=1)["parity_ok"]
+    rep = P.parity_report(got, ref_ids, margins, None, None, tokens=6)  # no logits: the flat round-2 licence of 0.5
+    assert rep["parity_ok"] and rep["parity_threshold"] == 0.5
+
+
+def test_logit_error_in_bf16_ulps():
+    ref = np.array([[[16.0, 8.0, 1.0]]], dtype=np.float32)   # bf16 spacing 0.125, 0.0625, 0.0078125
+    got = ref + np.array([[[0.125, 0.125, 0.0078125]]], dtype=np.float32)
+    st = P.logit_error_stats(got, ref)
+    assert st["max"] == 0.125 and st["max_ulps"] == 2.0 and st["decisions"] == 1
+
+
+def test_reference_fixture_against_itself():
+    """tests/golden/md2b_bench64.npz: the reference's own ids are 64/64; the fixture's tie / narrow-margin census is the one
+    the bench's exact-count floor is argued from."""
+    g = np.load(os.path.join(GOLD, "md2b_bench64.npz"))
+    ids = g["tokens"].tolist()
+    rep = P.parity_report(ids, ids, g["margins"], g["top8_val"], g["top8_val"], tokens=32, min_exact=64)
+    assert rep["parity_ok"] and rep["parity_exact"] == 64 and rep["parity_threshold"] == 0.0
+    m = g["margins"][:, :32]
+    assert int((m.min(axis=1) == 0.0).sum()) == 9          # sequences with an exact tie somewhere
+    assert int((m.min(axis=1) > 0.25).sum()) == 12         # sequences every decision of which is wider than 0.25
+
+
+def test_detect_parity_compares_leading_wide_objects_exactly():
+    g = np.load(os.path.join(GOLD, "md2b_detect13.npz"))
+    n = int(g["n_images"])
+    objs = []
+    for i in range(n):
+        ref = np.asarray(g[f"img{i}.objects"]).reshape(-1, 4)
+        objs.append([dict(zip(("x_min", "y_min", "x_max", "y_max"), r.tolist())) for r in ref])
+    rep = P.detect_parity(objs, g)
+    assert rep["ok"] and rep["objects_compared"] > 0 and rep["objects_mismatched"] == 0
+    # leading_wide_objects stops at the first object with a narrow decision
+    assert P.leading_wide_objects(np.array([[9, 9, 9, 9, 9], [9, 3.9, 9, 9, 9], [9, 9, 9, 9, 9]], dtype=np.float32), 4.0) == 1
+    # a changed coordinate of a compared object is a mismatch; a missing object too
+    i0 = next(i for i in range(n) if P.leading_wide_objects(g[f"img{i}.margins"], 4.0) > 0)
+    bad = [list(o) for o in objs]
+    bad[i0] = [dict(bad[i0][0], y_min=bad[i0][0]["y_min"] + 1e-3)] + bad[i0][1:]
+    assert P.detect_parity(bad, g)["objects_mismatched"] == 1
+    bad[i0] = []
+    assert not P.detect_parity(bad, g)["ok"]

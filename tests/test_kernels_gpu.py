@@ -855,6 +855,18 @@ def test_quantize_layernorm_amax_f8(lib):
     _lib.check(lib.md_layernorm_bf16(x.data_ptr(), x.stride(0), yb.data_ptr(), yb.stride(0), C.byref(st), rows, dim, 1e-5, stream()))
     torch.cuda.synchronize()
     assert torch.equal(y2[:, :dim], quant_rows(yb, scale).view(torch.uint8)) and int(y2[:, dim:].max()) == 0
+    # other row widths: two pairs of chunks per lane, an odd chunk count, padding wider than a pair
+    for rows_i, dim_i, pad_i in ((77, 2048, 2048), (130, 720, 768), (9, 88, 128), (5, 3000, 3008)):
+        xi = randn(rows_i, dim_i, scale=2.0, seed=63)
+        lni = PackedLayerNorm(1.0 + randn(dim_i, scale=0.1, seed=64), randn(dim_i, scale=0.1, seed=65), "cuda")
+        sti = lni.struct()
+        yi = torch.full((rows_i, pad_i), 0x7F, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.md_layernorm_f8(xi.data_ptr(), xi.stride(0), yi.data_ptr(), yi.stride(0), C.byref(sti), rows_i, dim_i, pad_i, 1e-5, 1.0 / scale, stream()))
+        ybi = torch.empty(rows_i, dim_i, dtype=BF16, device="cuda")
+        _lib.check(lib.md_layernorm_bf16(xi.data_ptr(), xi.stride(0), ybi.data_ptr(), ybi.stride(0), C.byref(sti), rows_i, dim_i, 1e-5, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(yi[:, :dim_i], quant_rows(ybi, scale).view(torch.uint8)), dim_i
+        assert pad_i == dim_i or int(yi[:, dim_i:].max()) == 0, dim_i
     am = torch.zeros(1, dtype=torch.float32, device="cuda")
     x[9, 100] = float("inf")
     _lib.check(lib.md_amax_bf16(x.data_ptr(), x.stride(0), rows, dim, am.data_ptr(), stream()))

@@ -488,6 +488,9 @@ def main():
             "traffic": traffic,
             "launches": int(n.value),
             "share_of_step": (ms.value * 1e-3) / step_gpu_s if step_gpu_s > 0 else None,
+            "mfma_only_ceiling": {"tflops": 1832.0, "frac_of_it": gemm_tflops / 1832.0,
+                                  "note": "profiles/r03_mfma_shape_probe.txt: a kernel of nothing but v_mfma_f32_32x32x16_bf16 on random register "
+                                          "operands sustains 1.83 PF/s on this chip (power-limited clock); `frac` above stays against the nominal 2.5 PF/s"},
             "measured_on": "one non-overlapped, eagerly launched step after the timed region",
         },
         "decode_gemm": {

@@ -64,3 +64,63 @@ def test_graft_entry_build_loads_the_library():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """Every argument struct of include/moondream_hip.h against its ctypes mirror: total size and the offset of every
+    field, as gcc lays the header out (a field added to one side only would shift everything behind it silently)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    from moondream_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {
+        "md_linear": _lib.MdLinear, "md_layernorm": _lib.MdLayerNorm, "md_gemm_args": _lib.MdGemmArgs, "md_linear_fp8": _lib.MdLinearFp8,
+        "md_linear_f8": _lib.MdLinearF8, "md_gemm_f8_args": _lib.MdGemmF8Args, "md_attn_args": _lib.MdAttnArgs,
+        "md_vit_block": _lib.MdVitBlock, "md_vit_block_f8": _lib.MdVitBlockF8, "md_vit_f8": _lib.MdVitF8, "md_vit_model": _lib.MdVitModel,
+        "md_text_block": _lib.MdTextBlock, "md_text_block_fp8": _lib.MdTextBlockFp8, "md_text_fp8": _lib.MdTextFp8,
+        "md_text_block_f8": _lib.MdTextBlockF8, "md_text_f8": _lib.MdTextF8, "md_text_model": _lib.MdTextModel,
+        "md_kv_cache": _lib.MdKvCache, "md_lora_pair": _lib.MdLoraPair, "md_text_block_lora": _lib.MdTextBlockLora,
+    }
+    header = os.path.join(REPO, "include", "moondream_hip.h")
+    text = open(header).read()
+    # field names per struct from the header text (declarations between "typedef struct {" and "} name;")
+    import re
+
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{header}"', "int main(void) {"]
+    fields = {}
+    for name in pairs:
+        m = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} " + name + ";", text, flags=re.S)
+        assert m, name
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            # "type a, b, c" / "const type* a" / "type a[N]"
+            first, *rest = decl.split(",")
+            names.append(re.sub(r"\[.*?\]", "", first.split()[-1]).lstrip("*"))
+            names += [re.sub(r"\[.*?\]", "", r.strip()).lstrip("*") for r in rest]
+        fields[name] = names
+        lines.append(f'  printf("{name} %zu", sizeof({name}));')
+        for f in names:
+            lines.append(f'  printf(" %zu", offsetof({name}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == len(pairs)
+    for line in out:
+        name, size, *offs = line.split()
+        cls = pairs[name]
+        assert C.sizeof(cls) == int(size), (name, C.sizeof(cls), size)
+        cnames = [f[0] for f in cls._fields_]
+        assert cnames == fields[name], (name, cnames, fields[name])
+        assert [getattr(cls, f).offset for f in cnames] == [int(o) for o in offs], name

@@ -49,7 +49,7 @@ std::vector<ProfRec> g_prof;
 // Experiment knobs, read ONCE (A/B runs; the product path never sets them).
 struct Knobs {
   int tile = -1;       // MD_GEMM_TILE: force a tile config
-  int group_m = 8;     // MD_GEMM_GROUP_M: row panels per tile-order group
+  int group_m = 0;     // MD_GEMM_GROUP_M: row panels per tile-order group (0 = by shape, md_gemm_auto_group_m)
   int w4 = 1;          // MD_GEMM_W4=0: the eight-wave 256x256 kernels instead of the four-wave one
   int persist = 1;     // MD_GEMM_PERSIST=0 (eight-wave kernels only)
   int nt = 0;          // MD_DECODE_NT=1: stream decode-regime weights non-temporally
@@ -59,7 +59,7 @@ struct Knobs {
   Knobs() {
     auto geti = [](const char* n, int d) { const char* e = getenv(n); return (e && *e) ? atoi(e) : d; };
     tile = geti("MD_GEMM_TILE", -1);
-    group_m = std::max(1, geti("MD_GEMM_GROUP_M", 8));
+    group_m = std::max(0, geti("MD_GEMM_GROUP_M", 0));
     w4 = geti("MD_GEMM_W4", 1);
     persist = geti("MD_GEMM_PERSIST", 1);
     nt = geti("MD_DECODE_NT", 0);
@@ -763,7 +763,7 @@ md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse*
   k.K = a->lin.k_pad;
   k.res_row_mod = a->res_row_mod;
   k.tiles_m = k.tiles_n = 0;
-  k.group_m = knobs().group_m;
+  k.group_m = knobs().group_m > 0 ? knobs().group_m : md_gemm_auto_group_m(k.n_store);
   k.gelu_from = a->gelu_from_col;
   k.partial = nullptr;
   k.partial_ld = k.partial_slice_stride = 0;
@@ -958,12 +958,19 @@ extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32
 
 bool md_gemm_knob_rope_fuse() { return knobs().rope_fuse != 0; }
 
+// Row panels per group of the tile order (a group = group_m row panels x all column panels, rows fastest; an XCD's 32
+// concurrent workgroups walk it contiguously).  Measured on the model's shapes (profiles/r03_gemm_tile_order_group_m.txt):
+// layers of at most eight 256-wide column panels (N <= 2048: proj, fc2) run 2-3.5 % faster when an XCD covers ALL column
+// panels of a few row panels at a time (group_m = 1: every activation panel crosses the fabric once), wide layers want a
+// squarer block (4; 8 was the value until round 3 and is 2-4 % slower on the long-K narrow layers, never faster).
+int md_gemm_auto_group_m(int n_store) { return (n_store + 255) / 256 <= 8 ? 1 : 4; }
+
 extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   MD_CHECK_ARG(key != nullptr);
   Knobs& k = knobs();
   const std::string s(key);
   if (s == "tile") k.tile = value;
-  else if (s == "group_m") k.group_m = std::max(1, (int)value);
+  else if (s == "group_m") k.group_m = std::max(0, (int)value);
   else if (s == "w4") k.w4 = value;
   else if (s == "persist") k.persist = value;
   else if (s == "decode_nt") k.nt = value;

@@ -430,7 +430,7 @@ md_status gemm_f8_dispatch(const md_gemm_f8_args* a, void* stream, const md_rope
   k.K = a->lin.k_pad;
   k.tiles_m = k.tiles_n = 0;
   k.res_row_mod = a->res_row_mod;
-  k.group_m = 8;
+  k.group_m = md_gemm_auto_group_m(n_store);
   k.gelu_from = a->gelu_from_col;
   k.f8_from = a->c8 ? a->f8_from_col : 0;
   k.rope_cs = nullptr; k.rope_kv = nullptr; k.kslab = k.vslab = nullptr; k.k8slab = k.v8slab = nullptr;

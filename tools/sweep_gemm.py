@@ -4,7 +4,7 @@ GPU, ViT in groups of 128 crops) and on square problems, random operands.  Every
 `rounds` times in ONE process, round-robin, and the median is printed (run-to-run noise of a single
 timing is ~3 %, cdna guide 5.4 rule 24).
 
-    python tools/sweep_gemm.py [tiles=20,11,15] [rounds=3] [zero=0] [epi=2]
+    python tools/sweep_gemm.py [tiles=20,11,15] [rounds=3] [zero=0] [epi=2] [group_m=8]
 """
 import ctypes as C
 import math
@@ -25,6 +25,8 @@ TILES = [int(t) for t in opts.get("tiles", "20,11,15").split(",")]
 ROUNDS = int(opts.get("rounds", "3"))
 ZERO = opts.get("zero", "0") == "1"
 ONLY_EPI = int(opts["epi"]) if "epi" in opts else None  # epi=2: residual layers only
+if "group_m" in opts:  # row panels per tile-order group (the XCD-level blocking of the persistent tile sequence)
+    lib.md_gemm_set_tuning(b"group_m", int(opts["group_m"]))
 
 # (m, k, n, epilogue, label): the layers of one B=64 step
 SHAPES = [

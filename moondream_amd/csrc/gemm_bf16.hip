@@ -979,6 +979,8 @@ extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   else if (s == "w4_variant") md_gemm_w4_set_variant(value);
   else if (s == "rope_fuse") k.rope_fuse = value;
   else if (s == "w4_grid") md_gemm_w4_set_grid(value);
+  else if (s == "w4_dbg_lo") md_gemm_w4_set_debug(0, (uint32_t)value);
+  else if (s == "w4_dbg_hi") md_gemm_w4_set_debug(1, (uint32_t)value);
   else return MD_ERR_INVALID_ARG;
   return MD_OK;
 }

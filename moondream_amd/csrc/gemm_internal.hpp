@@ -64,4 +64,5 @@ int md_gemm_w4_residual_max_cols();   // widest residual layer the four-wave ker
 int md_gemm_w4_max_cols(int epi);     // the same per epilogue kind (bias / GELU layers: 14336 columns)
 bool md_gemm_w4_takes(const GemmK& k, int epi);  // shape limits of the four-wave kernel for this launch
 void md_gemm_w4_set_grid(int v);     // persistent workgroups per launch of the four-wave kernel (0 = one per CU)
+void md_gemm_w4_set_debug(int half, uint32_t v);  // measurement builds: device buffer for in-kernel stamps
 void md_gemm_w4_set_variant(int v);  // measurement hook: schedule / ablation variant of the bias-epilogue kernel

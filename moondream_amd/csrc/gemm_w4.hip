@@ -38,6 +38,7 @@
 #include "gemm_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -153,10 +154,54 @@ constexpr int frag_wait(int h, int m) {
 }
 static_assert(frag_wait(0, 0) <= 15 && frag_wait(1, 12) <= 15 && frag_wait(2, 12) <= 15 && frag_wait(3, 0) <= 15, "lgkmcnt is a 4-bit counter");
 
+// ---- MODE >= 1: operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no register round trip ----------
+// LDS image: TWO pair buffers of 64 KiB; a buffer holds 64 K elements of the tile's 256 activation rows (32 KiB) and 256
+// weight rows (32 KiB) as 128-byte rows, logical 16-byte chunk c of row r at physical chunk c ^ ((r >> 1) & 7).  A DMA
+// instruction moves 8 rows x 128 bytes (whole cache lines; the lane -> LDS mapping is linear, so the permutation sits in
+// the per-lane SOURCE offset); a wave issues 16 of them per pair.  Fragment reads: K step s (0-3) of a pair = logical chunks
+// 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63).
+//   filler schedule of one pair (gap g = right after MFMA g):
+//     ds_read      half 1's fragments in gaps 1, 3, .., 15, half 2's in 17, .., 31, half 3's in 32, 34, .., 46 (EVEN: the last
+//                  read of the buffer being multiplied is two MFMAs old at the barrier), the NEXT pair's half 0 in 49, .., 63
+//     gap 48       s_waitcnt lgkmcnt(0) (this wave has finished reading the current buffer), vmcnt(0) (its DMA pieces of the
+//                  next pair have landed), s_barrier: the next buffer is published, the current one is released
+//     LDS-DMA      16 pieces of the pair AFTER the next one into the released buffer, at the gaps dma_pos() names: the
+//                  stream runs two pairs ahead of the MFMAs at issue, a piece has 32+ gaps (1000+ cycles) to land
+constexpr int PBUF = 65536;                     // one pair buffer
+constexpr int kAdvanceGap = 40;                 // the load cursor moves on here: after the last wrapped piece, before gap 48
+constexpr int dma_pos(int mode, int q) {        // stream gap (48 .. 111) at which piece q of pair p + 2 is issued, in body(p) / body(p + 1)
+  return mode == 1 ? (q < 8 ? 48 + 2 * q : 64 + 2 * (q - 8)) : mode == 2 ? 48 + q : 48 + 3 * q;
+}
+constexpr bool dma_is_read_gap(int g) {
+  const int x = ((g % 64) + 64) % 64;
+  return (x < 32 && x % 2 == 1) || (x >= 32 && x < 48 && x % 2 == 0) || (x > 48 && x % 2 == 1);
+}
+// stream position (relative to gap 0 of the consuming pair) of the k-th read of half h
+constexpr int dma_read_pos(int h, int k) { return h == 0 ? -15 + 2 * k : h == 1 ? 1 + 2 * k : h == 2 ? 17 + 2 * k : 32 + 2 * k; }
+// which (half, k) is read in gap x of a body, encoded 8 h + k; -1: none
+constexpr int dma_read_slot(int x) {
+  for (int h = 0; h < 4; ++h)
+    for (int k = 0; k < 8; ++k)
+      if (((dma_read_pos(h, k) % 64) + 64) % 64 == x) return 8 * h + k;
+  return -1;
+}
+constexpr int dma_frag_wait(int h, int m) {
+  int w = -1;
+  for (int k = 0; k < 8; ++k)
+    if (kFirstUse[k] == m) {
+      int c = 0;
+      for (int g = dma_read_pos(h, k) + 1; g < 16 * h + m; ++g) c += dma_is_read_gap(g) ? 1 : 0;
+      w = (w < 0 || c < w) ? c : w;
+    }
+  return w;
+}
+static_assert(dma_frag_wait(0, 0) <= 15 && dma_frag_wait(1, 12) <= 15 && dma_frag_wait(2, 12) <= 15 && dma_frag_wait(3, 12) <= 15, "lgkmcnt is a 4-bit counter");
+
 // ABL: timing ablations for profiling (bit 0: no ds_write, 1: no global loads, 2: no barrier, 3: no
 // fragment reads, 4: no epilogue stores); results are garbage with any bit set.
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, int MODE = 1>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
+  constexpr bool DMA = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -167,6 +212,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
 
   const int nwg = p.tiles_m * p.tiles_n;
   const int npair = p.K / 64;  // pairs of 32-wide slices per tile
+  int grid_x = gridDim.x;      // pinned in a scalar register: re-read from the dispatch packet inside the stream it is an
+  asm volatile("" : "+s"(grid_x));  // s_load + lgkmcnt(0) in the middle of a pair
 
   // workgroup sequence number -> tile: XCD-contiguous remap, then grouped (group_m row panels x all
   // column panels) order, so the 32 workgroups of an XCD that run together cover a compact block
@@ -192,7 +239,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   auto set_load_tile = [&](int vv) {
     int m0, n0;
     tile_origin(vv, m0, n0);
-    const int r8 = tid >> 3, c8 = tid & 7;
+    // r8: this thread's row within a 32-row block (wave w covers rows 8 w .. 8 w + 7 of every block).  DMA modes: the lane's LDS
+    // slot is fixed (row r8, physical chunk tid & 7), so it FETCHES the logical chunk that belongs there
+    const int r8 = tid >> 3, c8 = DMA ? ((tid & 7) ^ ((r8 >> 1) & 7)) : (tid & 7);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       voff[j] = (uint32_t)min(m0 + 32 * j + r8, p.M - 1) * (uint32_t)(p.lda * 2) + c8 * 16;
@@ -200,6 +249,25 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     }
   };
   set_load_tile(ld_tile);
+  // DMA modes: the buffer descriptors as four scalar words each (inline asm operand), and the wave's LDS-DMA base:
+  // piece j lands at  pair buffer + (j < 8 ? 0 : 32 KiB) + (j & 7) * 4 KiB + wave * 1 KiB + lane * 16
+  u32x4 rs_a, rs_w;
+  rs_a[0] = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.A);
+  rs_a[1] = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.A >> 32));
+  rs_w[0] = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.W);
+  rs_w[1] = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.W >> 32));
+  rs_a[2] = rs_w[2] = 0xffffffffu;
+  rs_a[3] = rs_w[3] = 0x00020000u;
+  const uint32_t dma_lds = lds_base + (uint32_t)wave * 1024u;
+  auto dma_piece = [&](auto j_c, uint32_t buf) {
+    constexpr int J = decltype(j_c)::value;
+    constexpr int OFF = J < 8 ? J * 4096 : 32768 + (J - 8) * 4096;
+    // (operands copied to locals first: clang does not capture variables that appear only as asm operands of a generic lambda)
+    const uint32_t base = dma_lds + buf, vo = voff[J], so = ld_soff;  // base, so: wave-uniform
+    const u32x4 rs = J < 8 ? rs_a : rs_w;
+    if constexpr (!(ABL & 2))
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds" ::"s"(base), "i"(OFF), "v"(vo), "s"(rs), "s"(so) : "memory", "scc");
+  };
 
   u32x4 R[16];  // one pair of slices in registers; each piece is re-requested right after it is written out
   if constexpr (ABL != 0) {
@@ -222,8 +290,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       ld_soff = 0;
       // past the end of the stream the cursor stays on the last tile: the loads keep going
       // (their data is never written anywhere that is read), which keeps the loop free of branches
-      if (ld_tile + (int)gridDim.x < nwg) {
-        ld_tile += gridDim.x;
+      if (ld_tile + grid_x < nwg) {
+        ld_tile += grid_x;
         set_load_tile(ld_tile);
       }
     }
@@ -260,6 +328,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       ra[par][st] = lds_base + par * STAGE + ((wm * 128 + l31) ^ par) * ROW_BYTES + coff[st];
       rb[par][st] = lds_base + par * STAGE + A_BYTES + ((wn * 128 + l31) ^ par) * ROW_BYTES + coff[st];
     }
+  // DMA modes: 128-byte rows, [K step 0-3]
+  const uint32_t swz8 = (l31 >> 1) & 7;
+  uint32_t da[4], db[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    da[st] = lds_base + (wm * 128 + l31) * 128 + (((2 * st + hi) ^ swz8) * 16);
+    db[st] = lds_base + 32768 + (wn * 128 + l31) * 128 + (((2 * st + hi) ^ swz8) * 16);
+  }
   bf16x8 fa[2][4], fb[2][4];  // [fragment set][32-row block]
   if constexpr (ABL != 0) {
 #pragma unroll
@@ -270,9 +346,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     if constexpr (ABL & 8) {
       if constexpr (Q < 4) opaque(fb[SET][Q]); else opaque(fa[SET][Q - 4]);
     } else if constexpr (Q < 4)
-      ds_read_b128<Q * 32 * ROW_BYTES>(fb[SET][Q], b_addr);
+      ds_read_b128<Q * 32 * (DMA ? 128 : ROW_BYTES)>(fb[SET][Q], b_addr);
     else
-      ds_read_b128<(Q - 4) * 32 * ROW_BYTES>(fa[SET][Q - 4], a_addr);
+      ds_read_b128<(Q - 4) * 32 * (DMA ? 128 : ROW_BYTES)>(fa[SET][Q - 4], a_addr);
   };
 
   acc_reserve();
@@ -280,18 +356,33 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   // ---- stream prologue: pair 0 written, pair 1 requested ---------------------------------------
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  static_for<0, 16>([&](auto j) { load_piece(j); });
-  advance_load_cursor();
-  asm volatile("" ::: "memory");
-  static_for<0, 16>([&](auto j) { write_piece(j, pair_cur); });
-  asm volatile("" ::: "memory");
-  static_for<0, 16>([&](auto j) { load_piece(j); });
-  advance_load_cursor();
-  wait_lgkm<0>();
+  // the first fragments (K step 0) of the pair in pair_cur, all eight, waited for: stream start and after every epilogue
+  auto read_first_frags = [&]() {
+    const uint32_t a0 = (DMA ? da[0] : ra[0][0]) + pair_cur, b0 = (DMA ? db[0] : rb[0][0]) + pair_cur;
+    static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, a0, b0); });
+    wait_lgkm<0>();
+    MD_PIN();
+  };
+  if constexpr (!DMA) {
+    static_for<0, 16>([&](auto j) { load_piece(j); });
+    advance_load_cursor();
+    asm volatile("" ::: "memory");
+    static_for<0, 16>([&](auto j) { write_piece(j, pair_cur); });
+    asm volatile("" ::: "memory");
+    static_for<0, 16>([&](auto j) { load_piece(j); });
+    advance_load_cursor();
+    wait_lgkm<0>();
+  } else {
+    // pair 0 whole, and the pieces of pair 1 that the steady state issues at the END of a body (dma_pos < 64)
+    static_for<0, 16>([&](auto j) { dma_piece(j, pair_cur); });
+    advance_load_cursor();
+    static_for<0, 16>([&](auto j) {
+      if constexpr (dma_pos(MODE, decltype(j)::value) < 64) dma_piece(j, pair_wr);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
-  static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, ra[0][0] + pair_cur, rb[0][0] + pair_cur); });
-  wait_lgkm<0>();
-  MD_PIN();
+  read_first_frags();
 
   // One pair of slices = 64 MFMAs = 64 gaps (four halves of 16: even slice K steps 0, 1, odd slice K steps 0, 1;
   // fragment sets 0, 1, 0, 1).  The four waves run in lockstep between barriers, so whatever one wave does in a
@@ -300,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   // gap 48 publishes it (every wave drains its own writes first); its stages were last read in gap 47 of the
   // PREVIOUS pair, before that pair's barrier.  ONE straight-line body, no branch inside it (a second code path
   // would be a join over ~200 live registers); past the end of the stream the fillers keep running on data nobody reads.
-  auto pair_body = [&](auto first_c) {
+  auto pair_body_reg = [&](auto first_c) {
     constexpr bool FIRST = decltype(first_c)::value;  // first K step of a tile: accumulate onto zero
     const uint32_t a_e1 = ra[0][1] + pair_cur, b_e1 = rb[0][1] + pair_cur;   // even slice, K step 1
     const uint32_t a_o0 = ra[1][0] + pair_cur, b_o0 = rb[1][0] + pair_cur;   // odd slice, K step 0
@@ -336,6 +427,64 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     pair_cur = pair_wr;
     pair_wr = t;
   };
+  // The same pair with the operands arriving by LDS-DMA (schedule: the tables above).  pair_cur = the buffer being
+  // multiplied, pair_wr = the other one: it receives the late pieces of the NEXT pair in the first gaps, is published by
+  // the barrier in gap 48, and is read from gap 49 on; from gap 48 on pair_cur receives the pair after that.
+  // measurement build (ABL & 64): shader-clock stamps around the waits of gap 48 (s_memtime is counted by lgkmcnt: only here,
+  // where the counter is drained anyway)
+  uint32_t st_lgkm = 0, st_vm = 0, st_bar = 0, st_n = 0;
+  uint64_t st_first = 0, st_last = 0, st_epi = 0;
+  auto pair_body_dma = [&](auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    const uint32_t a1 = da[1] + pair_cur, b1 = db[1] + pair_cur, a2 = da[2] + pair_cur, b2 = db[2] + pair_cur;
+    const uint32_t a3 = da[3] + pair_cur, b3 = db[3] + pair_cur, an = da[0] + pair_wr, bn = db[0] + pair_wr;
+    const uint32_t buf_cur = pair_cur, buf_nxt = pair_wr;
+    static_for<0, 64>([&](auto xc) {
+      constexpr int X = decltype(xc)::value, H = X / 16, M = X % 16, I = M / 4, J = M % 4, SET = H & 1;
+      if constexpr (X == 48) {
+        uint64_t t0 = 0;
+        if constexpr (ABL & 64) t0 = __builtin_readcyclecounter();
+        if constexpr (!(ABL & 8)) wait_lgkm<0>();
+        if constexpr (ABL & 64) { const uint64_t t = __builtin_readcyclecounter(); st_lgkm += (uint32_t)(t - t0); t0 = t; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (ABL & 64) { const uint64_t t = __builtin_readcyclecounter(); st_vm += (uint32_t)(t - t0); t0 = t; }
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (ABL & 64) {
+          const uint64_t t = __builtin_readcyclecounter();
+          st_bar += (uint32_t)(t - t0);
+          if (st_n == 0) st_first = t;
+          st_last = t;
+          ++st_n;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      if constexpr (dma_frag_wait(H, M) >= 0 && !(ABL & 8)) wait_lgkm<dma_frag_wait(H, M)>();
+      mfma_acc<M, FIRST && H == 0>(fb[SET][J], fa[SET][I]);
+      MD_PIN();
+      constexpr int RS = dma_read_slot(X);
+      if constexpr (RS >= 0) {
+        using Q = std::integral_constant<int, kReadOrder[RS % 8]>;
+        if constexpr (RS / 8 == 1) read_frag(I1{}, Q{}, a1, b1);
+        if constexpr (RS / 8 == 2) read_frag(I0{}, Q{}, a2, b2);
+        if constexpr (RS / 8 == 3) read_frag(I1{}, Q{}, a3, b3);
+        if constexpr (RS / 8 == 0) read_frag(I0{}, Q{}, an, bn);
+      }
+      static_for<0, 16>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        if constexpr (dma_pos(MODE, Q) == X) dma_piece(qc, buf_cur);        // pair p + 2 -> the buffer released in gap 48
+        if constexpr (dma_pos(MODE, Q) - 64 == X) dma_piece(qc, buf_nxt);   // late pieces of pair p + 1
+      });
+      if constexpr (X == kAdvanceGap) advance_load_cursor();
+      MD_PIN();
+    });
+    const uint32_t t = pair_cur;
+    pair_cur = pair_wr;
+    pair_wr = t;
+  };
+  auto pair_body = [&](auto first_c) {
+    if constexpr (DMA) pair_body_dma(first_c); else pair_body_reg(first_c);
+  };
 
   // ---- tile loop ------------------------------------------------------------------------------
   // The layer's bias vector goes to LDS once per launch: a global load inside the epilogue would have to wait for
@@ -352,20 +501,24 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     wait_lgkm<0>();
     __syncthreads();
   }
-  for (int vtile = blockIdx.x; vtile < nwg; vtile += gridDim.x) {
+  for (int vtile = blockIdx.x; vtile < nwg; vtile += grid_x) {
     // the accumulators are (re)defined by the first K step of every tile: nothing is carried from
     // one tile to the next in them
     pair_body(std::true_type{});
     for (int u = 1; u < npair; ++u) pair_body(std::false_type{});
     wait_lgkm<0>();
     MD_PIN();
+    uint64_t te0 = 0;
+    if constexpr (ABL & 64) { te0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
     // ---- epilogue of tile vtile (the next tile's first slices are already in the ring / in flight)
     // block X = 4 i + j, register r: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)   within the wave's quarter
     int m0c, n0c;
     tile_origin(vtile, m0c, n0c);
     const int wm0 = m0c + wm * 128, wn0 = n0c + wn * 128;
-    if constexpr (EPI == MD_EPI_RESIDUAL) {
+    if constexpr (ABL & 32) {
+      // measurement build: no epilogue at all (what a tile costs without one)
+    } else if constexpr (EPI == MD_EPI_RESIDUAL) {
     // Residual layers keep the LDS transposition: their second operand is read in whole 128-byte row pieces (the
     // register-only path below reads / writes 32-byte pieces, which costs these short-K, narrow-N layers 5 % --
     // profiles/r02_gemm_w4_epilogue_variants.txt).
@@ -628,20 +781,31 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
     // registers the epilogue does not have to carry); its first pair was published by the last barrier above
-    static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, ra[0][0] + pair_cur, rb[0][0] + pair_cur); });
-    wait_lgkm<0>();
-    MD_PIN();
+    read_first_frags();
+    if constexpr (ABL & 64) { st_epi += __builtin_readcyclecounter() - te0; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  }
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of the run-on stream in flight at the end of the wave
+  if constexpr (ABL & 64) {
+    if (lane == 0 && p.slabs != nullptr) {
+      float* o = p.slabs + (blockIdx.x * 4 + wave) * 8;
+      o[0] = (float)st_n; o[1] = (float)(st_last - st_first); o[2] = (float)st_lgkm; o[3] = (float)st_vm; o[4] = (float)st_bar; o[5] = (float)st_epi;
+    }
   }
 }
 
 int g_w4_grid = 0;     // md_gemm_set_tuning "w4_grid": persistent workgroups per launch (0 = one per CU); a multiple of 8
-int g_w4_variant = 0;  // measurement hook (md_gemm_set_tuning "w4_variant"): 16 * ABL, bias epilogue only
+// md_gemm_set_tuning "w4_variant": low 4 bits = operand path / schedule (MODE: 0 register-staged, 1-3 LDS-DMA schedules; 2 and 3
+// exist for the bias epilogue only), the rest 16 * ABL (measurement builds, bias epilogue only)
+int g_w4_variant = [] { const char* e = getenv("MD_W4_VARIANT"); return (e && *e) ? atoi(e) : 0; }();
 
-template <int EPI, int ABL = 0>
+uint64_t g_w4_debug = 0;  // measurement builds: device buffer for the in-kernel stamps (md_gemm_set_tuning "w4_dbg_lo" / "w4_dbg_hi")
+
+template <int EPI, int ABL = 0, int MODE = 1>
 md_status launch(const GemmK& k, hipStream_t stream) {
-  auto fn = gemm_w4_kernel<EPI, ABL>;
+  auto fn = gemm_w4_kernel<EPI, ABL, MODE>;
   MD_TRY(md_ensure_dynamic_lds((const void*)fn, LDS_BYTES));
   GemmK kk = k;
+  if constexpr (ABL & 64) kk.slabs = (float*)(uintptr_t)g_w4_debug;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.n_store + BN - 1) / BN;
   const int nwg = kk.tiles_m * kk.tiles_n;
@@ -657,12 +821,24 @@ md_status launch(const GemmK& k, hipStream_t stream) {
   return md_launch_status();
 }
 
+template <int MODE>
+md_status launch_mode(const GemmK& k, int epi, hipStream_t stream) {
+  switch (epi) {
+    case MD_EPI_BIAS: return launch<MD_EPI_BIAS, 0, MODE>(k, stream);
+    case MD_EPI_GELU: return launch<MD_EPI_GELU, 0, MODE>(k, stream);
+    case MD_EPI_RESIDUAL: return launch<MD_EPI_RESIDUAL, 0, MODE>(k, stream);
+    case MD_EPI_QKV_ROPE: return launch<MD_EPI_QKV_ROPE, 0, MODE>(k, stream);
+    default: return MD_ERR_INVALID_ARG;
+  }
+}
+
 }  // namespace
 
 int md_gemm_w4_residual_max_cols() { return bias_max_cols<MD_EPI_RESIDUAL>(); }
 int md_gemm_w4_max_cols(int epi) { return epi == MD_EPI_RESIDUAL ? bias_max_cols<MD_EPI_RESIDUAL>() : bias_max_cols<MD_EPI_BIAS>(); }
 
 void md_gemm_w4_set_variant(int v) { g_w4_variant = v; }
+void md_gemm_w4_set_debug(int half, uint32_t v) { g_w4_debug = half ? ((g_w4_debug & 0xffffffffull) | ((uint64_t)v << 32)) : ((g_w4_debug & ~0xffffffffull) | v); }
 void md_gemm_w4_set_grid(int v) { g_w4_grid = v > 0 ? std::max(8, v / 8 * 8) : 0; }
 
 bool md_gemm_w4_takes(const GemmK& k, int epi) {
@@ -685,28 +861,33 @@ bool md_gemm_w4_takes(const GemmK& k, int epi) {
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   if (k.K % 64 != 0 || k.M <= 0) return MD_ERR_INVALID_ARG;
   if (!md_gemm_w4_takes(k, epi)) return MD_ERR_UNSUPPORTED;
+  const int mode = g_w4_variant & 15, abl = g_w4_variant >> 4;  // (ablation codes: mode + 16 * ABL)
 #ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
-  if (epi == MD_EPI_BIAS && g_w4_variant != 0) {
-    switch (g_w4_variant) {
-      case 16 * 1: return launch<MD_EPI_BIAS, 1>(k, stream);
-      case 16 * 2: return launch<MD_EPI_BIAS, 2>(k, stream);
-      case 16 * 3: return launch<MD_EPI_BIAS, 3>(k, stream);
-      case 16 * 4: return launch<MD_EPI_BIAS, 4>(k, stream);
-      case 16 * 8: return launch<MD_EPI_BIAS, 8>(k, stream);
-      case 16 * 16: return launch<MD_EPI_BIAS, 16>(k, stream);
-      case 16 * 15: return launch<MD_EPI_BIAS, 15>(k, stream);
-      case 16 * 31: return launch<MD_EPI_BIAS, 31>(k, stream);
-      case 16 * 64: return launch<MD_EPI_BIAS, 64>(k, stream);
-      case 16 * 128: return launch<MD_EPI_BIAS, 128>(k, stream);
+  if (epi == MD_EPI_BIAS && abl != 0) {
+    switch (256 * mode + abl) {
+      case 256 * 0 + 2: return launch<MD_EPI_BIAS, 2, 0>(k, stream);
+      case 256 * 0 + 8: return launch<MD_EPI_BIAS, 8, 0>(k, stream);
+      case 256 * 0 + 16: return launch<MD_EPI_BIAS, 16, 0>(k, stream);
+      case 256 * 0 + 32: return launch<MD_EPI_BIAS, 32, 0>(k, stream);
+      case 256 * 1 + 2: return launch<MD_EPI_BIAS, 2, 1>(k, stream);
+      case 256 * 1 + 4: return launch<MD_EPI_BIAS, 4, 1>(k, stream);
+      case 256 * 1 + 8: return launch<MD_EPI_BIAS, 8, 1>(k, stream);
+      case 256 * 1 + 14: return launch<MD_EPI_BIAS, 14, 1>(k, stream);
+      case 256 * 1 + 16: return launch<MD_EPI_BIAS, 16, 1>(k, stream);
+      case 256 * 1 + 32: return launch<MD_EPI_BIAS, 32, 1>(k, stream);
+      case 256 * 1 + 46: return launch<MD_EPI_BIAS, 46, 1>(k, stream);
+      case 256 * 1 + 64: return launch<MD_EPI_BIAS, 64, 1>(k, stream);
+      case 256 * 3 + 64: return launch<MD_EPI_BIAS, 64, 3>(k, stream);
       default: return MD_ERR_INVALID_ARG;
     }
   }
 #endif
-  switch (epi) {
-    case MD_EPI_BIAS: return launch<MD_EPI_BIAS>(k, stream);
-    case MD_EPI_GELU: return launch<MD_EPI_GELU>(k, stream);
-    case MD_EPI_RESIDUAL: return launch<MD_EPI_RESIDUAL>(k, stream);
-    case MD_EPI_QKV_ROPE: return launch<MD_EPI_QKV_ROPE>(k, stream);
+  if (abl != 0) return MD_ERR_INVALID_ARG;
+  switch (mode) {
+    case 0: return launch_mode<0>(k, epi, stream);
+    case 1: return launch_mode<1>(k, epi, stream);
+    case 2: return epi == MD_EPI_BIAS ? launch<MD_EPI_BIAS, 0, 2>(k, stream) : MD_ERR_INVALID_ARG;
+    case 3: return epi == MD_EPI_BIAS ? launch<MD_EPI_BIAS, 0, 3>(k, stream) : MD_ERR_INVALID_ARG;
     default: return MD_ERR_INVALID_ARG;
   }
 }

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Timing ablations of the four-wave 256x256 GEMM (gemm_w4.hip): what each class of filler costs.
-Variants are compiled into the library for the bias epilogue only (results are garbage for
-ablations); code = SCHED + 16 * ABL, ABL bits: 1 no ds_write, 2 no global loads, 4 no barrier,
-8 no fragment reads, 16 no epilogue stores."""
+"""Timing ablations and in-kernel stamps of the four-wave 256x256 GEMM (gemm_w4.hip), bias epilogue.  Needs the measurement build
+(MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()").  md_gemm_set_tuning "w4_variant" = MODE + 16 * ABL;
+MODE 0 = register-staged operands, 1-3 = LDS-DMA schedules; ABL bits: 2 no operand loads, 4 no barrier, 8 no fragment reads,
+16 no epilogue stores, 32 no epilogue, 64 = shader-clock stamps around the waits of gap 48 and the epilogue (results are garbage
+with bits 2-32 set)."""
 import ctypes as C
 import math
 import os
@@ -18,26 +19,57 @@ from tools.sweep_gemm import timeit, stream
 
 lib = _lib.load()
 BF16 = torch.bfloat16
-VARIANTS = [("w4", 20, 0), ("no ds_write", 20, 16), ("no loads", 20, 32), ("no write+loads", 20, 48),
-            ("no barrier", 20, 64), ("no frag reads", 20, 128), ("no stores", 20, 256), ("mfma+stores only", 20, 240),
-            ("mfma only", 20, 496), ("vmcnt0 after stores", 20, 1024), ("nt stores", 20, 2048), ("8-wave alt", 11, 0)]
+V = lambda mode, abl: mode + 16 * abl
+VARIANTS = [("reg", V(0, 0)), ("reg no-loads", V(0, 2)), ("reg no-reads", V(0, 8)), ("reg no-stores", V(0, 16)), ("reg no-epi", V(0, 32)),
+            ("dma", V(1, 0)), ("dma no-dma", V(1, 2)), ("dma no-barrier", V(1, 4)), ("dma no-reads", V(1, 8)), ("dma mfma+epi", V(1, 14)),
+            ("dma no-stores", V(1, 16)), ("dma no-epi", V(1, 32)), ("dma mfma only", V(1, 46))]
 SHAPES = [(8192, 8192, 8192), (46720, 2048, 2048), (93312, 1152, 3456)]
-if len(sys.argv) > 1:
-    VARIANTS = [v for v in VARIANTS if v[0] in sys.argv[1:] or str(v[2]) in sys.argv[1:]] or VARIANTS
 
-for m, k, n in SHAPES:
+
+def problem(m, k, n):
     a = (torch.randn(m, k, device="cuda") * 0.5).to(BF16)
     w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(BF16)
     lin = PackedLinear(w, torch.zeros(n, dtype=BF16), "cuda")
     c = torch.empty(m, lin.n_pad, dtype=BF16, device="cuda")
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), lin.struct(), c.data_ptr(), c.stride(0), None, 0, 0, m, 0, 0, 0, None, 0)
-    res = {v[0]: [] for v in VARIANTS}
-    for _ in range(2):
-        for name, tile, var in VARIANTS:
-            lib.md_gemm_set_tuning(b"tile", tile)
-            lib.md_gemm_set_tuning(b"w4_variant", var)
-            dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=5, warm=2)
-            res[name].append(2.0 * m * n * k / dt / 1e12)
-    lib.md_gemm_set_tuning(b"tile", -1)
-    lib.md_gemm_set_tuning(b"w4_variant", 0)
-    print(f"m={m} k={k} n={n}: " + " | ".join(f"{nm}: {statistics.median(v):6.0f}" for nm, v in res.items()), flush=True)
+    return a, w, lin, c, args
+
+
+lib.md_gemm_set_tuning(b"tile", 20)
+if "stamps" not in sys.argv[1:]:
+    for m, k, n in SHAPES:
+        keep = problem(m, k, n)
+        args = keep[-1]
+        res = {v[0]: [] for v in VARIANTS}
+        for _ in range(2):
+            for name, var in VARIANTS:
+                lib.md_gemm_set_tuning(b"w4_variant", var)
+                dt = timeit(lambda: _lib.check(lib.md_gemm_bf16(C.byref(args), stream())), iters=5, warm=2)
+                res[name].append(2.0 * m * n * k / dt / 1e12)
+        lib.md_gemm_set_tuning(b"w4_variant", 0)
+        print(f"m={m} k={k} n={n}: " + " | ".join(f"{nm}: {statistics.median(v):6.0f}" for nm, v in res.items()), flush=True)
+        del keep
+
+# stamps: per wave [pairs, cycles first..last stamp, lgkm wait, vmcnt wait, barrier wait, epilogue cycles]
+dbg = torch.zeros(256 * 4 * 8, dtype=torch.float32, device="cuda")
+lib.md_gemm_set_tuning(b"w4_dbg_lo", C.c_int32(dbg.data_ptr() & 0xffffffff).value)
+lib.md_gemm_set_tuning(b"w4_dbg_hi", C.c_int32(dbg.data_ptr() >> 32).value)
+for mode in (1, 3):
+    for m, k, n in SHAPES:
+        keep = problem(m, k, n)
+        args = keep[-1]
+        lib.md_gemm_set_tuning(b"w4_variant", V(mode, 64))
+        for _ in range(3):
+            _lib.check(lib.md_gemm_bf16(C.byref(args), stream()))
+        torch.cuda.synchronize()
+        d = dbg.view(256, 4, 8).cpu()
+        tiles = ((m + 255) // 256) * ((n + 255) // 256)
+        npair = d[:, :, 0]
+        per = d[:, :, 1] / (npair - 1).clamp(min=1)
+        print(f"mode {mode} m={m} k={k} n={n}: pairs/wave {npair.mean():.0f}  cycles per pair (epilogues inside) {per.mean():.0f} "
+              f"| per pair: lgkm wait {(d[:, :, 2] / npair).mean():.0f}  vmcnt wait {(d[:, :, 3] / npair).mean():.0f} "
+              f"(max wave {(d[:, :, 3] / npair).max():.0f})  barrier wait {(d[:, :, 4] / npair).mean():.0f} (max {(d[:, :, 4] / npair).max():.0f}) "
+              f"| epilogue + refill per tile {(d[:, :, 5] / (npair / (k // 64))).mean():.0f} cycles", flush=True)
+        del keep
+lib.md_gemm_set_tuning(b"w4_variant", 0)
+lib.md_gemm_set_tuning(b"tile", -1)

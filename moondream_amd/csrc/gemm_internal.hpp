@@ -60,8 +60,6 @@ md_status md_gemm_f8_qkv_rope(const md_gemm_f8_args* a, const md_rope_fuse* rf, 
 // gemm_w4.hip: the 256x256 tile kernel with one wave per SIMD (4 waves x 128x128), persistent.
 // epi = MD_EPI_*.  Fills tiles_m / tiles_n itself.
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream);
-int md_gemm_w4_residual_max_cols();   // widest residual layer the four-wave kernel takes (its bias vector lives in LDS)
-int md_gemm_w4_max_cols(int epi);     // the same per epilogue kind (bias / GELU layers: 14336 columns)
 bool md_gemm_w4_takes(const GemmK& k, int epi);  // shape limits of the four-wave kernel for this launch
 void md_gemm_w4_set_grid(int v);     // persistent workgroups per launch of the four-wave kernel (0 = one per CU)
 void md_gemm_w4_set_debug(int half, uint32_t v);  // measurement builds: device buffer for in-kernel stamps

@@ -1,40 +1,36 @@
 // bf16 GEMM, big-tile kernel:  C = epilogue(A . W^T + b)  for M > 64 and K % 64 == 0.
 //
-// One workgroup = FOUR waves, one per SIMD, each owning a 128 x 128 quarter of a 256 x 256 tile
-// of C with its 16 accumulator blocks (256 registers) in the accumulator half of the register
-// file, named literally by inline asm.  Per 16-wide K step a wave issues 16
-// v_mfma_f32_32x32x16_bf16 (512 matrix-pipe cycles) for 8 ds_read_b128 -- two thirds of the LDS
-// reads per FLOP of an eight-wave 128 x 64 split, and no second wave on the SIMD to arbitrate with.
-// Because nothing else runs on the SIMD, everything that is not an MFMA is a FILLER placed by hand
-// between two MFMAs (tables below), and since the four waves run in lockstep between barriers the
-// fillers of one kind are spread out evenly so that neither the LDS nor the vector-memory front
-// end sees a burst:
+// One workgroup = FOUR waves, one per SIMD, each owning a 128 x 128 quarter of a 256 x 256 tile of C with its 16
+// accumulator blocks (256 registers) in the accumulator half of the register file, named literally by inline asm.  Per
+// 16-wide K step a wave issues 16 v_mfma_f32_32x32x16_bf16 (512 matrix-pipe cycles) for 8 ds_read_b128.  Nothing else runs
+// on the SIMD, so everything that is not an MFMA is a FILLER placed by hand between two MFMAs (tables below); the four
+// waves run in lockstep between barriers, so fillers of one kind are spread out.
 //
-//   stream of K in PAIRS of 32-wide slices, software pipelined over three levels
-//     HBM/L2 -> registers   raw buffer loads of 8 rows x 128 bytes (whole cache lines; with 64-byte row
-//                           pieces every line crossed L2 -> L1 twice), issued one pair (~2000 cycles) ahead
-//     registers -> LDS      ds_write_b128 into a 4-stage ring (pair being multiplied + pair being written),
-//                           chunk-swizzled on the WRITE side; each register is re-requested right after it
-//                           is written out, so ONE pair's worth of registers carries the whole stream
-//     LDS -> fragments      ds_read_b128 one 16-wide K step ahead of the MFMAs that consume them, waited
-//                           for with COUNTED lgkmcnt (only the fragment an MFMA is first to use)
-//   one s_barrier per pair (64 MFMAs).
+// Operand path (round 4): global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no register round trip, no ds_write.
+//   LDS image   TWO pair buffers of 64 KiB.  A buffer holds 64 K elements ("a pair of 32-wide slices") of the tile's 256
+//               activation rows (32 KiB) and 256 weight rows (32 KiB) as 128-byte rows; logical 16-byte chunk c of row r sits
+//               at physical chunk c ^ ((r >> 1) & 7), so the 16-lane groups of a ds_read_b128 touch 16 distinct bank slots.
+//   LDS-DMA     an instruction moves 8 rows x 128 bytes = whole cache lines (the lane -> LDS mapping is linear: the
+//               permutation sits in the per-lane SOURCE offset); a wave issues 16 per pair, two pairs ahead of the MFMAs
+//               that consume them.  One 32-bit offset register per piece (constant per tile) + one scalar K offset.
+//   fragments   ds_read_b128 one 16-wide K step ahead of the MFMAs that consume them, waited for with COUNTED lgkmcnt
+//               (only the fragment an MFMA is first to use); LDS-DMA is counted by vmcnt, so the count sees reads only.
+//   one s_barrier per pair (64 MFMAs): lgkmcnt(0) (this wave has finished reading the current buffer), vmcnt(0) (its pieces
+//   of the next pair have landed), barrier: the next buffer is published, the current one is released to the DMA stream.
 //
-// (LDS-DMA is deliberately not used here: an LDS-DMA issue costs its wave 60-180 cycles, which a
-// second wave on the SIMD can cover but a lone wave cannot; a buffer load and a ds_write cost a
-// few issue cycles each.)
+// The stream is CONTINUOUS across the tiles of a persistent workgroup (grid = one workgroup per CU, tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ...): the next tile's first pairs are requested under the current tile's last MFMAs and land
+// under its epilogue.
 //
-// The slice stream is CONTINUOUS across the tiles of a persistent workgroup (grid = one
-// workgroup per CU, tiles blockIdx.x, blockIdx.x + gridDim.x, ...): while the last slices of a
-// tile are multiplied, the first slices of the next tile are already being loaded and written, so
-// the epilogue is the only part of a tile that does not overlap with MFMA work.
+// Epilogue (round 4): every layer kind leaves through a 4 KiB per-wave LDS transposition tile, so that a store
+// instruction writes 8 rows x 128 bytes -- WHOLE lines.  (The register-only epilogue of rounds 2-3 wrote 32 rows x 32
+// bytes per instruction; profiles/r04_gemm_w4_lds_dma_ablations_stamps.txt: its stores alone cost 19 % of a K <= 2048
+// layer.)  Software pipelined: pass p + 1 is converted and written to the tile while pass p's 16-byte pieces are in flight
+// back from it; LDS executes a wave's operations in order, which is all the ordering one tile needs.  The tile's bias
+// slice (128 columns per wave) arrives by one small LDS-DMA per tile into a wave-private slot.
 //
-// Numerics: K is accumulated in the same order as every other tile config (sequential 16-wide
-// steps into one fp32 accumulator), so results are bit-identical to them.
-//
-// Measured (profiles/r02_gemm_w4_*): 1.37 PF/s at 8192^3, 1.09-1.26 PF/s on the decoder-prefill / projector
-// shapes, 0.84-0.97 on the K = 1152 ViT shapes (random operands; the chip runs ~1.75 GHz under it: MFMA-busy
-// 70 %, 18 % of wave cycles parked at waits / the barrier).
+// Numerics: K is accumulated in the same order as every other tile config (sequential 16-wide steps into one fp32
+// accumulator), so results are bit-identical to them.
 #include "gemm_internal.hpp"
 
 #include <algorithm>
@@ -43,16 +39,13 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BKT = 32;
-constexpr int ROW_BYTES = BKT * 2;             // 64-byte rows: 4 chunks of 16 bytes
-constexpr int A_BYTES = BM * ROW_BYTES;        // 16 KiB
-constexpr int STAGE = (BM + BN) * ROW_BYTES;   // 32 KiB
-constexpr int RING = 4 * STAGE;                // 128 KiB: the pair of slices being multiplied + the pair being written
-// next to the ring: the layer's whole bias vector (28 KiB), or -- residual layers, whose epilogue transposes through
-// LDS -- four 4 KiB transposition tiles and a bias vector of up to 6144 columns
-constexpr int XPOSE_BYTES = 32 * 128;          // 32 rows x 64 bf16
-constexpr int LDS_BYTES = RING + 14336 * 2;
-template <int EPI> constexpr int bias_max_cols() { return EPI == MD_EPI_RESIDUAL ? (LDS_BYTES - RING - 4 * XPOSE_BYTES) / 2 : (LDS_BYTES - RING) / 2; }
+constexpr int BM = 256, BN = 256;
+constexpr int PBUF = 65536;                    // one pair buffer: 256 A rows + 256 W rows of 128 bytes
+constexpr int W_OFF = 32768;                   // the weight rows' half of a pair buffer
+constexpr int RING = 2 * PBUF;
+constexpr int XPOSE_BYTES = 32 * 128;          // per wave: 32 rows x 64 bf16
+constexpr int BIAS_SLOT = 256;                 // per wave: the bias of its 128 columns
+constexpr int LDS_BYTES = RING + 4 * XPOSE_BYTES + 4 * BIAS_SLOT;
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -67,13 +60,11 @@ __device__ __forceinline__ void ds_read_b128(bf16x8& dst, uint32_t addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
-template <int OFF>
-__device__ __forceinline__ void ds_write_b128(uint32_t addr, const u32x4& v) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
-  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "i"(OFF) : "memory");
-}
 __device__ __forceinline__ void ds_write_b64_asm(uint32_t addr, u32x2 v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ds_write_b32_asm(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ void ds_read_b128_u32(u32x4& dst, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
@@ -124,84 +115,61 @@ __device__ __forceinline__ float acc_read() {
   return v;
 }
 
-// ---- the filler schedule of one PAIR of slices (64 MFMAs, 64 gaps), as compile-time tables --------
-// Fillers are issued right AFTER the MFMA of their gap, in the order read, write, load:
-//   ds_read      every odd gap: 8 fragment reads per 16-gap half, for the half that follows
-//   ds_write     gaps 0, 3, 6, .., 45: the 16 pieces of the NEXT pair of slices (published by the barrier in gap 48)
-//   buffer_load  one gap after each write: the same registers are re-requested for the pair after that
-// The k-th read of a half fetches fragment kReadOrder[k] (0-3 = weight blocks j, 4-7 = activation blocks i) in
-// the order the MFMAs first need them: MFMA m = 4 i + j uses B_j and A_i, so B0 A0 B1 B2 B3 A1 A2 A3 are first
-// used by MFMAs 0 0 1 2 3 4 8 12 of the consuming half.
+// ---- the filler schedule of one PAIR of slices (64 MFMAs, 64 gaps; gap g = right after MFMA g), as compile-time tables ----
+// A pair is four HALVES of 16 MFMAs = the four 16-wide K steps of the pair buffer; MFMA m = 4 i + j of a half multiplies
+// weight block j with activation block i.  The k-th read for a half fetches fragment kReadOrder[k] (0-3 = weight blocks j,
+// 4-7 = activation blocks i) in the order the MFMAs first need them: B0 A0 B1 B2 B3 A1 A2 A3 are first used by MFMAs
+// 0 0 1 2 3 4 8 12 of the consuming half.
+//   ds_read      half 1's fragments in gaps 1, 3, .., 15, half 2's in 17, .., 31, half 3's in 32, 34, .., 46 (EVEN: the last
+//                read of the buffer being multiplied is two MFMAs old at the barrier), the NEXT pair's half 0 in 49, .., 63
+//   gap 48       lgkmcnt(0), vmcnt(0), s_barrier (see the head of the file)
+//   LDS-DMA      the 16 pieces of the pair AFTER the next one, into the buffer the barrier released, at the stream positions
+//                dma_pos() names (48 .. 63 = the rest of this pair, 64 .. = the first gaps of the next pair); a piece has 32+
+//                gaps (1000+ cycles) to land.  MODE picks the placement (profiles/r04_gemm_w4_lds_dma_first_contact.txt).
 constexpr int kReadOrder[8] = {0, 4, 1, 2, 3, 5, 6, 7};
 constexpr int kFirstUse[8] = {0, 0, 1, 2, 3, 4, 8, 12};  // by read position k
-constexpr bool gap_has_write(int g) { return ((g % 64) + 64) % 64 % 3 == 0 && ((g % 64) + 64) % 64 < 48; }
-// LDS operations issued strictly after the read of gap g_issue and before MFMA x_need (gaps along the periodic stream)
-constexpr int lds_ops_between(int g_issue, int x_need) {
-  int n = gap_has_write(g_issue) ? 1 : 0;  // the write of the read's own gap is issued after the read
-  for (int g = g_issue + 1; g < x_need; ++g) n += (((g % 2) + 2) % 2 == 1) + (gap_has_write(g) ? 1 : 0);
-  return n;
-}
-// lgkmcnt to wait for before MFMA m of half h (0..3) of a pair; -1: the MFMA introduces no new fragment.  The
-// fragments of half h are read in gaps 16 (h - 1) + 1 + 2 k  (half 0: at the end of the previous pair).
-constexpr int frag_wait(int h, int m) {
-  int w = -1;
-  for (int k = 0; k < 8; ++k)
-    if (kFirstUse[k] == m) {
-      const int c = lds_ops_between(16 * (h - 1) + 1 + 2 * k, 16 * h + m);
-      w = (w < 0 || c < w) ? c : w;
-    }
-  return w;
-}
-static_assert(frag_wait(0, 0) <= 15 && frag_wait(1, 12) <= 15 && frag_wait(2, 12) <= 15 && frag_wait(3, 0) <= 15, "lgkmcnt is a 4-bit counter");
-
-// ---- MODE >= 1: operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no register round trip ----------
-// LDS image: TWO pair buffers of 64 KiB; a buffer holds 64 K elements of the tile's 256 activation rows (32 KiB) and 256
-// weight rows (32 KiB) as 128-byte rows, logical 16-byte chunk c of row r at physical chunk c ^ ((r >> 1) & 7).  A DMA
-// instruction moves 8 rows x 128 bytes (whole cache lines; the lane -> LDS mapping is linear, so the permutation sits in
-// the per-lane SOURCE offset); a wave issues 16 of them per pair.  Fragment reads: K step s (0-3) of a pair = logical chunks
-// 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63).
-//   filler schedule of one pair (gap g = right after MFMA g):
-//     ds_read      half 1's fragments in gaps 1, 3, .., 15, half 2's in 17, .., 31, half 3's in 32, 34, .., 46 (EVEN: the last
-//                  read of the buffer being multiplied is two MFMAs old at the barrier), the NEXT pair's half 0 in 49, .., 63
-//     gap 48       s_waitcnt lgkmcnt(0) (this wave has finished reading the current buffer), vmcnt(0) (its DMA pieces of the
-//                  next pair have landed), s_barrier: the next buffer is published, the current one is released
-//     LDS-DMA      16 pieces of the pair AFTER the next one into the released buffer, at the gaps dma_pos() names: the
-//                  stream runs two pairs ahead of the MFMAs at issue, a piece has 32+ gaps (1000+ cycles) to land
-constexpr int PBUF = 65536;                     // one pair buffer
 constexpr int kAdvanceGap = 40;                 // the load cursor moves on here: after the last wrapped piece, before gap 48
-constexpr int dma_pos(int mode, int q) {        // stream gap (48 .. 111) at which piece q of pair p + 2 is issued, in body(p) / body(p + 1)
-  return mode == 1 ? (q < 8 ? 48 + 2 * q : 64 + 2 * (q - 8)) : mode == 2 ? 48 + q : 48 + 3 * q;
+constexpr int dma_pos(int mode, int q) {
+  return mode == 1 ? (q < 8 ? 48 + 2 * q : 64 + 2 * (q - 8)) : mode == 2 ? 48 + q : mode == 3 ? 48 + 3 * q : 48 + (5 * q) / 2;
 }
-constexpr bool dma_is_read_gap(int g) {
+constexpr bool modes_ok() {
+  for (int m = 1; m <= 4; ++m)
+    for (int q = 0; q < 16; ++q)
+      if (dma_pos(m, q) < 48 || dma_pos(m, q) - 64 >= kAdvanceGap || (q > 0 && dma_pos(m, q) <= dma_pos(m, q - 1))) return false;
+  return true;
+}
+static_assert(modes_ok(), "pieces are issued in order, from gap 48 on, and the wrapped ones before the cursor advances");
+constexpr bool is_read_gap(int g) {
   const int x = ((g % 64) + 64) % 64;
   return (x < 32 && x % 2 == 1) || (x >= 32 && x < 48 && x % 2 == 0) || (x > 48 && x % 2 == 1);
 }
 // stream position (relative to gap 0 of the consuming pair) of the k-th read of half h
-constexpr int dma_read_pos(int h, int k) { return h == 0 ? -15 + 2 * k : h == 1 ? 1 + 2 * k : h == 2 ? 17 + 2 * k : 32 + 2 * k; }
+constexpr int read_pos(int h, int k) { return h == 0 ? -15 + 2 * k : h == 1 ? 1 + 2 * k : h == 2 ? 17 + 2 * k : 32 + 2 * k; }
 // which (half, k) is read in gap x of a body, encoded 8 h + k; -1: none
-constexpr int dma_read_slot(int x) {
+constexpr int read_slot(int x) {
   for (int h = 0; h < 4; ++h)
     for (int k = 0; k < 8; ++k)
-      if (((dma_read_pos(h, k) % 64) + 64) % 64 == x) return 8 * h + k;
+      if (((read_pos(h, k) % 64) + 64) % 64 == x) return 8 * h + k;
   return -1;
 }
-constexpr int dma_frag_wait(int h, int m) {
+// lgkmcnt to wait for before MFMA m of half h; -1: the MFMA introduces no new fragment
+constexpr int frag_wait(int h, int m) {
   int w = -1;
   for (int k = 0; k < 8; ++k)
     if (kFirstUse[k] == m) {
       int c = 0;
-      for (int g = dma_read_pos(h, k) + 1; g < 16 * h + m; ++g) c += dma_is_read_gap(g) ? 1 : 0;
+      for (int g = read_pos(h, k) + 1; g < 16 * h + m; ++g) c += is_read_gap(g) ? 1 : 0;
       w = (w < 0 || c < w) ? c : w;
     }
   return w;
 }
-static_assert(dma_frag_wait(0, 0) <= 15 && dma_frag_wait(1, 12) <= 15 && dma_frag_wait(2, 12) <= 15 && dma_frag_wait(3, 12) <= 15, "lgkmcnt is a 4-bit counter");
+static_assert(frag_wait(0, 0) <= 15 && frag_wait(1, 12) <= 15 && frag_wait(2, 12) <= 15 && frag_wait(3, 12) <= 15, "lgkmcnt is a 4-bit counter");
 
-// ABL: timing ablations for profiling (bit 0: no ds_write, 1: no global loads, 2: no barrier, 3: no
-// fragment reads, 4: no epilogue stores); results are garbage with any bit set.
+// ABL: measurement builds (bit 1: no operand DMA, 2: no barrier, 3: no fragment reads, 4: no epilogue stores, 5: no
+// epilogue, 6: shader-clock stamps around the waits of gap 48 and the epilogue, 7: every store into one 2 MiB window, 8: sc1
+// stores, 7 + 8: sc0 sc1 stores); results are garbage with bits 1-5 or 7 alone set.
 template <int EPI, int ABL = 0, int MODE = 1>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
-  constexpr bool DMA = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -226,22 +194,17 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     n0 = ((L % per_group) / gsz) * BN;
   };
 
-  // ---- load cursor: one pair of slices (64 K elements) at a time, across tile boundaries --------
-  // A load instruction covers 8 rows x 128 bytes: WHOLE cache lines (with 64-byte row pieces every line
-  // would be fetched twice, once per slice, ~1000 cycles apart, and the 32 KiB L1 does not keep it).  Piece
-  // j (0-7: activations, 8-15: weights) of this thread: row 32 (j & 7) + (tid >> 3), 16-byte chunk c8 = tid & 7
-  // of the row's 128 bytes: chunks 0-3 belong to the even slice of the pair, 4-7 to the odd one.
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffffu, 0x00020000);
+  // ---- load cursor: one pair (64 K elements) at a time, across tile boundaries --------------------------------
+  // Piece j (0-7: activations, 8-15: weights) of this wave: rows 32 (j & 7) + 8 wave + (lane >> 3) of the tile, all 128 bytes
+  // of each.  The lane's LDS slot is fixed (row lane >> 3, physical chunk lane & 7), so it FETCHES the logical chunk that
+  // belongs there.  Rows past M / n_pad are clamped (their products land in rows / columns nobody stores).
   uint32_t voff[16];
   int ld_tile = blockIdx.x, ld_pair = 0;
   uint32_t ld_soff = 0;
   auto set_load_tile = [&](int vv) {
     int m0, n0;
     tile_origin(vv, m0, n0);
-    // r8: this thread's row within a 32-row block (wave w covers rows 8 w .. 8 w + 7 of every block).  DMA modes: the lane's LDS
-    // slot is fixed (row r8, physical chunk tid & 7), so it FETCHES the logical chunk that belongs there
-    const int r8 = tid >> 3, c8 = DMA ? ((tid & 7) ^ ((r8 >> 1) & 7)) : (tid & 7);
+    const int r8 = tid >> 3, c8 = (tid & 7) ^ ((r8 >> 1) & 7);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       voff[j] = (uint32_t)min(m0 + 32 * j + r8, p.M - 1) * (uint32_t)(p.lda * 2) + c8 * 16;
@@ -249,19 +212,35 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     }
   };
   set_load_tile(ld_tile);
-  // DMA modes: the buffer descriptors as four scalar words each (inline asm operand), and the wave's LDS-DMA base:
-  // piece j lands at  pair buffer + (j < 8 ? 0 : 32 KiB) + (j & 7) * 4 KiB + wave * 1 KiB + lane * 16
-  u32x4 rs_a, rs_w;
-  rs_a[0] = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.A);
-  rs_a[1] = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.A >> 32));
-  rs_w[0] = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.W);
-  rs_w[1] = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.W >> 32));
-  rs_a[2] = rs_w[2] = 0xffffffffu;
-  rs_a[3] = rs_w[3] = 0x00020000u;
+  auto advance_load_cursor = [&]() {
+    ld_soff += 128;
+    if (++ld_pair == npair) {
+      ld_pair = 0;
+      ld_soff = 0;
+      // past the end of the stream the cursor stays on the last tile: the DMA keeps going into buffers
+      // nobody reads any more, which keeps the loop free of "is there a next pair" tests
+      if (ld_tile + grid_x < nwg) {
+        ld_tile += grid_x;
+        set_load_tile(ld_tile);
+      }
+    }
+  };
+  // buffer descriptors as four scalar words each (inline-asm operands); piece j lands at
+  //   pair buffer + (j < 8 ? 0 : 32 KiB) + (j & 7) * 4 KiB + wave * 1 KiB + lane * 16
+  auto make_rsrc = [](const void* ptr, uint32_t bytes) {
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ptr);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)ptr >> 32));
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+  };
+  const u32x4 rs_a = make_rsrc(p.A, 0xffffffffu), rs_w = make_rsrc(p.W, 0xffffffffu);
+  const u32x4 rs_bias = make_rsrc(p.bias, (uint32_t)p.n_pad * 2u);  // columns past n_pad (last column tile) read as zero
   const uint32_t dma_lds = lds_base + (uint32_t)wave * 1024u;
   auto dma_piece = [&](auto j_c, uint32_t buf) {
     constexpr int J = decltype(j_c)::value;
-    constexpr int OFF = J < 8 ? J * 4096 : 32768 + (J - 8) * 4096;
+    constexpr int OFF = J < 8 ? J * 4096 : W_OFF + (J - 8) * 4096;
     // (operands copied to locals first: clang does not capture variables that appear only as asm operands of a generic lambda)
     const uint32_t base = dma_lds + buf, vo = voff[J], so = ld_soff;  // base, so: wave-uniform
     const u32x4 rs = J < 8 ? rs_a : rs_w;
@@ -269,75 +248,16 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds" ::"s"(base), "i"(OFF), "v"(vo), "s"(rs), "s"(so) : "memory", "scc");
   };
 
-  u32x4 R[16];  // one pair of slices in registers; each piece is re-requested right after it is written out
-  if constexpr (ABL != 0) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) R[j] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-  }
-  auto load_piece = [&](auto j_c) {
-    constexpr int J = decltype(j_c)::value;
-    if constexpr (ABL & 2)
-      opaque(R[J]);
-    else if constexpr (J < 8)
-      R[J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[J], ld_soff, 0));
-    else
-      R[J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff[J], ld_soff, 0));
-  };
-  auto advance_load_cursor = [&]() {
-    ld_soff += 128;
-    if (++ld_pair == npair) {
-      ld_pair = 0;
-      ld_soff = 0;
-      // past the end of the stream the cursor stays on the last tile: the loads keep going
-      // (their data is never written anywhere that is read), which keeps the loop free of branches
-      if (ld_tile + grid_x < nwg) {
-        ld_tile += grid_x;
-        set_load_tile(ld_tile);
-      }
-    }
-  };
-
-  // ---- the LDS ring: four 32 KiB stages = two pairs, roles swapping after every pair (byte offsets,
-  // wave-uniform).  A stage holds one 32-wide slice: A rows then W rows, 64 bytes each, logical chunk c
-  // of row r at physical chunk c ^ ((r >> 2) & 3) (a ds_read_b128 of one chunk column over a 16-lane
-  // group's rows then touches 16 distinct 16-byte bank slots).  ODD slices additionally store row r at
-  // row r ^ 1: the two halves of a ds_write_b128's 8-lane group (even slice | odd slice of one row)
-  // would otherwise hit the same banks.
-  uint32_t pair_cur = 0, pair_wr = 2 * STAGE;
-  const uint32_t r8w = tid >> 3, c8w = tid & 7;
-  const uint32_t wr_even = lds_base + r8w * ROW_BYTES + (((c8w & 3) ^ ((r8w >> 2) & 3)) * 16);
-  const uint32_t wr_odd = lds_base + STAGE + (r8w ^ 1) * ROW_BYTES + (((c8w & 3) ^ ((r8w >> 2) & 3)) * 16);
-  const uint32_t wr_lane = (c8w < 4) ? wr_even : wr_odd;
-  auto write_piece = [&](auto j_c, uint32_t pair) {
-    constexpr int J = decltype(j_c)::value;
-    if constexpr (ABL & 1)
-      keep_alive(R[J]);
-    else
-      ds_write_b128<(J < 8 ? J * 32 * ROW_BYTES : A_BYTES + (J - 8) * 32 * ROW_BYTES)>(wr_lane + pair, R[J]);
-  };
-
-  // ---- fragment reads: K step s of a slice = logical chunks 2s (lanes 0-31) and 2s+1 (lanes 32-63)
-  const uint32_t swz = (l31 >> 2) & 3;
-  const uint32_t coff[2] = {((0 + hi) ^ swz) * 16, ((2 + hi) ^ swz) * 16};
-  // [slice parity within the pair][K step]
-  uint32_t ra[2][2], rb[2][2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      ra[par][st] = lds_base + par * STAGE + ((wm * 128 + l31) ^ par) * ROW_BYTES + coff[st];
-      rb[par][st] = lds_base + par * STAGE + A_BYTES + ((wn * 128 + l31) ^ par) * ROW_BYTES + coff[st];
-    }
-  // DMA modes: 128-byte rows, [K step 0-3]
+  // ---- fragment reads: K step s (0-3) of a pair = logical chunks 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63) ----------
   const uint32_t swz8 = (l31 >> 1) & 7;
   uint32_t da[4], db[4];
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     da[st] = lds_base + (wm * 128 + l31) * 128 + (((2 * st + hi) ^ swz8) * 16);
-    db[st] = lds_base + 32768 + (wn * 128 + l31) * 128 + (((2 * st + hi) ^ swz8) * 16);
+    db[st] = lds_base + W_OFF + (wn * 128 + l31) * 128 + (((2 * st + hi) ^ swz8) * 16);
   }
   bf16x8 fa[2][4], fb[2][4];  // [fragment set][32-row block]
-  if constexpr (ABL != 0) {
+  if constexpr (ABL & 8) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) fa[0][j] = fa[1][j] = fb[0][j] = fb[1][j] = bf16x8{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   }
@@ -346,96 +266,56 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     if constexpr (ABL & 8) {
       if constexpr (Q < 4) opaque(fb[SET][Q]); else opaque(fa[SET][Q - 4]);
     } else if constexpr (Q < 4)
-      ds_read_b128<Q * 32 * (DMA ? 128 : ROW_BYTES)>(fb[SET][Q], b_addr);
+      ds_read_b128<Q * 4096>(fb[SET][Q], b_addr);
     else
-      ds_read_b128<(Q - 4) * 32 * (DMA ? 128 : ROW_BYTES)>(fa[SET][Q - 4], a_addr);
+      ds_read_b128<(Q - 4) * 4096>(fa[SET][Q - 4], a_addr);
   };
 
   acc_reserve();
 
-  // ---- stream prologue: pair 0 written, pair 1 requested ---------------------------------------
+  // ---- per-wave LDS next to the ring: the transposition tile and the bias slot ------------------------------------
+  const uint32_t tile_lds = lds_base + RING + wave * XPOSE_BYTES;
+  const uint32_t bias_lds = lds_base + RING + 4 * XPOSE_BYTES + wave * BIAS_SLOT;
+  const bool has_bias = p.bias != nullptr;  // uniform
+  if (!has_bias) ds_write_b32_asm(bias_lds + lane * 4, 0u);  // a layer without bias adds the zeros of a slot that is never refilled
+  uint32_t bias_soff = 0;  // byte offset of the current tile's (wave's) first bias column
+  auto dma_bias = [&]() {
+    const uint32_t base = bias_lds, vo = (uint32_t)lane * 4u, so = bias_soff;
+    const u32x4 rs = rs_bias;
+    if (has_bias) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(base), "v"(vo), "s"(rs), "s"(so) : "memory");
+  };
+
+  // ---- stream prologue: pair 0 whole, and the pieces of pair 1 that the steady state issues at the END of a body -------
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  uint32_t pair_cur = 0, pair_wr = PBUF;  // byte offsets of the buffer being multiplied / the other one
   // the first fragments (K step 0) of the pair in pair_cur, all eight, waited for: stream start and after every epilogue
   auto read_first_frags = [&]() {
-    const uint32_t a0 = (DMA ? da[0] : ra[0][0]) + pair_cur, b0 = (DMA ? db[0] : rb[0][0]) + pair_cur;
+    const uint32_t a0 = da[0] + pair_cur, b0 = db[0] + pair_cur;
     static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, a0, b0); });
     wait_lgkm<0>();
     MD_PIN();
   };
-  if constexpr (!DMA) {
-    static_for<0, 16>([&](auto j) { load_piece(j); });
-    advance_load_cursor();
-    asm volatile("" ::: "memory");
-    static_for<0, 16>([&](auto j) { write_piece(j, pair_cur); });
-    asm volatile("" ::: "memory");
-    static_for<0, 16>([&](auto j) { load_piece(j); });
-    advance_load_cursor();
-    wait_lgkm<0>();
-  } else {
-    // pair 0 whole, and the pieces of pair 1 that the steady state issues at the END of a body (dma_pos < 64)
-    static_for<0, 16>([&](auto j) { dma_piece(j, pair_cur); });
-    advance_load_cursor();
-    static_for<0, 16>([&](auto j) {
-      if constexpr (dma_pos(MODE, decltype(j)::value) < 64) dma_piece(j, pair_wr);
-    });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  static_for<0, 16>([&](auto j) { dma_piece(j, pair_cur); });
+  advance_load_cursor();
+  static_for<0, 16>([&](auto j) {
+    if constexpr (dma_pos(MODE, decltype(j)::value) < 64) dma_piece(j, pair_wr);
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_first_frags();
 
-  // One pair of slices = 64 MFMAs = 64 gaps (four halves of 16: even slice K steps 0, 1, odd slice K steps 0, 1;
-  // fragment sets 0, 1, 0, 1).  The four waves run in lockstep between barriers, so whatever one wave does in a
-  // gap all four do: fillers of one kind are spread out so that neither the LDS nor the vector-memory front end
-  // sees a burst.  The pair being written was requested one pair (64 gaps, ~2000 cycles) earlier.  The barrier in
-  // gap 48 publishes it (every wave drains its own writes first); its stages were last read in gap 47 of the
-  // PREVIOUS pair, before that pair's barrier.  ONE straight-line body, no branch inside it (a second code path
-  // would be a join over ~200 live registers); past the end of the stream the fillers keep running on data nobody reads.
-  auto pair_body_reg = [&](auto first_c) {
-    constexpr bool FIRST = decltype(first_c)::value;  // first K step of a tile: accumulate onto zero
-    const uint32_t a_e1 = ra[0][1] + pair_cur, b_e1 = rb[0][1] + pair_cur;   // even slice, K step 1
-    const uint32_t a_o0 = ra[1][0] + pair_cur, b_o0 = rb[1][0] + pair_cur;   // odd slice, K step 0
-    const uint32_t a_o1 = ra[1][1] + pair_cur, b_o1 = rb[1][1] + pair_cur;   // odd slice, K step 1
-    const uint32_t a_n0 = ra[0][0] + pair_wr, b_n0 = rb[0][0] + pair_wr;     // next pair's even slice, K step 0
-    const uint32_t wr = pair_wr;
-    static_for<0, 64>([&](auto xc) {
-      constexpr int X = decltype(xc)::value, H = X / 16, M = X % 16, I = M / 4, J = M % 4, SET = H & 1;
-      if constexpr (X == 48 && !(ABL & 4)) {
-        // this wave's writes (the last one in gap 45; one younger read in gap 47) are complete
-        wait_lgkm<1>();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      // counted wait: the fragments this MFMA is the first to use have landed, younger LDS operations stay in flight
-      if constexpr (frag_wait(H, M) >= 0 && !(ABL & 8)) wait_lgkm<frag_wait(H, M)>();
-      mfma_acc<M, FIRST && H == 0>(fb[SET][J], fa[SET][I]);
-      MD_PIN();
-      if constexpr (X % 2 == 1) {
-        using Q = std::integral_constant<int, kReadOrder[(X % 16) / 2]>;
-        if constexpr (H == 0) read_frag(I1{}, Q{}, a_e1, b_e1);
-        if constexpr (H == 1) read_frag(I0{}, Q{}, a_o0, b_o0);
-        if constexpr (H == 2) read_frag(I1{}, Q{}, a_o1, b_o1);
-        if constexpr (H == 3) read_frag(I0{}, Q{}, a_n0, b_n0);
-      }
-      if constexpr (X % 3 == 0 && X < 48) write_piece(std::integral_constant<int, X / 3>{}, wr);
-      if constexpr (X % 3 == 1 && X < 48) load_piece(std::integral_constant<int, X / 3>{});
-      MD_PIN();
-    });
-    advance_load_cursor();
-    const uint32_t t = pair_cur;  // swap the roles of the two pairs of stages
-    pair_cur = pair_wr;
-    pair_wr = t;
-  };
-  // The same pair with the operands arriving by LDS-DMA (schedule: the tables above).  pair_cur = the buffer being
-  // multiplied, pair_wr = the other one: it receives the late pieces of the NEXT pair in the first gaps, is published by
-  // the barrier in gap 48, and is read from gap 49 on; from gap 48 on pair_cur receives the pair after that.
   // measurement build (ABL & 64): shader-clock stamps around the waits of gap 48 (s_memtime is counted by lgkmcnt: only here,
   // where the counter is drained anyway)
   uint32_t st_lgkm = 0, st_vm = 0, st_bar = 0, st_n = 0;
   uint64_t st_first = 0, st_last = 0, st_epi = 0;
-  auto pair_body_dma = [&](auto first_c) {
-    constexpr bool FIRST = decltype(first_c)::value;
+
+  // One pair = 64 MFMAs = 64 gaps.  pair_cur = the buffer being multiplied, pair_wr = the other one: it receives the late
+  // pieces of the NEXT pair in the first gaps, is published by the barrier in gap 48 and read from gap 49 on; from gap 48 on
+  // pair_cur receives the pair after that.  ONE straight-line body but for the cursor's once-per-tile branch in gap 40;
+  // past the end of the stream the fillers keep running on data nobody reads.
+  auto pair_body = [&](auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;  // first pair of a tile: accumulate onto zero, request the tile's bias slice
     const uint32_t a1 = da[1] + pair_cur, b1 = db[1] + pair_cur, a2 = da[2] + pair_cur, b2 = db[2] + pair_cur;
     const uint32_t a3 = da[3] + pair_cur, b3 = db[3] + pair_cur, an = da[0] + pair_wr, bn = db[0] + pair_wr;
     const uint32_t buf_cur = pair_cur, buf_nxt = pair_wr;
@@ -459,10 +339,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
       }
-      if constexpr (dma_frag_wait(H, M) >= 0 && !(ABL & 8)) wait_lgkm<dma_frag_wait(H, M)>();
+      // counted wait: the fragments this MFMA is the first to use have landed, younger reads stay in flight
+      if constexpr (frag_wait(H, M) >= 0 && !(ABL & 8)) wait_lgkm<frag_wait(H, M)>();
       mfma_acc<M, FIRST && H == 0>(fb[SET][J], fa[SET][I]);
       MD_PIN();
-      constexpr int RS = dma_read_slot(X);
+      constexpr int RS = read_slot(X);
       if constexpr (RS >= 0) {
         using Q = std::integral_constant<int, kReadOrder[RS % 8]>;
         if constexpr (RS / 8 == 1) read_frag(I1{}, Q{}, a1, b1);
@@ -475,6 +356,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
         if constexpr (dma_pos(MODE, Q) == X) dma_piece(qc, buf_cur);        // pair p + 2 -> the buffer released in gap 48
         if constexpr (dma_pos(MODE, Q) - 64 == X) dma_piece(qc, buf_nxt);   // late pieces of pair p + 1
       });
+      if constexpr (FIRST && X == 41) dma_bias();  // the slot's previous contents went to registers in the last epilogue
       if constexpr (X == kAdvanceGap) advance_load_cursor();
       MD_PIN();
     });
@@ -482,26 +364,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     pair_cur = pair_wr;
     pair_wr = t;
   };
-  auto pair_body = [&](auto first_c) {
-    if constexpr (DMA) pair_body_dma(first_c); else pair_body_reg(first_c);
-  };
 
   // ---- tile loop ------------------------------------------------------------------------------
-  // The layer's bias vector goes to LDS once per launch: a global load inside the epilogue would have to wait for
-  // every older operand load of the running stream (loads return in order), i.e. drain the prefetch once per tile.
-  const uint32_t tile_lds = lds_base + RING + wave * XPOSE_BYTES;  // residual epilogue only
-  const uint32_t bias_lds = lds_base + RING + (EPI == MD_EPI_RESIDUAL ? 4 * XPOSE_BYTES : 0);
-  const bool bias_in_lds = p.n_pad <= bias_max_cols<EPI>();
-  if (bias_in_lds) {
-    for (int c = tid * 4; c < p.n_pad; c += 256 * 4) {
-      u32x2 bw = {0u, 0u};
-      if (p.bias != nullptr) bw = *(const u32x2*)(p.bias + c);
-      ds_write_b64_asm(bias_lds + c * 2, bw);
-    }
-    wait_lgkm<0>();
-    __syncthreads();
-  }
   for (int vtile = blockIdx.x; vtile < nwg; vtile += grid_x) {
+    int m0c, n0c;
+    tile_origin(vtile, m0c, n0c);
+    const int wm0 = m0c + wm * 128, wn0 = n0c + wn * 128;
+    bias_soff = (uint32_t)wn0 * 2u;
     // the accumulators are (re)defined by the first K step of every tile: nothing is carried from
     // one tile to the next in them
     pair_body(std::true_type{});
@@ -511,106 +380,17 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     uint64_t te0 = 0;
     if constexpr (ABL & 64) { te0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-    // ---- epilogue of tile vtile (the next tile's first slices are already in the ring / in flight)
+    // ---- epilogue of tile vtile (the next tile's first pairs are already in the ring / in flight) ----------------------
     // block X = 4 i + j, register r: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)   within the wave's quarter
-    int m0c, n0c;
-    tile_origin(vtile, m0c, n0c);
-    const int wm0 = m0c + wm * 128, wn0 = n0c + wn * 128;
-    if constexpr (ABL & 32) {
-      // measurement build: no epilogue at all (what a tile costs without one)
-    } else if constexpr (EPI == MD_EPI_RESIDUAL) {
-    // Residual layers keep the LDS transposition: their second operand is read in whole 128-byte row pieces (the
-    // register-only path below reads / writes 32-byte pieces, which costs these short-K, narrow-N layers 5 % --
-    // profiles/r02_gemm_w4_epilogue_variants.txt).
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
-    // eight passes of 32 rows x 64 columns (row block i, column half jp): bias add + ONE bf16 rounding on the
-    // accumulator layout, transposition through the wave's 4 KiB LDS tile, then GELU / residual and the global
-    // stores on whole 16-byte row pieces.  Piece q of this lane: row (q*64 + lane) >> 3, chunk (q*64 + lane) & 7.
-    // Piece q of this lane in pass (i, jp): row 32 i + 8 q + (lane >> 3), columns 64 jp + 8 (lane & 7) .. + 7.  Residual
-    // loads and result stores go through buffer resources over R and C (num_records = M rows): rows past M read as zero /
-    // are dropped by the range check, the address is one 32-bit offset per (i, q) -- a scalar multiple of the 8-row step
-    // added to the lane's base -- and the column half is an immediate (the per-piece m / n tests, 64-bit address arithmetic
-    // and exec-mask branches were ~600 of this epilogue's VALU instructions per tile).
-    const int lane_row = lane >> 3, lane_col = (lane & 7) * 8;
-    const __amdgpu_buffer_rsrc_t rsrc_cr = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)min((uint64_t)p.M * (uint64_t)p.ldc * 2, (uint64_t)0xffffffffu), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)p.R, 0, (int)min((uint64_t)(p.res_row_mod ? p.res_row_mod : p.M) * (uint64_t)p.ldr * 2, (uint64_t)0xffffffffu), 0x00020000);
-    const bool col_ok0 = wn0 + lane_col < p.n_store, col_ok1 = wn0 + 64 + lane_col < p.n_store;
-    const uint32_t col_bytes = (uint32_t)(wn0 + lane_col) * 2u;
-    const uint32_t c_base = (uint32_t)(wm0 + lane_row) * (uint32_t)(p.ldc * 2) + col_bytes;
-    const uint32_t c_step = (uint32_t)p.ldc * 16u;  // 8 rows
-    // residual row of this lane's first piece; a broadcast residual wraps at res_row_mod (>= 256: at most one wrap per tile)
-    const uint32_t wrap = p.res_row_mod ? (uint32_t)p.res_row_mod : 0x7fffffffu;
-    const uint32_t r_row0 = (uint32_t)(wm0 + lane_row) % wrap;
-    auto load_residual = [&](int pass, u32x4 (&rv)[4]) {
-      const int i = pass >> 1, jp = pass & 1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint32_t row = r_row0 + 8u * (uint32_t)(4 * i + q);
-        row -= (row >= wrap) ? wrap : 0u;
-        const uint32_t off = (jp ? col_ok1 : col_ok0) ? row * (uint32_t)(p.ldr * 2) + col_bytes : 0xfffff000u;
-        rv[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off + 128 * jp, 0, 0));
-      }
-    };
-    auto store_off = [&](int i, int q, int jp) -> uint32_t {
-      const uint32_t off = c_base + (uint32_t)(4 * i + q) * c_step;
-      return ((jp ? col_ok1 : col_ok0) ? off : 0xfffff000u) + 128 * jp;  // columns past n_store (last column tile): out of range
-    };
-    u32x4 rres[2][4];
-    if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
-    // this lane's 16 bias quads, once per tile (not per pass: one LDS round trip less on every pass)
-    u32x2 bias_r[4][4];
-    static_for<0, 16>([&](auto jq) {
-      constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
-      ds_read_b64_u32<(32 * j + 8 * q) * 2>(bias_r[j][q], bias_lds + (wn0 + 4 * hi) * 2);
-    });
-    wait_lgkm<0>();
-    MD_PIN();
-    static_for<0, 8>([&](auto pc) {
-      constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
-      if constexpr (EPI == MD_EPI_RESIDUAL && PASS + 1 < 8) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
-      MD_PIN();
-      static_for<0, 8>([&](auto jq) {
-        constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4, base = 16 * (4 * i + 2 * jp + jj) + 4 * q;
-        u32x2 w;
-        w[0] = pack_bf16x2(acc_read<base + 0>() + lo_bf(bias_r[2 * jp + jj][q][0]), acc_read<base + 1>() + hi_bf(bias_r[2 * jp + jj][q][0]));
-        w[1] = pack_bf16x2(acc_read<base + 2>() + lo_bf(bias_r[2 * jp + jj][q][1]), acc_read<base + 3>() + hi_bf(bias_r[2 * jp + jj][q][1]));
-        constexpr int ch = 4 * jj + q;
-        ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, w);
-      });
-      MD_PIN();
-      u32x4 tv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
-        ds_read_b128_u32(tv[q], tile_lds + row * 128 + ((ch ^ (row & 7)) * 16));
-      }
-      wait_lgkm<0>();
-      MD_PIN();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        u32x4 v = tv[q];
-        if constexpr (EPI == MD_EPI_RESIDUAL) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][q][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][q][e]) + hi_bf(v[e]));
-        }
-        const uint32_t off = store_off(i, q, jp);
-        if constexpr (ABL & 128) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_cr, off, 0, 2);
-        else if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_cr, off, 0, 0);
-        else keep_alive(v);
-      }
-      MD_PIN();
-    });
-    } else {
-    // ---- bias / GELU layers: registers only, no trip through LDS --------------------------------------------------
-    // This lane's 64 bias values (column 32 j + 8 q + 4 hi + e), unpacked ONCE per tile from the LDS-resident vector (they
-    // are reused by the four row blocks: unpacking at every use cost 256 of the epilogue's ~1150 VALU instructions).
+    if constexpr (!(ABL & 32)) {
+    // This lane's 64 bias values (column 32 j + 8 q + 4 hi + e), unpacked ONCE per tile from the wave's slot.  (npair == 1: the
+    // slot's DMA was waited for by gap 48's vmcnt(0) like every other piece.)
     md_f32x2 bias_f[4][4][2];
     {
       u32x2 bw[4][4];
       static_for<0, 16>([&](auto jq) {
         constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
-        ds_read_b64_u32<(32 * j + 8 * q) * 2>(bw[j][q], bias_lds + (wn0 + 4 * hi) * 2);
+        ds_read_b64_u32<(32 * j + 8 * q) * 2>(bw[j][q], bias_lds + 8 * hi);
       });
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
       wait_lgkm<0>();
@@ -623,54 +403,100 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
           bias_f[j][q][1] = md_f32x2{lo_bf(bw[j][q][1]), hi_bf(bw[j][q][1])};
         }
     }
-    // Stores go through a buffer resource over C with num_records = M x ldc x 2 bytes: rows past M are dropped by the range
-    // check (no exec masking, no branch), the address is ONE 32-bit row offset per row block plus an immediate per piece
-    // (per-store 64-bit address arithmetic and an exec-mask branch were another ~320 instructions per tile).  Columns past
-    // n_store exist only in a layer's last column tile: there the offset of an out-of-range piece is pushed out of range.
+    // C (and a residual R) are addressed through buffer resources with num_records = M rows: rows past M read as zero / are
+    // dropped by the range check (no exec masking, no branch); an address is one 32-bit offset.
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)min((uint64_t)p.M * (uint64_t)p.ldc * 2, (uint64_t)0xffffffffu), 0x00020000);
-    const bool full_cols = wn0 + 128 <= p.n_store;   // wave-uniform
-    // Eight passes of 32 rows x 64 columns (row block i, column half jp).  Bias add + ONE bf16 rounding happen on the
-    // accumulator layout (a lane: one row, quads of 4 consecutive columns; the two lane halves hold the two quads of an
-    // 8-column group).  Two v_permlane32_swap per pair of groups hand every lane a full 16-byte row piece -- lanes
-    // 0-31 the even group, lanes 32-63 the odd one, adjacent in memory -- so GELU and the global stores work on
-    // 16-byte pieces: piece t of a pass: row l31, columns 64 jp + 32 (t >> 1) + 16 (t & 1) + 8 hi.
-    auto store_tile = [&](auto full_c) {
-    constexpr bool FULL = decltype(full_c)::value;  // every column of this wave's 128 is inside n_store: no per-piece test
-    static_for<0, 8>([&](auto pc) {
-      constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
-      const uint32_t row_off = (uint32_t)(wm0 + 32 * i + l31) * (uint32_t)(p.ldc * 2) + (uint32_t)(wn0 + 8 * hi) * 2u;
-      static_for<0, 4>([&](auto tc) {
-        // piece t: groups q = 2 (t & 1) and q + 1 of column block j = 2 jp + (t >> 1)
-        constexpr int T = decltype(tc)::value, j = 2 * jp + (T >> 1), q0 = 2 * (T & 1);
-        constexpr int base0 = 16 * (4 * i + j) + 4 * q0, base1 = base0 + 4;
-        const md_f32x2 x0 = md_f32x2{acc_read<base0 + 0>(), acc_read<base0 + 1>()} + bias_f[j][q0][0];
-        const md_f32x2 x1 = md_f32x2{acc_read<base0 + 2>(), acc_read<base0 + 3>()} + bias_f[j][q0][1];
-        const md_f32x2 y0 = md_f32x2{acc_read<base1 + 0>(), acc_read<base1 + 1>()} + bias_f[j][q0 + 1][0];
-        const md_f32x2 y1 = md_f32x2{acc_read<base1 + 2>(), acc_read<base1 + 3>()} + bias_f[j][q0 + 1][1];
-        const uint32_t a0 = pack_bf16x2(x0[0], x0[1]), a1 = pack_bf16x2(x1[0], x1[1]);
-        const uint32_t b0 = pack_bf16x2(y0[0], y0[1]), b1 = pack_bf16x2(y1[0], y1[1]);
-        // swap(x, y): x' = {x of lanes 0-31, y of lanes 0-31}, y' = {x of lanes 32-63, y of lanes 32-63}
-        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
-        if constexpr (EPI == MD_EPI_GELU || EPI == MD_EPI_QKV_ROPE) {
-          if (wn0 + 32 * j >= p.gelu_from) {  // wave-uniform: gelu_from is a multiple of 64 (fused [qkv | fc1] layers)
+    // ---- the generic path: eight passes of 32 rows x 64 columns (row block i, column half jp) through the wave's LDS tile ----
+    // write side, on the accumulator layout: bias add + ONE bf16 rounding (F.linear's rounding point), a lane's quad of 4
+    // columns = 8 bytes at row l31, chunk (4 jj + q) ^ (l31 & 7), half hi.  Read side: piece q of this lane = row 8 q +
+    // (lane >> 3), columns 8 (lane & 7) .. + 7 of the pass: 8 lanes cover a row's 128 bytes, an instruction 8 whole lines.
+    // GELU / the residual add work on those 16-byte pieces.  Pass p + 1 is converted and written while pass p's pieces are
+    // in flight back (LDS executes a wave's operations in order: read p, write p + 1, read p + 1 need no waits between them).
+    auto lds_epilogue = [&]() {
+      const int lane_row = lane >> 3, lane_col = (lane & 7) * 8;
+      const bool col_ok0 = wn0 + lane_col < p.n_store, col_ok1 = wn0 + 64 + lane_col < p.n_store;  // columns past n_store: last column tile only
+      const uint32_t col_bytes = (uint32_t)(wn0 + lane_col) * 2u;
+      const uint32_t c_base = (uint32_t)(wm0 + lane_row) * (uint32_t)(p.ldc * 2) + col_bytes;
+      const uint32_t c_step = (uint32_t)p.ldc * 16u;  // 8 rows
+      auto store_off = [&](int i, int q, int jp) -> uint32_t {
+        const uint32_t off = c_base + (uint32_t)(4 * i + q) * c_step;
+        return ((jp ? col_ok1 : col_ok0) ? off : 0xfffff000u) + 128 * jp;  // out of range: dropped
+      };
+      // residual layers: the second operand in the same whole-line pieces, prefetched one pass ahead; a broadcast residual
+      // (the ViT's position embedding) wraps at res_row_mod (>= 256: at most one wrap per tile)
+      const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)p.R, 0, (int)min((uint64_t)(p.res_row_mod ? p.res_row_mod : p.M) * (uint64_t)p.ldr * 2, (uint64_t)0xffffffffu), 0x00020000);
+      const uint32_t wrap = p.res_row_mod ? (uint32_t)p.res_row_mod : 0x7fffffffu;
+      const uint32_t r_row0 = (uint32_t)(wm0 + lane_row) % wrap;
+      auto load_residual = [&](int pass, u32x4 (&rv)[4]) {
+        const int i = pass >> 1, jp = pass & 1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const md_f32x2 ge = gelu_tanh_f32x2(md_f32x2{lo_bf(v[e]), hi_bf(v[e])});
-              v[e] = pack_bf16x2(ge[0], ge[1]);
+        for (int q = 0; q < 4; ++q) {
+          uint32_t row = r_row0 + 8u * (uint32_t)(4 * i + q);
+          row -= (row >= wrap) ? wrap : 0u;
+          const uint32_t off = (jp ? col_ok1 : col_ok0) ? row * (uint32_t)(p.ldr * 2) + col_bytes : 0xfffff000u;
+          rv[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off + 128 * jp, 0, 0));
+        }
+      };
+      auto convert_write = [&](auto pc) {
+        constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
+        static_for<0, 8>([&](auto jq) {
+          constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4, j = 2 * jp + jj, base = 16 * (4 * i + j) + 4 * q;
+          const md_f32x2 x0 = md_f32x2{acc_read<base + 0>(), acc_read<base + 1>()} + bias_f[j][q][0];
+          const md_f32x2 x1 = md_f32x2{acc_read<base + 2>(), acc_read<base + 3>()} + bias_f[j][q][1];
+          constexpr int ch = 4 * jj + q;
+          ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, u32x2{pack_bf16x2(x0[0], x0[1]), pack_bf16x2(x1[0], x1[1])});
+        });
+      };
+      auto read_pieces = [&](u32x4 (&tv)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+          ds_read_b128_u32(tv[q], tile_lds + row * 128 + ((ch ^ (row & 7)) * 16));
+        }
+      };
+      u32x4 tv[2][4], rres[2][4];
+      if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
+      convert_write(I0{});
+      read_pieces(tv[0]);
+      MD_PIN();
+      static_for<0, 8>([&](auto pc) {
+        constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
+        if constexpr (PASS + 1 < 8) {
+          if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
+          convert_write(std::integral_constant<int, PASS + 1>{});
+          wait_lgkm<8>();  // this pass's four reads are back; the next pass's eight writes may still be on their way
+        } else {
+          wait_lgkm<0>();
+        }
+        MD_PIN();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x4 v = tv[PASS & 1][q];
+          if constexpr (EPI == MD_EPI_GELU || EPI == MD_EPI_QKV_ROPE) {
+            if (wn0 + 64 * jp >= p.gelu_from) {  // wave-uniform: gelu_from is a multiple of 64 (fused [qkv | fc1] layers)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const md_f32x2 ge = gelu_tanh_f32x2(md_f32x2{lo_bf(v[e]), hi_bf(v[e])});
+                v[e] = pack_bf16x2(ge[0], ge[1]);
+              }
             }
           }
+          if constexpr (EPI == MD_EPI_RESIDUAL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][q][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][q][e]) + hi_bf(v[e]));
+          }
+          const uint32_t off = store_off(i, q, jp);
+          if constexpr ((ABL & (128 | 256)) == 128) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off & 0x1fffffu, 0, 0);  // every store into one 2 MiB window
+          else if constexpr ((ABL & (128 | 256)) == 256) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off, 0, 16);       // sc1
+          else if constexpr ((ABL & (128 | 256)) == 384) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off, 0, 17);       // sc0 sc1
+          else if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off, 0, 0);
+          else keep_alive(v);
         }
-        constexpr int col_off = (32 * j + 8 * q0) * 2;  // bytes from the row offset's column (wn0 + 8 hi)
-        uint32_t off = row_off;
-        if constexpr (!FULL) off = (wn0 + 32 * j + 8 * (q0 + hi) < p.n_store) ? row_off : 0xfffff000u;  // out of range: dropped
-        if constexpr (ABL & 128) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off + col_off, 0, 2);
-        else if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off + col_off, 0, 0);
-        else keep_alive(v);
+        MD_PIN();
+        if constexpr (PASS + 1 < 8) read_pieces(tv[(PASS + 1) & 1]);
+        MD_PIN();
       });
-      MD_PIN();
-    });
     };
     // ---- MD_EPI_QKV_ROPE: the q / k / v sections of the decoder's fused layer at prefill ------------------------------
     // A wave's 128 columns are two heads of ONE section (sections are n_heads x 64 wide, a multiple of 128).  Per head the
@@ -771,20 +597,17 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       });
     };
     if constexpr (EPI == MD_EPI_QKV_ROPE) {
-      if (wn0 < 3 * p.rope_d) rope_tile();
-      else if (full_cols) store_tile(std::true_type{});
-      else store_tile(std::false_type{});
+      if (wn0 < 3 * p.rope_d) rope_tile(); else lds_epilogue();
     } else {
-      if (full_cols) store_tile(std::true_type{}); else store_tile(std::false_type{});
+      lds_epilogue();
     }
     }
-    if constexpr (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
     // registers the epilogue does not have to carry); its first pair was published by the last barrier above
     read_first_frags();
     if constexpr (ABL & 64) { st_epi += __builtin_readcyclecounter() - te0; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   }
-  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of the run-on stream in flight at the end of the wave
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of the run-on stream in flight at the end of the wave
   if constexpr (ABL & 64) {
     if (lane == 0 && p.slabs != nullptr) {
       float* o = p.slabs + (blockIdx.x * 4 + wave) * 8;
@@ -794,13 +617,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
 }
 
 int g_w4_grid = 0;     // md_gemm_set_tuning "w4_grid": persistent workgroups per launch (0 = one per CU); a multiple of 8
-// md_gemm_set_tuning "w4_variant": low 4 bits = operand path / schedule (MODE: 0 register-staged, 1-3 LDS-DMA schedules; 2 and 3
-// exist for the bias epilogue only), the rest 16 * ABL (measurement builds, bias epilogue only)
+// md_gemm_set_tuning "w4_variant" (MD_W4_VARIANT): low 4 bits = placement of the LDS-DMA pieces (MODE, 0 = the default;
+// the others exist for the bias epilogue only), the rest 16 * ABL (measurement builds, bias epilogue only)
 int g_w4_variant = [] { const char* e = getenv("MD_W4_VARIANT"); return (e && *e) ? atoi(e) : 0; }();
-
 uint64_t g_w4_debug = 0;  // measurement builds: device buffer for the in-kernel stamps (md_gemm_set_tuning "w4_dbg_lo" / "w4_dbg_hi")
+constexpr int kDefaultMode = 1;
 
-template <int EPI, int ABL = 0, int MODE = 1>
+template <int EPI, int ABL = 0, int MODE = kDefaultMode>
 md_status launch(const GemmK& k, hipStream_t stream) {
   auto fn = gemm_w4_kernel<EPI, ABL, MODE>;
   MD_TRY(md_ensure_dynamic_lds((const void*)fn, LDS_BYTES));
@@ -814,28 +637,14 @@ md_status launch(const GemmK& k, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? (n / 8) * 8 : 256;  // a multiple of 8 keeps (sequence number % 8) == XCD for the tile-order remap
   }();
-  // one persistent workgroup per CU -- or fewer ("w4_grid"): a workgroup owns its CU (156 KiB of LDS, the whole register file),
+  // one persistent workgroup per CU -- or fewer ("w4_grid"): a workgroup owns its CU (145 KiB of LDS, the whole register file),
   // so a smaller grid leaves whole CUs to kernels of another stream (the pipelined engine's decode steps)
   const int gx = std::min(nwg, g_w4_grid > 0 ? std::min(g_w4_grid, n_cu) : n_cu);
   hipLaunchKernelGGL(fn, dim3(gx), dim3(256), LDS_BYTES, stream, kk);
   return md_launch_status();
 }
 
-template <int MODE>
-md_status launch_mode(const GemmK& k, int epi, hipStream_t stream) {
-  switch (epi) {
-    case MD_EPI_BIAS: return launch<MD_EPI_BIAS, 0, MODE>(k, stream);
-    case MD_EPI_GELU: return launch<MD_EPI_GELU, 0, MODE>(k, stream);
-    case MD_EPI_RESIDUAL: return launch<MD_EPI_RESIDUAL, 0, MODE>(k, stream);
-    case MD_EPI_QKV_ROPE: return launch<MD_EPI_QKV_ROPE, 0, MODE>(k, stream);
-    default: return MD_ERR_INVALID_ARG;
-  }
-}
-
 }  // namespace
-
-int md_gemm_w4_residual_max_cols() { return bias_max_cols<MD_EPI_RESIDUAL>(); }
-int md_gemm_w4_max_cols(int epi) { return epi == MD_EPI_RESIDUAL ? bias_max_cols<MD_EPI_RESIDUAL>() : bias_max_cols<MD_EPI_BIAS>(); }
 
 void md_gemm_w4_set_variant(int v) { g_w4_variant = v; }
 void md_gemm_w4_set_debug(int half, uint32_t v) { g_w4_debug = half ? ((g_w4_debug & 0xffffffffull) | ((uint64_t)v << 32)) : ((g_w4_debug & ~0xffffffffull) | v); }
@@ -845,8 +654,6 @@ bool md_gemm_w4_takes(const GemmK& k, int epi) {
   if (k.K % 64 != 0 || k.M <= 0) return false;
   // 32-bit byte offsets into A and W
   if ((uint64_t)k.M * (uint64_t)k.lda * 2 >= (1ull << 32) || (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32)) return false;
-  // every epilogue takes its bias from the LDS-resident vector only (md_gemm_bf16 sends wider layers to the eight-wave kernel)
-  if (k.n_pad > md_gemm_w4_max_cols(epi)) return false;
   // C (and a residual R) are addressed through buffer resources with 32-bit byte offsets: the rows of the last, partial
   // row tile must stay below the out-of-range sentinel without wrapping
   const uint64_t lim = 0xfffff000ull, rows = (uint64_t)k.M + 256;
@@ -861,14 +668,10 @@ bool md_gemm_w4_takes(const GemmK& k, int epi) {
 md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   if (k.K % 64 != 0 || k.M <= 0) return MD_ERR_INVALID_ARG;
   if (!md_gemm_w4_takes(k, epi)) return MD_ERR_UNSUPPORTED;
-  const int mode = g_w4_variant & 15, abl = g_w4_variant >> 4;  // (ablation codes: mode + 16 * ABL)
+  const int mode = g_w4_variant & 15, abl = g_w4_variant >> 4;  // (measurement codes: MODE + 16 * ABL)
 #ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
   if (epi == MD_EPI_BIAS && abl != 0) {
     switch (256 * mode + abl) {
-      case 256 * 0 + 2: return launch<MD_EPI_BIAS, 2, 0>(k, stream);
-      case 256 * 0 + 8: return launch<MD_EPI_BIAS, 8, 0>(k, stream);
-      case 256 * 0 + 16: return launch<MD_EPI_BIAS, 16, 0>(k, stream);
-      case 256 * 0 + 32: return launch<MD_EPI_BIAS, 32, 0>(k, stream);
       case 256 * 1 + 2: return launch<MD_EPI_BIAS, 2, 1>(k, stream);
       case 256 * 1 + 4: return launch<MD_EPI_BIAS, 4, 1>(k, stream);
       case 256 * 1 + 8: return launch<MD_EPI_BIAS, 8, 1>(k, stream);
@@ -877,17 +680,28 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
       case 256 * 1 + 32: return launch<MD_EPI_BIAS, 32, 1>(k, stream);
       case 256 * 1 + 46: return launch<MD_EPI_BIAS, 46, 1>(k, stream);
       case 256 * 1 + 64: return launch<MD_EPI_BIAS, 64, 1>(k, stream);
-      case 256 * 3 + 64: return launch<MD_EPI_BIAS, 64, 3>(k, stream);
+      case 256 * 1 + 128: return launch<MD_EPI_BIAS, 128, 1>(k, stream);
+      case 256 * 1 + 256: return launch<MD_EPI_BIAS, 256, 1>(k, stream);
+      case 256 * 1 + 384: return launch<MD_EPI_BIAS, 384, 1>(k, stream);
       default: return MD_ERR_INVALID_ARG;
     }
   }
 #endif
   if (abl != 0) return MD_ERR_INVALID_ARG;
-  switch (mode) {
-    case 0: return launch_mode<0>(k, epi, stream);
-    case 1: return launch_mode<1>(k, epi, stream);
-    case 2: return epi == MD_EPI_BIAS ? launch<MD_EPI_BIAS, 0, 2>(k, stream) : MD_ERR_INVALID_ARG;
-    case 3: return epi == MD_EPI_BIAS ? launch<MD_EPI_BIAS, 0, 3>(k, stream) : MD_ERR_INVALID_ARG;
+  if (mode != 0 && mode != kDefaultMode) {
+    if (epi != MD_EPI_BIAS) return MD_ERR_INVALID_ARG;
+    switch (mode) {
+      case 2: return launch<MD_EPI_BIAS, 0, 2>(k, stream);
+      case 3: return launch<MD_EPI_BIAS, 0, 3>(k, stream);
+      case 4: return launch<MD_EPI_BIAS, 0, 4>(k, stream);
+      default: return MD_ERR_INVALID_ARG;
+    }
+  }
+  switch (epi) {
+    case MD_EPI_BIAS: return launch<MD_EPI_BIAS>(k, stream);
+    case MD_EPI_GELU: return launch<MD_EPI_GELU>(k, stream);
+    case MD_EPI_RESIDUAL: return launch<MD_EPI_RESIDUAL>(k, stream);
+    case MD_EPI_QKV_ROPE: return launch<MD_EPI_QKV_ROPE>(k, stream);
     default: return MD_ERR_INVALID_ARG;
   }
 }

@@ -10,6 +10,8 @@ from tools.kernel_bench import timeit, stream
 lib = _lib.load(); BF16 = torch.bfloat16
 shapes = [(93312, 1152, 3456), (93312, 1152, 4304), (93312, 1152, 1152), (93312, 4304, 1152),
           (46720, 2048, 14336), (46720, 2048, 2048), (46720, 8192, 2048), (4096, 4096, 4096), (8192, 8192, 8192)]
+if os.environ.get("VENDOR_SHAPES"):  # "m,k,n;m,k,n": a subset for the PMC passes
+    shapes = [tuple(int(x) for x in t.split(",")) for t in os.environ["VENDOR_SHAPES"].split(";")]
 for (m, k, n) in shapes:
     kp = (k + 63) // 64 * 64
     a = (torch.randn(m, kp, device="cuda") * 0.5).to(BF16)

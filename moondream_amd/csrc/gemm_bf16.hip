@@ -56,6 +56,9 @@ struct Knobs {
   int decode_cfg = 16; // MD_DECODE_CFG: d / 6 = alternatives to the 64x64 + helper-waves config
   int decode_slices = 0;  // MD_DECODE_SLICES
   int rope_fuse = 1;      // MD_ROPE_FUSE=0: prefill RoPE + KV write as their own kernel again (A/B, tests)
+  int strict = 0;         // md_gemm_set_tuning("strict"): every launch of more than 64 rows takes the four-wave kernel, whatever its
+                          // row count (that kernel multiplies with 16x16x32 MFMAs, the small-shape configs with 32x32x16: equal to fp32
+                          // rounding, not bitwise -- MoondreamModel.set_strict_batch_invariance)
   Knobs() {
     auto geti = [](const char* n, int d) { const char* e = getenv(n); return (e && *e) ? atoi(e) : d; };
     tile = geti("MD_GEMM_TILE", -1);
@@ -703,6 +706,7 @@ int decode_slices(int n_store, int k_pad) {
 // not depend on it.
 int pick_tile(int M, int n_store, int K) {
   if (knobs().tile >= 0) return knobs().tile;  // experiments / tests: force a tile config
+  if (knobs().strict && M > 64) return 20;
   // single-image regime: a layer that makes at most 128 tiles of 128 x 128 leaves half the chip idle and
   // runs at the latency of its K loop -- the 64 x 64 tiles with the 4-deep ring and DMA helper waves
   // (the decode-regime config) quadruple the workgroups and hide the load latency
@@ -978,6 +982,7 @@ extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   else if (s == "decode_slices") k.decode_slices = value;
   else if (s == "w4_variant") md_gemm_w4_set_variant(value);
   else if (s == "rope_fuse") k.rope_fuse = value;
+  else if (s == "strict") k.strict = value;
   else if (s == "w4_grid") md_gemm_w4_set_grid(value);
   else if (s == "w4_dbg_lo") md_gemm_w4_set_debug(0, (uint32_t)value);
   else if (s == "w4_dbg_hi") md_gemm_w4_set_debug(1, (uint32_t)value);

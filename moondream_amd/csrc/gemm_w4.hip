@@ -1,36 +1,41 @@
 // bf16 GEMM, big-tile kernel:  C = epilogue(A . W^T + b)  for M > 64 and K % 64 == 0.
 //
-// One workgroup = FOUR waves, one per SIMD, each owning a 128 x 128 quarter of a 256 x 256 tile of C with its 16
-// accumulator blocks (256 registers) in the accumulator half of the register file, named literally by inline asm.  Per
-// 16-wide K step a wave issues 16 v_mfma_f32_32x32x16_bf16 (512 matrix-pipe cycles) for 8 ds_read_b128.  Nothing else runs
-// on the SIMD, so everything that is not an MFMA is a FILLER placed by hand between two MFMAs (tables below); the four
-// waves run in lockstep between barriers, so fillers of one kind are spread out.
+// One workgroup = FOUR waves, one per SIMD, each owning a 128 x 128 quarter of a 256 x 256 tile of C as 8 x 8 accumulator
+// blocks of v_mfma_f32_16x16x32_bf16 (256 registers) in the accumulator half of the register file, named literally by
+// inline asm.  The 16x16x32 shape (round 4): with nothing else running the chip holds 2.07 GHz under it and 1.78 GHz under
+// 32x32x16 (profiles/r04_mfma_power_probe.txt) -- it reads and writes each accumulator once per 32 K elements instead of
+// once per 16, and on a power-limited chip energy per FLOP is rate.  Per 32-wide K step a wave issues 64 MFMAs (1024
+// matrix-pipe cycles) for 16 ds_read_b128.  Nothing else runs on the SIMD, so everything that is not an MFMA is a FILLER
+// placed by hand between two MFMAs (tables below); the four waves run in lockstep between barriers.
 //
-// Operand path (round 4): global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no register round trip, no ds_write.
-//   LDS image   TWO pair buffers of 64 KiB.  A buffer holds 64 K elements ("a pair of 32-wide slices") of the tile's 256
-//               activation rows (32 KiB) and 256 weight rows (32 KiB) as 128-byte rows; logical 16-byte chunk c of row r sits
-//               at physical chunk c ^ ((r >> 1) & 7), so the 16-lane groups of a ds_read_b128 touch 16 distinct bank slots.
+// Operand path: global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no register round trip, no ds_write.
+//   LDS image   TWO pair buffers of 64 KiB.  A buffer holds 64 K elements (two K steps) of the tile's 256 activation rows
+//               (32 KiB) and 256 weight rows (32 KiB) as 128-byte rows; logical 16-byte chunk c of row r sits at physical
+//               chunk c ^ ((r >> 1) & 7), so the 16-lane groups of a ds_read_b128 touch 16 distinct bank slots.
 //   LDS-DMA     an instruction moves 8 rows x 128 bytes = whole cache lines (the lane -> LDS mapping is linear: the
 //               permutation sits in the per-lane SOURCE offset); a wave issues 16 per pair, two pairs ahead of the MFMAs
 //               that consume them.  One 32-bit offset register per piece (constant per tile) + one scalar K offset.
-//   fragments   ds_read_b128 one 16-wide K step ahead of the MFMAs that consume them, waited for with COUNTED lgkmcnt
-//               (only the fragment an MFMA is first to use); LDS-DMA is counted by vmcnt, so the count sees reads only.
-//   one s_barrier per pair (64 MFMAs): lgkmcnt(0) (this wave has finished reading the current buffer), vmcnt(0) (its pieces
-//   of the next pair have landed), barrier: the next buffer is published, the current one is released to the DMA stream.
+//   fragments   a 16 x 32 fragment = one ds_read_b128 (lane: row lane & 15, chunk 4 s + (lane >> 4) of K step s), read one
+//               K step ahead of the MFMAs that consume it and waited for with COUNTED lgkmcnt (only the fragment an MFMA is
+//               first to use); LDS-DMA is counted by vmcnt, so the count sees reads only.
+//   one s_barrier per pair (128 MFMAs), in the middle: every read of the current buffer is issued in the first 46 gaps, so
+//   at gap 64 lgkmcnt(0) (this wave has finished reading it), vmcnt(0) (its pieces of the next pair have landed), barrier:
+//   the next buffer is published, the current one is released to the DMA stream.
 //
 // The stream is CONTINUOUS across the tiles of a persistent workgroup (grid = one workgroup per CU, tiles blockIdx.x,
 // blockIdx.x + gridDim.x, ...): the next tile's first pairs are requested under the current tile's last MFMAs and land
 // under its epilogue.
 //
-// Epilogue (round 4): every layer kind leaves through a 4 KiB per-wave LDS transposition tile, so that a store
-// instruction writes 8 rows x 128 bytes -- WHOLE lines.  (The register-only epilogue of rounds 2-3 wrote 32 rows x 32
-// bytes per instruction; profiles/r04_gemm_w4_lds_dma_ablations_stamps.txt: its stores alone cost 19 % of a K <= 2048
-// layer.)  Software pipelined: pass p + 1 is converted and written to the tile while pass p's 16-byte pieces are in flight
-// back from it; LDS executes a wave's operations in order, which is all the ordering one tile needs.  The tile's bias
-// slice (128 columns per wave) arrives by one small LDS-DMA per tile into a wave-private slot.
+// Epilogue: every layer kind leaves through a 4 KiB per-wave LDS transposition tile, so that a store instruction writes
+// 8 rows x 128 bytes -- whole lines.  Software pipelined: pass p + 1 is converted and written to the tile while pass p's
+// 16-byte pieces are in flight back from it; LDS executes a wave's operations in order, which is all the ordering one tile
+// needs.  The tile's bias slice (128 columns per wave) arrives by one small LDS-DMA per tile into a wave-private slot.
+// The decoder's fused [q | k | v | fc1] layer at prefill rotates q and k (rope.py:20-48) on the write side of the
+// transposition and sends k / v pieces straight to the KV slab (text.py:45-46).
 //
-// Numerics: K is accumulated in the same order as every other tile config (sequential 16-wide steps into one fp32
-// accumulator), so results are bit-identical to them.
+// Numerics: fp32 accumulation over K in 32-wide MFMA steps, bias add in fp32, ONE rounding to bf16 (F.linear's rounding
+// point).  (Rounds 2-3 used 32x32x16 like the other tile configs and were bit-identical to them; the summation inside an
+// MFMA differs between the shapes, so this kernel agrees with them to fp32 rounding of the accumulator, not bitwise.)
 #include "gemm_internal.hpp"
 
 #include <algorithm>
@@ -63,6 +68,9 @@ __device__ __forceinline__ void ds_read_b128(bf16x8& dst, uint32_t addr) {
 __device__ __forceinline__ void ds_write_b64_asm(uint32_t addr, u32x2 v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+__device__ __forceinline__ void ds_write_b128_asm(uint32_t addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
 __device__ __forceinline__ void ds_write_b32_asm(uint32_t addr, uint32_t v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -88,11 +96,11 @@ __device__ __forceinline__ void keep_alive(const T& v) {
   asm volatile("" ::"v"(v));
 }
 
-// The 16 accumulator blocks of a wave (256 registers) live in a[0:255], OWNED BY INLINE ASM: block X is
-// a[16X : 16X+15].  As compiler-visible f32x16 values they made the register allocator shuffle and spill
-// around every control-flow join; named literally they cost it nothing.  acc_reserve() lists them as
-// clobbers once (which also makes the kernel descriptor allocate them); the build audits that no
-// compiler-generated v_accvgpr_* / scratch instruction appears in the kernel (see _lib.build_library).
+// The 64 accumulator blocks of a wave (256 registers) live in a[0:255], OWNED BY INLINE ASM: block X is
+// a[4X : 4X+3].  As compiler-visible values they made the register allocator shuffle and spill around every
+// control-flow join; named literally they cost it nothing.  acc_reserve() lists them as clobbers once (which
+// also makes the kernel descriptor allocate them); the build audits that no compiler-generated v_accvgpr_* /
+// scratch instruction appears in the kernel (see _lib.build_library).
 #define MD_A16(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
 __device__ __forceinline__ void acc_reserve() {
   asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", MD_A16(1), MD_A16(2), MD_A16(3), MD_A16(4),
@@ -100,13 +108,14 @@ __device__ __forceinline__ void acc_reserve() {
                MD_A16(15), MD_A16(16), MD_A16(17), MD_A16(18), MD_A16(19), MD_A16(20), MD_A16(21), MD_A16(22), MD_A16(23),
                MD_A16(24), "a250", "a251", "a252", "a253", "a254", "a255");
 }
-// block X (+)= W-fragment . A-fragment^T      (first operand = weight rows, so a lane holds one row m and runs of 4 columns n)
+// block X (+)= W-fragment . A-fragment^T      (first operand = weight rows: a lane then holds token row lane & 15 and the
+// four consecutive columns 4 (lane >> 4) .. + 3 of the block)
 template <int X, bool FIRST>
 __device__ __forceinline__ void mfma_acc(const bf16x8& wf, const bf16x8& af) {
   if constexpr (FIRST)
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(wf), "v"(af), "i"(16 * X), "i"(16 * X + 15));
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(wf), "v"(af), "i"(4 * X), "i"(4 * X + 3));
   else
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(af), "i"(16 * X), "i"(16 * X + 15));
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(af), "i"(4 * X), "i"(4 * X + 3));
 }
 template <int N>
 __device__ __forceinline__ float acc_read() {
@@ -115,59 +124,55 @@ __device__ __forceinline__ float acc_read() {
   return v;
 }
 
-// ---- the filler schedule of one PAIR of slices (64 MFMAs, 64 gaps; gap g = right after MFMA g), as compile-time tables ----
-// A pair is four HALVES of 16 MFMAs = the four 16-wide K steps of the pair buffer; MFMA m = 4 i + j of a half multiplies
-// weight block j with activation block i.  The k-th read for a half fetches fragment kReadOrder[k] (0-3 = weight blocks j,
-// 4-7 = activation blocks i) in the order the MFMAs first need them: B0 A0 B1 B2 B3 A1 A2 A3 are first used by MFMAs
-// 0 0 1 2 3 4 8 12 of the consuming half.
-//   ds_read      half 1's fragments in gaps 1, 3, .., 15, half 2's in 17, .., 31, half 3's in 32, 34, .., 46 (EVEN: the last
-//                read of the buffer being multiplied is two MFMAs old at the barrier), the NEXT pair's half 0 in 49, .., 63
-//   gap 48       lgkmcnt(0), vmcnt(0), s_barrier (see the head of the file)
+// ---- the filler schedule of one PAIR (two K steps = 128 MFMAs, 128 gaps; gap g = right after MFMA g), as compile-time tables ----
+// MFMA m of a K step multiplies activation block i = m / 8 with weight block j = m % 8 (odd i: 7 - m % 8, so that only one
+// operand changes between neighbours).  Fragment f: 0-7 = weight blocks j, 8-15 = activation blocks i.  The k-th read of a
+// step fetches kReadOrder[k], in the order the MFMAs first need them (kFirstUse[k]).
+//   ds_read      K step 1's fragments (current buffer) in gaps 0, 3, .., 45; the NEXT pair's K step 0 (other buffer) in gaps
+//                65, 68, .., 110
+//   gap 64       lgkmcnt(0), vmcnt(0), s_barrier (see the head of the file)
 //   LDS-DMA      the 16 pieces of the pair AFTER the next one, into the buffer the barrier released, at the stream positions
-//                dma_pos() names (48 .. 63 = the rest of this pair, 64 .. = the first gaps of the next pair); a piece has 32+
-//                gaps (1000+ cycles) to land.  MODE picks the placement (profiles/r04_gemm_w4_lds_dma_first_contact.txt).
-constexpr int kReadOrder[8] = {0, 4, 1, 2, 3, 5, 6, 7};
-constexpr int kFirstUse[8] = {0, 0, 1, 2, 3, 4, 8, 12};  // by read position k
-constexpr int kAdvanceGap = 40;                 // the load cursor moves on here: after the last wrapped piece, before gap 48
-constexpr int dma_pos(int mode, int q) {
-  return mode == 1 ? (q < 8 ? 48 + 2 * q : 64 + 2 * (q - 8)) : mode == 2 ? 48 + q : mode == 3 ? 48 + 3 * q : 48 + (5 * q) / 2;
-}
+//                dma_pos() names (64 .. 127 = the rest of this pair, 128 .. = the first gaps of the next pair).  MODE picks
+//                the placement.
+constexpr int kReadOrder[16] = {0, 8, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15};
+constexpr int kFirstUse[16] = {0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 32, 40, 48, 56};  // by read position k
+constexpr int kAdvanceGap = 50;                 // the load cursor moves on here: after the last wrapped piece, before gap 64
+constexpr int kBiasGap = 52;                    // first pair of a tile: the tile's bias slice is requested here
+constexpr int dma_pos(int mode, int q) { return mode == 1 ? 66 + 4 * q : mode == 2 ? 64 + 6 * q : mode == 3 ? 66 + 2 * q : 67 + 3 * q; }
 constexpr bool modes_ok() {
   for (int m = 1; m <= 4; ++m)
     for (int q = 0; q < 16; ++q)
-      if (dma_pos(m, q) < 48 || dma_pos(m, q) - 64 >= kAdvanceGap || (q > 0 && dma_pos(m, q) <= dma_pos(m, q - 1))) return false;
+      if (dma_pos(m, q) < 64 || dma_pos(m, q) - 128 >= kAdvanceGap || (q > 0 && dma_pos(m, q) <= dma_pos(m, q - 1))) return false;
   return true;
 }
-static_assert(modes_ok(), "pieces are issued in order, from gap 48 on, and the wrapped ones before the cursor advances");
+static_assert(modes_ok(), "pieces are issued in order, from gap 64 on, and the wrapped ones before the cursor advances");
+// stream position (relative to gap 0 of the consuming pair) of the k-th read of K step h
+constexpr int read_pos(int h, int k) { return h == 0 ? -63 + 3 * k : 3 * k; }
 constexpr bool is_read_gap(int g) {
-  const int x = ((g % 64) + 64) % 64;
-  return (x < 32 && x % 2 == 1) || (x >= 32 && x < 48 && x % 2 == 0) || (x > 48 && x % 2 == 1);
+  const int x = ((g % 128) + 128) % 128;
+  return (x < 48 && x % 3 == 0) || (x >= 65 && x < 113 && (x - 65) % 3 == 0);
 }
-// stream position (relative to gap 0 of the consuming pair) of the k-th read of half h
-constexpr int read_pos(int h, int k) { return h == 0 ? -15 + 2 * k : h == 1 ? 1 + 2 * k : h == 2 ? 17 + 2 * k : 32 + 2 * k; }
-// which (half, k) is read in gap x of a body, encoded 8 h + k; -1: none
+// which (step, k) is read in gap x of a body, encoded 16 h + k; -1: none
 constexpr int read_slot(int x) {
-  for (int h = 0; h < 4; ++h)
-    for (int k = 0; k < 8; ++k)
-      if (((read_pos(h, k) % 64) + 64) % 64 == x) return 8 * h + k;
+  for (int h = 0; h < 2; ++h)
+    for (int k = 0; k < 16; ++k)
+      if (((read_pos(h, k) % 128) + 128) % 128 == x) return 16 * h + k;
   return -1;
 }
-// lgkmcnt to wait for before MFMA m of half h; -1: the MFMA introduces no new fragment
-constexpr int frag_wait(int h, int m) {
+// lgkmcnt to wait for before MFMA m of K step 0 (step 1's fragments are all covered by gap 64's lgkmcnt(0)); -1: no new fragment
+constexpr int frag_wait(int m) {
   int w = -1;
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < 16; ++k)
     if (kFirstUse[k] == m) {
       int c = 0;
-      for (int g = read_pos(h, k) + 1; g < 16 * h + m; ++g) c += is_read_gap(g) ? 1 : 0;
+      for (int g = read_pos(0, k) + 1; g < m; ++g) c += is_read_gap(g) ? 1 : 0;
       w = (w < 0 || c < w) ? c : w;
     }
-  return w;
+  return w > 15 ? 15 : w;  // lgkmcnt is a 4-bit counter; a smaller count only waits for more
 }
-static_assert(frag_wait(0, 0) <= 15 && frag_wait(1, 12) <= 15 && frag_wait(2, 12) <= 15 && frag_wait(3, 12) <= 15, "lgkmcnt is a 4-bit counter");
 
 // ABL: measurement builds (bit 1: no operand DMA, 2: no barrier, 3: no fragment reads, 4: no epilogue stores, 5: no
-// epilogue, 6: shader-clock stamps around the waits of gap 48 and the epilogue, 7: every store into one 2 MiB window, 8: sc1
-// stores, 7 + 8: sc0 sc1 stores); results are garbage with bits 1-5 or 7 alone set.
+// epilogue, 6: shader-clock stamps around the waits of gap 64 and the epilogue); results are garbage with bits 1-5 set.
 template <int EPI, int ABL = 0, int MODE = 1>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,11 +180,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int hi = lane >> 5, l31 = lane & 31;
+  const int g4 = lane >> 4, l15 = lane & 15;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int npair = p.K / 64;  // pairs of 32-wide slices per tile
+  const int npair = p.K / 64;  // pairs of 32-wide K steps per tile
   int grid_x = gridDim.x;      // pinned in a scalar register: re-read from the dispatch packet inside the stream it is an
   asm volatile("" : "+s"(grid_x));  // s_load + lgkmcnt(0) in the middle of a pair
 
@@ -248,27 +253,27 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds" ::"s"(base), "i"(OFF), "v"(vo), "s"(rs), "s"(so) : "memory", "scc");
   };
 
-  // ---- fragment reads: K step s (0-3) of a pair = logical chunks 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63) ----------
-  const uint32_t swz8 = (l31 >> 1) & 7;
-  uint32_t da[4], db[4];
+  // ---- fragment reads: K step s (0, 1) of a pair = logical chunks 4 s + (lane >> 4); block b of an operand = rows 16 b .. ----
+  const uint32_t swz8 = (l15 >> 1) & 7;
+  uint32_t da[2], db[2];
 #pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    da[st] = lds_base + (wm * 128 + l31) * 128 + (((2 * st + hi) ^ swz8) * 16);
-    db[st] = lds_base + W_OFF + (wn * 128 + l31) * 128 + (((2 * st + hi) ^ swz8) * 16);
+  for (int st = 0; st < 2; ++st) {
+    da[st] = lds_base + (wm * 128 + l15) * 128 + (((4 * st + g4) ^ swz8) * 16);
+    db[st] = lds_base + W_OFF + (wn * 128 + l15) * 128 + (((4 * st + g4) ^ swz8) * 16);
   }
-  bf16x8 fa[2][4], fb[2][4];  // [fragment set][32-row block]
+  bf16x8 fa[2][8], fb[2][8];  // [fragment set = K step parity][16-row block]
   if constexpr (ABL & 8) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fa[0][j] = fa[1][j] = fb[0][j] = fb[1][j] = bf16x8{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    for (int j = 0; j < 8; ++j) fa[0][j] = fa[1][j] = fb[0][j] = fb[1][j] = bf16x8{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   }
-  auto read_frag = [&](auto set_c, auto q_c, uint32_t a_addr, uint32_t b_addr) {
-    constexpr int SET = decltype(set_c)::value, Q = decltype(q_c)::value;
+  auto read_frag = [&](auto set_c, auto f_c, uint32_t a_addr, uint32_t b_addr) {
+    constexpr int SET = decltype(set_c)::value, F = decltype(f_c)::value;
     if constexpr (ABL & 8) {
-      if constexpr (Q < 4) opaque(fb[SET][Q]); else opaque(fa[SET][Q - 4]);
-    } else if constexpr (Q < 4)
-      ds_read_b128<Q * 4096>(fb[SET][Q], b_addr);
+      if constexpr (F < 8) opaque(fb[SET][F]); else opaque(fa[SET][F - 8]);
+    } else if constexpr (F < 8)
+      ds_read_b128<F * 2048>(fb[SET][F], b_addr);
     else
-      ds_read_b128<(Q - 4) * 4096>(fa[SET][Q - 4], a_addr);
+      ds_read_b128<(F - 8) * 2048>(fa[SET][F - 8], a_addr);
   };
 
   acc_reserve();
@@ -289,39 +294,38 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   uint32_t pair_cur = 0, pair_wr = PBUF;  // byte offsets of the buffer being multiplied / the other one
-  // the first fragments (K step 0) of the pair in pair_cur, all eight, waited for: stream start and after every epilogue
+  // the fragments of K step 0 of the pair in pair_cur, all sixteen, waited for: stream start and after every epilogue
   auto read_first_frags = [&]() {
     const uint32_t a0 = da[0] + pair_cur, b0 = db[0] + pair_cur;
-    static_for<0, 8>([&](auto q) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(q)::value]>{}, a0, b0); });
+    static_for<0, 16>([&](auto k) { read_frag(I0{}, std::integral_constant<int, kReadOrder[decltype(k)::value]>{}, a0, b0); });
     wait_lgkm<0>();
     MD_PIN();
   };
   static_for<0, 16>([&](auto j) { dma_piece(j, pair_cur); });
   advance_load_cursor();
   static_for<0, 16>([&](auto j) {
-    if constexpr (dma_pos(MODE, decltype(j)::value) < 64) dma_piece(j, pair_wr);
+    if constexpr (dma_pos(MODE, decltype(j)::value) < 128) dma_piece(j, pair_wr);
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_first_frags();
 
-  // measurement build (ABL & 64): shader-clock stamps around the waits of gap 48 (s_memtime is counted by lgkmcnt: only here,
+  // measurement build (ABL & 64): shader-clock stamps around the waits of gap 64 (s_memtime is counted by lgkmcnt: only here,
   // where the counter is drained anyway)
   uint32_t st_lgkm = 0, st_vm = 0, st_bar = 0, st_n = 0;
   uint64_t st_first = 0, st_last = 0, st_epi = 0;
 
-  // One pair = 64 MFMAs = 64 gaps.  pair_cur = the buffer being multiplied, pair_wr = the other one: it receives the late
-  // pieces of the NEXT pair in the first gaps, is published by the barrier in gap 48 and read from gap 49 on; from gap 48 on
-  // pair_cur receives the pair after that.  ONE straight-line body but for the cursor's once-per-tile branch in gap 40;
+  // One pair = 128 MFMAs = 128 gaps.  pair_cur = the buffer being multiplied, pair_wr = the other one: it receives the late
+  // pieces of the NEXT pair in the first gaps, is published by the barrier in gap 64 and read from gap 65 on; from gap 64 on
+  // pair_cur receives the pair after that.  ONE straight-line body but for the cursor's once-per-tile branch in gap 50;
   // past the end of the stream the fillers keep running on data nobody reads.
   auto pair_body = [&](auto first_c) {
     constexpr bool FIRST = decltype(first_c)::value;  // first pair of a tile: accumulate onto zero, request the tile's bias slice
-    const uint32_t a1 = da[1] + pair_cur, b1 = db[1] + pair_cur, a2 = da[2] + pair_cur, b2 = db[2] + pair_cur;
-    const uint32_t a3 = da[3] + pair_cur, b3 = db[3] + pair_cur, an = da[0] + pair_wr, bn = db[0] + pair_wr;
+    const uint32_t a1 = da[1] + pair_cur, b1 = db[1] + pair_cur, an = da[0] + pair_wr, bn = db[0] + pair_wr;
     const uint32_t buf_cur = pair_cur, buf_nxt = pair_wr;
-    static_for<0, 64>([&](auto xc) {
-      constexpr int X = decltype(xc)::value, H = X / 16, M = X % 16, I = M / 4, J = M % 4, SET = H & 1;
-      if constexpr (X == 48) {
+    static_for<0, 128>([&](auto xc) {
+      constexpr int X = decltype(xc)::value, H = X / 64, M = X % 64, I = M / 8, J = (I & 1) ? 7 - M % 8 : M % 8;
+      if constexpr (X == 64) {
         uint64_t t0 = 0;
         if constexpr (ABL & 64) t0 = __builtin_readcyclecounter();
         if constexpr (!(ABL & 8)) wait_lgkm<0>();
@@ -340,23 +344,23 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
         }
       }
       // counted wait: the fragments this MFMA is the first to use have landed, younger reads stay in flight
-      if constexpr (frag_wait(H, M) >= 0 && !(ABL & 8)) wait_lgkm<frag_wait(H, M)>();
-      mfma_acc<M, FIRST && H == 0>(fb[SET][J], fa[SET][I]);
+      if constexpr (H == 0 && frag_wait(M) >= 0 && !(ABL & 8)) wait_lgkm<frag_wait(M)>();
+      // (the first-use table assumes ascending j in row i = 0 and that block (i, *) first needs activation fragment i: both hold
+      // for the serpentine order)
+      mfma_acc<8 * I + J, FIRST && H == 0>(fb[H][J], fa[H][I]);
       MD_PIN();
       constexpr int RS = read_slot(X);
       if constexpr (RS >= 0) {
-        using Q = std::integral_constant<int, kReadOrder[RS % 8]>;
-        if constexpr (RS / 8 == 1) read_frag(I1{}, Q{}, a1, b1);
-        if constexpr (RS / 8 == 2) read_frag(I0{}, Q{}, a2, b2);
-        if constexpr (RS / 8 == 3) read_frag(I1{}, Q{}, a3, b3);
-        if constexpr (RS / 8 == 0) read_frag(I0{}, Q{}, an, bn);
+        using F = std::integral_constant<int, kReadOrder[RS % 16]>;
+        if constexpr (RS / 16 == 1) read_frag(I1{}, F{}, a1, b1);
+        if constexpr (RS / 16 == 0) read_frag(I0{}, F{}, an, bn);
       }
       static_for<0, 16>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
-        if constexpr (dma_pos(MODE, Q) == X) dma_piece(qc, buf_cur);        // pair p + 2 -> the buffer released in gap 48
-        if constexpr (dma_pos(MODE, Q) - 64 == X) dma_piece(qc, buf_nxt);   // late pieces of pair p + 1
+        if constexpr (dma_pos(MODE, Q) == X) dma_piece(qc, buf_cur);         // pair p + 2 -> the buffer released in gap 64
+        if constexpr (dma_pos(MODE, Q) - 128 == X) dma_piece(qc, buf_nxt);   // late pieces of pair p + 1
       });
-      if constexpr (FIRST && X == 41) dma_bias();  // the slot's previous contents went to registers in the last epilogue
+      if constexpr (FIRST && X == kBiasGap) dma_bias();  // the slot's previous contents went to registers in the last epilogue
       if constexpr (X == kAdvanceGap) advance_load_cursor();
       MD_PIN();
     });
@@ -381,45 +385,50 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     if constexpr (ABL & 64) { te0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
     // ---- epilogue of tile vtile (the next tile's first pairs are already in the ring / in flight) ----------------------
-    // block X = 4 i + j, register r: row m = 32 i + l31, col n = 32 j + 8 (r >> 2) + 4 hi + (r & 3)   within the wave's quarter
+    // block X = 8 i + j, register r: row m = 16 i + l15, col n = 16 j + 4 g4 + r   within the wave's quarter
     if constexpr (!(ABL & 32)) {
-    // This lane's 64 bias values (column 32 j + 8 q + 4 hi + e), unpacked ONCE per tile from the wave's slot.  (npair == 1: the
-    // slot's DMA was waited for by gap 48's vmcnt(0) like every other piece.)
-    md_f32x2 bias_f[4][4][2];
+    // This lane's 32 bias values (column 16 j + 4 g4 + r), unpacked ONCE per tile from the wave's slot.  (npair == 1: the slot's
+    // DMA was waited for by gap 64's vmcnt(0) like every other piece.)
+    md_f32x2 bias_f[8][2];
     {
-      u32x2 bw[4][4];
-      static_for<0, 16>([&](auto jq) {
-        constexpr int j = decltype(jq)::value / 4, q = decltype(jq)::value % 4;
-        ds_read_b64_u32<(32 * j + 8 * q) * 2>(bw[j][q], bias_lds + 8 * hi);
-      });
+      u32x2 bw[8];
+      static_for<0, 8>([&](auto jc) { ds_read_b64_u32<32 * decltype(jc)::value>(bw[decltype(jc)::value], bias_lds + 8 * g4); });
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are not readable before they retire
       wait_lgkm<0>();
       MD_PIN();
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          bias_f[j][q][0] = md_f32x2{lo_bf(bw[j][q][0]), hi_bf(bw[j][q][0])};
-          bias_f[j][q][1] = md_f32x2{lo_bf(bw[j][q][1]), hi_bf(bw[j][q][1])};
-        }
+      for (int j = 0; j < 8; ++j) {
+        bias_f[j][0] = md_f32x2{lo_bf(bw[j][0]), hi_bf(bw[j][0])};
+        bias_f[j][1] = md_f32x2{lo_bf(bw[j][1]), hi_bf(bw[j][1])};
+      }
     }
-    // C (and a residual R) are addressed through buffer resources with num_records = M rows: rows past M read as zero / are
-    // dropped by the range check (no exec masking, no branch); an address is one 32-bit offset.
+    // C (and a residual R, and the KV slabs) are addressed through buffer resources: rows past M read as zero / are dropped by
+    // the range check (no exec masking, no branch); an address is one 32-bit offset.
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)min((uint64_t)p.M * (uint64_t)p.ldc * 2, (uint64_t)0xffffffffu), 0x00020000);
-    // ---- the generic path: eight passes of 32 rows x 64 columns (row block i, column half jp) through the wave's LDS tile ----
-    // write side, on the accumulator layout: bias add + ONE bf16 rounding (F.linear's rounding point), a lane's quad of 4
-    // columns = 8 bytes at row l31, chunk (4 jj + q) ^ (l31 & 7), half hi.  Read side: piece q of this lane = row 8 q +
-    // (lane >> 3), columns 8 (lane & 7) .. + 7 of the pass: 8 lanes cover a row's 128 bytes, an instruction 8 whole lines.
-    // GELU / the residual add work on those 16-byte pieces.  Pass p + 1 is converted and written while pass p's pieces are
-    // in flight back (LDS executes a wave's operations in order: read p, write p + 1, read p + 1 need no waits between them).
-    auto lds_epilogue = [&]() {
+    // Eight passes of 32 rows x 64 columns (row pair ip = i / 2, column half jp) through the wave's LDS tile.
+    // write side, on the accumulator layout: bias add + ONE bf16 rounding (F.linear's rounding point); a lane's quad of 4 columns
+    // = 8 bytes at row 16 (i & 1) + l15, chunk 2 jj + (g4 >> 1), half g4 & 1 (chunks swizzled by row & 7).  Read side: piece q
+    // of this lane = row 8 q + (lane >> 3), columns 8 (lane & 7) .. + 7 of the pass: 8 lanes cover a row's 128 bytes, an
+    // instruction 8 whole lines.  GELU / the residual add work on those 16-byte pieces.  Pass p + 1 is converted and written
+    // while pass p's pieces are in flight back (LDS executes a wave's operations in order: read p, write p + 1, read p + 1
+    // need no waits between them).
+    // KIND 0: bias / GELU / residual layers and the fc1 columns of the decoder's fused layer.  KIND 1-3 (MD_EPI_QKV_ROPE): a
+    // pass is one head (64 features) of the q / k / v section.  q and k: the first 32 features are rotated ON THE WRITE SIDE --
+    // the reference reads them half-split (re = x[d], im = x[16 + d]) and writes them interleaved (rope.py:37-46); in the
+    // accumulator layout re (block jj = 0) and im (jj = 1) of pairs d = 4 g4 .. + 3 sit in the SAME lane and their interleaved
+    // outputs are the 8 consecutive features 8 g4 ..: one 16-byte chunk, no lane exchange.  fp32 arithmetic on the bf16-rounded
+    // layer output with separately rounded mul, mul, sub / add, as torch evaluates it (bit-equal to rope_kv_kernel).  q stays in
+    // the activation; k and v pieces go straight to the KV slab (text.py:45-46) at the row's (slot, position) offset.
+    auto lds_epilogue = [&](auto kind_c) {
+      constexpr int KIND = decltype(kind_c)::value;
+      constexpr bool ROT = KIND == 1 || KIND == 2, SLAB = KIND == 2 || KIND == 3;
       const int lane_row = lane >> 3, lane_col = (lane & 7) * 8;
       const bool col_ok0 = wn0 + lane_col < p.n_store, col_ok1 = wn0 + 64 + lane_col < p.n_store;  // columns past n_store: last column tile only
       const uint32_t col_bytes = (uint32_t)(wn0 + lane_col) * 2u;
       const uint32_t c_base = (uint32_t)(wm0 + lane_row) * (uint32_t)(p.ldc * 2) + col_bytes;
       const uint32_t c_step = (uint32_t)p.ldc * 16u;  // 8 rows
-      auto store_off = [&](int i, int q, int jp) -> uint32_t {
-        const uint32_t off = c_base + (uint32_t)(4 * i + q) * c_step;
+      auto store_off = [&](int ip, int q, int jp) -> uint32_t {
+        const uint32_t off = c_base + (uint32_t)(4 * ip + q) * c_step;
         return ((jp ? col_ok1 : col_ok0) ? off : 0xfffff000u) + 128 * jp;  // out of range: dropped
       };
       // residual layers: the second operand in the same whole-line pieces, prefetched one pass ahead; a broadcast residual
@@ -428,23 +437,72 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       const uint32_t wrap = p.res_row_mod ? (uint32_t)p.res_row_mod : 0x7fffffffu;
       const uint32_t r_row0 = (uint32_t)(wm0 + lane_row) % wrap;
       auto load_residual = [&](int pass, u32x4 (&rv)[4]) {
-        const int i = pass >> 1, jp = pass & 1;
+        const int ip = pass >> 1, jp = pass & 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          uint32_t row = r_row0 + 8u * (uint32_t)(4 * i + q);
+          uint32_t row = r_row0 + 8u * (uint32_t)(4 * ip + q);
           row -= (row >= wrap) ? wrap : 0u;
           const uint32_t off = (jp ? col_ok1 : col_ok0) ? row * (uint32_t)(p.ldr * 2) + col_bytes : 0xfffff000u;
           rv[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off + 128 * jp, 0, 0));
         }
       };
+      // q / k / v sections: the wave's 128 columns are two heads of ONE section (sections are n_heads x 64 wide, a multiple of 128)
+      const int sec = (KIND == 0) ? 0 : wn0 / p.rope_d;
+      const int head0 = (KIND == 0) ? 0 : (wn0 - sec * p.rope_d) >> 6;
+      const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)(KIND == 2 ? p.kslab : p.vslab), 0, (int)p.slab_bytes, 0x00020000);
+      // write side, rows 32 ip + 16 ii + l15: (cos, sin) of pairs d = 4 g4 .. + 3; read side, rows 32 ip + 8 q + (lane >> 3): the
+      // row's byte offset in a layer's slab (rows past M: out of range, dropped)
+      // (all of a tile's row info is requested here, ahead of the first pass: 16 + 4 registers per row pair)
+      f32x4 cs[4][2][2];
+      uint32_t kv_off[4][4];
+      if constexpr (ROT) {
+#pragma unroll
+        for (int ip = 0; ip < 4; ++ip)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const f32x4* cp = (const f32x4*)(p.rope_cs + (int64_t)min(wm0 + 32 * ip + 16 * ii + l15, p.M - 1) * 32);
+            cs[ip][ii][0] = cp[2 * g4];
+            cs[ip][ii][1] = cp[2 * g4 + 1];
+          }
+      }
+      if constexpr (SLAB) {
+#pragma unroll
+        for (int ip = 0; ip < 4; ++ip)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = wm0 + 32 * ip + 8 * q + lane_row;
+            kv_off[ip][q] = m < p.M ? p.rope_kv[m] + (uint32_t)(lane & 7) * 16u : 0xfffff000u;
+          }
+      }
       auto convert_write = [&](auto pc) {
-        constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
-        static_for<0, 8>([&](auto jq) {
-          constexpr int jj = decltype(jq)::value / 4, q = decltype(jq)::value % 4, j = 2 * jp + jj, base = 16 * (4 * i + j) + 4 * q;
-          const md_f32x2 x0 = md_f32x2{acc_read<base + 0>(), acc_read<base + 1>()} + bias_f[j][q][0];
-          const md_f32x2 x1 = md_f32x2{acc_read<base + 2>(), acc_read<base + 3>()} + bias_f[j][q][1];
-          constexpr int ch = 4 * jj + q;
-          ds_write_b64_asm(tile_lds + l31 * 128 + ((ch ^ (l31 & 7)) * 16) + hi * 8, u32x2{pack_bf16x2(x0[0], x0[1]), pack_bf16x2(x1[0], x1[1])});
+        constexpr int PASS = decltype(pc)::value, ip = PASS >> 1, jp = PASS & 1;
+        static_for<0, 2>([&](auto iic) {
+          constexpr int ii = decltype(iic)::value, i = 2 * ip + ii;
+          const uint32_t row = 16 * ii + l15;
+          const uint32_t row_lds = tile_lds + row * 128;
+          u32x2 w[4];
+          static_for<0, 4>([&](auto jjc) {
+            constexpr int jj = decltype(jjc)::value, j = 4 * jp + jj, base = 4 * (8 * i + j);
+            const md_f32x2 x0 = md_f32x2{acc_read<base + 0>(), acc_read<base + 1>()} + bias_f[j][0];
+            const md_f32x2 x1 = md_f32x2{acc_read<base + 2>(), acc_read<base + 3>()} + bias_f[j][1];
+            w[jj] = u32x2{pack_bf16x2(x0[0], x0[1]), pack_bf16x2(x1[0], x1[1])};  // the layer's bf16 output
+          });
+          static_for<0, 4>([&](auto jjc) {
+            constexpr int jj = decltype(jjc)::value;
+            if constexpr (ROT && jj == 0) {
+              u32x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float re = (r & 1) ? hi_bf(w[0][r >> 1]) : lo_bf(w[0][r >> 1]), im = (r & 1) ? hi_bf(w[1][r >> 1]) : lo_bf(w[1][r >> 1]);
+                float o_re, o_im;
+                md_rope_pair(re, im, cs[ip][ii][r >> 1][2 * (r & 1)], cs[ip][ii][r >> 1][2 * (r & 1) + 1], o_re, o_im);
+                v[r] = pack_bf16x2(o_re, o_im);
+              }
+              ds_write_b128_asm(row_lds + ((g4 ^ (row & 7)) * 16), v);  // features 8 g4 .. + 7 of the head
+            } else if constexpr (!(ROT && jj == 1)) {
+              ds_write_b64_asm(row_lds + (((2 * jj + (g4 >> 1)) ^ (row & 7)) * 16) + (g4 & 1) * 8, w[jj]);
+            }
+          });
         });
       };
       auto read_pieces = [&](u32x4 (&tv)[4]) {
@@ -454,17 +512,18 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
           ds_read_b128_u32(tv[q], tile_lds + row * 128 + ((ch ^ (row & 7)) * 16));
         }
       };
+      constexpr int WRITES = ROT ? 6 : 8;  // LDS writes of a pass
       u32x4 tv[2][4], rres[2][4];
       if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(0, rres[0]);
       convert_write(I0{});
       read_pieces(tv[0]);
       MD_PIN();
       static_for<0, 8>([&](auto pc) {
-        constexpr int PASS = decltype(pc)::value, i = PASS >> 1, jp = PASS & 1;
+        constexpr int PASS = decltype(pc)::value, ip = PASS >> 1, jp = PASS & 1;
         if constexpr (PASS + 1 < 8) {
           if constexpr (EPI == MD_EPI_RESIDUAL) load_residual(PASS + 1, rres[(PASS + 1) & 1]);
           convert_write(std::integral_constant<int, PASS + 1>{});
-          wait_lgkm<8>();  // this pass's four reads are back; the next pass's eight writes may still be on their way
+          wait_lgkm<WRITES>();  // this pass's four reads are back; the next pass's writes may still be on their way
         } else {
           wait_lgkm<0>();
         }
@@ -472,7 +531,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           u32x4 v = tv[PASS & 1][q];
-          if constexpr (EPI == MD_EPI_GELU || EPI == MD_EPI_QKV_ROPE) {
+          if constexpr (KIND == 0 && (EPI == MD_EPI_GELU || EPI == MD_EPI_QKV_ROPE)) {
             if (wn0 + 64 * jp >= p.gelu_from) {  // wave-uniform: gelu_from is a multiple of 64 (fused [qkv | fc1] layers)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -486,123 +545,32 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
             for (int e = 0; e < 4; ++e)
               v[e] = pack_bf16x2(lo_bf(rres[PASS & 1][q][e]) + lo_bf(v[e]), hi_bf(rres[PASS & 1][q][e]) + hi_bf(v[e]));
           }
-          const uint32_t off = store_off(i, q, jp);
-          if constexpr ((ABL & (128 | 256)) == 128) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off & 0x1fffffu, 0, 0);  // every store into one 2 MiB window
-          else if constexpr ((ABL & (128 | 256)) == 256) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off, 0, 16);       // sc1
-          else if constexpr ((ABL & (128 | 256)) == 384) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off, 0, 17);       // sc0 sc1
-          else if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off, 0, 0);
-          else keep_alive(v);
+          if constexpr (SLAB) {
+            // slab: [head][position][64] bf16 per slot
+            const uint32_t head_off = (uint32_t)(head0 + jp) * (uint32_t)p.rope_ctx * 128u;
+            if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_s, kv_off[ip][q], head_off, 0);
+          } else {
+            const uint32_t off = store_off(ip, q, jp);
+            if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, off, 0, 0);
+            else keep_alive(v);
+          }
         }
         MD_PIN();
         if constexpr (PASS + 1 < 8) read_pieces(tv[(PASS + 1) & 1]);
         MD_PIN();
       });
     };
-    // ---- MD_EPI_QKV_ROPE: the q / k / v sections of the decoder's fused layer at prefill ------------------------------
-    // A wave's 128 columns are two heads of ONE section (sections are n_heads x 64 wide, a multiple of 128).  Per head the
-    // first 32 features are rotated: the reference reads them half-split (re = x[d], im = x[16 + d]) and writes them
-    // interleaved (rope.py:37-46).  In the accumulator layout a lane holds quads q = 0..3 of column block j, i.e. features
-    // 8 q + 4 hi + e: re (q = 0, 1) and im (q + 2) of a pair sit in the SAME lane, and the rotated pairs of quad q are the 8
-    // consecutive output features 16 q + 8 hi ..: a 16-byte piece with no lane exchange.  fp32 arithmetic on the bf16-rounded
-    // layer output with separately rounded mul, mul, sub / add, as torch evaluates it (bit-equal to rope_kv_kernel).
-    // q stays in the activation (rotated), k and v go straight to the KV slab (text.py:45-46): one pass over the bytes
-    // instead of the GEMM's stores + rope_kv_kernel's load and store of every q / k / v element.
-    auto rope_tile = [&]() {
-      const int sec = wn0 / p.rope_d;               // 0 q, 1 k, 2 v   (wave-uniform)
-      const int head0 = (wn0 - sec * p.rope_d) >> 6;
-      bf16_t* slab = (sec == 1) ? p.kslab : p.vslab;
-      const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (int)p.slab_bytes, 0x00020000);
-      static_for<0, 4>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int m = wm0 + 32 * i + l31, mc = min(m, p.M - 1);
-        const uint32_t row_off = (uint32_t)m * (uint32_t)(p.ldc * 2) + (uint32_t)(wn0 + 8 * hi) * 2u;
-        uint32_t kv_off = 0xfffff000u;  // rows past M: dropped by the range check
-        if (sec != 0 && m < p.M) kv_off = p.rope_kv[mc] + (uint32_t)hi * 16u;
-        f32x4 cs[4];  // (cos, sin) of features 4 hi + {0,1}, {2,3}, 8 + 4 hi + {0,1}, {2,3}
-        if (sec != 2) {
-          const f32x4* cp = (const f32x4*)(p.rope_cs + (int64_t)mc * 32);
-          cs[0] = cp[2 * hi];
-          cs[1] = cp[2 * hi + 1];
-          cs[2] = cp[4 + 2 * hi];
-          cs[3] = cp[4 + 2 * hi + 1];
-        }
-        static_for<0, 2>([&](auto jc) {
-          constexpr int jp = decltype(jc)::value;
-          const uint32_t head_off = (uint32_t)(head0 + jp) * (uint32_t)p.rope_ctx * 128u;  // slab: [head][position][64] bf16
-          auto put = [&](const u32x4& v, int col_in_head_bytes) {  // col_in_head_bytes: immediate-sized constant
-            if (sec == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_c, row_off + 128 * jp + col_in_head_bytes, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_s, kv_off + col_in_head_bytes, head_off, 0);
-          };
-          // features 0..31 of the head: column block j = 2 jp
-          {
-            constexpr int j = 2 * jp, base = 16 * (4 * i + j);
-            float x[4][4];
-            static_for<0, 4>([&](auto qc) {
-              constexpr int q = decltype(qc)::value;
-              const md_f32x2 u0 = md_f32x2{acc_read<base + 4 * q + 0>(), acc_read<base + 4 * q + 1>()} + bias_f[j][q][0];
-              const md_f32x2 u1 = md_f32x2{acc_read<base + 4 * q + 2>(), acc_read<base + 4 * q + 3>()} + bias_f[j][q][1];
-              const uint32_t w0 = pack_bf16x2(u0[0], u0[1]), w1 = pack_bf16x2(u1[0], u1[1]);  // the layer's bf16 output
-              x[q][0] = lo_bf(w0); x[q][1] = hi_bf(w0); x[q][2] = lo_bf(w1); x[q][3] = hi_bf(w1);
-            });
-            if (sec != 2) {
-#pragma unroll
-              for (int q = 0; q < 2; ++q) {
-                u32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float re = x[q][e], im = x[q + 2][e];
-                  const float c = cs[2 * q + (e >> 1)][2 * (e & 1)], sn = cs[2 * q + (e >> 1)][2 * (e & 1) + 1];
-                  float o_re, o_im;
-                  md_rope_pair(re, im, c, sn, o_re, o_im);
-                  v[e] = pack_bf16x2(o_re, o_im);
-                }
-                put(v, q * 32);  // features 16 q + 8 hi .. + 7 (the 8 hi is part of row_off / kv_off)
-              }
-            } else {
-              // v: no rotation; the standard 16-byte pieces (quads q0, q0 + 1 of the two lane halves side by side)
-#pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                const uint32_t a0 = pack_bf16x2(x[2 * t][0], x[2 * t][1]), a1 = pack_bf16x2(x[2 * t][2], x[2 * t][3]);
-                const uint32_t b0 = pack_bf16x2(x[2 * t + 1][0], x[2 * t + 1][1]), b1 = pack_bf16x2(x[2 * t + 1][2], x[2 * t + 1][3]);
-                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                put(u32x4{s0[0], s1[0], s0[1], s1[1]}, t * 32);
-              }
-            }
-          }
-          // features 32..63: column block j = 2 jp + 1, never rotated (rot_dim 32)
-          {
-            constexpr int j = 2 * jp + 1, base = 16 * (4 * i + j);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              uint32_t w[4];
-              static_for<0, 2>([&](auto hc) {
-                constexpr int hq = decltype(hc)::value;  // quads 2 t and 2 t + 1
-                auto rd = [&](auto tt) {
-                  constexpr int q = 2 * decltype(tt)::value + hq;
-                  const md_f32x2 u0 = md_f32x2{acc_read<base + 4 * q + 0>(), acc_read<base + 4 * q + 1>()} + bias_f[j][q][0];
-                  const md_f32x2 u1 = md_f32x2{acc_read<base + 4 * q + 2>(), acc_read<base + 4 * q + 3>()} + bias_f[j][q][1];
-                  w[2 * hq] = pack_bf16x2(u0[0], u0[1]);
-                  w[2 * hq + 1] = pack_bf16x2(u1[0], u1[1]);
-                };
-                if (t == 0) rd(std::integral_constant<int, 0>{}); else rd(std::integral_constant<int, 1>{});
-              });
-              const auto s0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
-              const auto s1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
-              put(u32x4{s0[0], s1[0], s0[1], s1[1]}, 64 + t * 32);
-            }
-          }
-        });
-        MD_PIN();
-      });
-    };
     if constexpr (EPI == MD_EPI_QKV_ROPE) {
-      if (wn0 < 3 * p.rope_d) rope_tile(); else lds_epilogue();
+      const int sec = wn0 / p.rope_d;  // 0 q, 1 k, 2 v, >= 3: the fc1 columns   (wave-uniform)
+      if (sec == 0) lds_epilogue(std::integral_constant<int, 1>{});
+      else if (sec == 1) lds_epilogue(std::integral_constant<int, 2>{});
+      else if (sec == 2) lds_epilogue(std::integral_constant<int, 3>{});
+      else lds_epilogue(I0{});
     } else {
-      lds_epilogue();
+      lds_epilogue(I0{});
     }
     }
-    // the next tile's first fragments again (the copy read before the epilogue was not kept: 32
+    // the next tile's first fragments again (the copy read before the epilogue was not kept: 64
     // registers the epilogue does not have to carry); its first pair was published by the last barrier above
     read_first_frags();
     if constexpr (ABL & 64) { st_epi += __builtin_readcyclecounter() - te0; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }

@@ -308,6 +308,10 @@ class MoondreamModel:
         self.single_sequence_kernel = not on
         self.fused_prefill = not on
         self.strict_batch_invariance = bool(on)
+        # the library's tile choice by row count would give a lone image (730 / 1458 rows) the small-shape configs and a batch
+        # the four-wave kernel, whose 16x16x32 MFMAs sum K in another association: strict mode pins the four-wave kernel for
+        # every launch of more than 64 rows (a process-wide library knob)
+        _lib.check(self.lib.md_gemm_set_tuning(b"strict", 1 if on else 0))
         self._graphs.clear()
 
     def compile(self):

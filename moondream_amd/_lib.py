@@ -277,7 +277,8 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 def audit_asm_owned_accumulators(asm_path: str) -> None:
     """gemm_w4.hip keeps its accumulators in a[0:255] through inline asm.  That is only sound while
     the compiler itself never touches the accumulator file or spills in those kernels: any
-    v_accvgpr_* outside an inline-asm block, or any scratch access, fails the build."""
+    v_accvgpr_* outside an inline-asm block, or any scratch access, fails the build.  The same for M0,
+    which its LDS-DMA groups carry across asm statements."""
     if not os.path.exists(asm_path):
         raise MoondreamHipError(f"{asm_path} missing: gemm_w4.hip must be compiled with -save-temps=obj for the ISA audit")
     import re
@@ -297,6 +298,9 @@ def audit_asm_owned_accumulators(asm_path: str) -> None:
         elif kernel and not t.startswith(";"):
             if ("v_accvgpr" in t and not in_asm) or t.startswith("scratch_") or ("a[" in t and not in_asm and t.startswith("v_mfma")):
                 bad.append(f"{kernel[-40:]}: {t}")
+            # M0 carries the LDS block of the running LDS-DMA group from one asm statement to the next
+            if not in_asm and re.search(r"\bm0\b", t.split(";")[0]):
+                bad.append(f"{kernel[-40:]}: compiler-generated use of m0: {t}")
         if t.startswith("s_endpgm"):
             kernel = None
     if seen == 0:

@@ -14,7 +14,11 @@
 //               chunk c ^ ((r >> 1) & 7), so the 16-lane groups of a ds_read_b128 touch 16 distinct bank slots.
 //   LDS-DMA     an instruction moves 8 rows x 128 bytes = whole cache lines (the lane -> LDS mapping is linear: the
 //               permutation sits in the per-lane SOURCE offset); a wave issues 16 per pair, two pairs ahead of the MFMAs
-//               that consume them.  One 32-bit offset register per piece (constant per tile) + one scalar K offset.
+//               that consume them.  One 32-bit offset register per piece (constant per tile) + one scalar K offset.  A
+//               wave's pieces are grouped four to a 4 KiB LDS block: M0 is written once per block and the piece is picked
+//               by the instruction's immediate offset (the M0 write and its wait state were 8-9 of a piece's ~20 issue
+//               cycles: profiles/r04_dma_issue_probe.txt); the immediate also moves the global address, which the
+//               piece's offset register takes back out.
 //   fragments   a 16 x 32 fragment = one ds_read_b128 (lane: row lane & 15, chunk 4 s + (lane >> 4) of K step s), read one
 //               K step ahead of the MFMAs that consume it and waited for with COUNTED lgkmcnt (only the fragment an MFMA is
 //               first to use); LDS-DMA is counted by vmcnt, so the count sees reads only.
@@ -200,20 +204,25 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   };
 
   // ---- load cursor: one pair (64 K elements) at a time, across tile boundaries --------------------------------
-  // Piece j (0-7: activations, 8-15: weights) of this wave: rows 32 (j & 7) + 8 wave + (lane >> 3) of the tile, all 128 bytes
-  // of each.  The lane's LDS slot is fixed (row lane >> 3, physical chunk lane & 7), so it FETCHES the logical chunk that
-  // belongs there.  Rows past M / n_pad are clamped (their products land in rows / columns nobody stores).
+  // Piece j (0-7: activations, 8-15: weights) of this wave: rows 64 wave + 8 (j & 7) + (lane >> 3) of the tile, all 128 bytes of
+  // each: a wave fills two 4 KiB LDS blocks per operand, four pieces each.  The lane's LDS slot is fixed (row lane >> 3, physical
+  // chunk lane & 7), so it FETCHES the logical chunk that belongs there.  The instruction's immediate (j & 3) * 1024 picks the
+  // piece inside its block and moves the global address along: the offset register holds (4096 - immediate) more and the buffer
+  // descriptors start 4096 bytes early, so that no offset goes negative.  Rows past M / n_pad are clamped (their products land
+  // in rows / columns nobody stores).
   uint32_t voff[16];
   int ld_tile = blockIdx.x, ld_pair = 0;
   uint32_t ld_soff = 0;
   auto set_load_tile = [&](int vv) {
     int m0, n0;
     tile_origin(vv, m0, n0);
-    const int r8 = tid >> 3, c8 = (tid & 7) ^ ((r8 >> 1) & 7);
+    const int r8 = lane >> 3;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      voff[j] = (uint32_t)min(m0 + 32 * j + r8, p.M - 1) * (uint32_t)(p.lda * 2) + c8 * 16;
-      voff[8 + j] = (uint32_t)min(n0 + 32 * j + r8, p.n_pad - 1) * (uint32_t)(p.ldw * 2) + c8 * 16;
+      const int row = 64 * wave + 8 * j + r8, c8 = (lane & 7) ^ ((row >> 1) & 7);
+      const uint32_t fix = 4096u - (uint32_t)(j & 3) * 1024u + c8 * 16;
+      voff[j] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)(p.lda * 2) + fix;
+      voff[8 + j] = (uint32_t)min(n0 + row, p.n_pad - 1) * (uint32_t)(p.ldw * 2) + fix;
     }
   };
   set_load_tile(ld_tile);
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     }
   };
   // buffer descriptors as four scalar words each (inline-asm operands); piece j lands at
-  //   pair buffer + (j < 8 ? 0 : 32 KiB) + (j & 7) * 4 KiB + wave * 1 KiB + lane * 16
+  //   pair buffer + (j < 8 ? 0 : 32 KiB) + wave * 8 KiB + (j & 7) * 1 KiB + lane * 16
   auto make_rsrc = [](const void* ptr, uint32_t bytes) {
     u32x4 r;
     r[0] = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ptr);
@@ -240,17 +249,23 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     r[3] = 0x00020000u;
     return r;
   };
-  const u32x4 rs_a = make_rsrc(p.A, 0xffffffffu), rs_w = make_rsrc(p.W, 0xffffffffu);
+  const u32x4 rs_a = make_rsrc((const char*)p.A - 4096, 0xffffffffu), rs_w = make_rsrc((const char*)p.W - 4096, 0xffffffffu);
   const u32x4 rs_bias = make_rsrc(p.bias, (uint32_t)p.n_pad * 2u);  // columns past n_pad (last column tile) read as zero
-  const uint32_t dma_lds = lds_base + (uint32_t)wave * 1024u;
-  auto dma_piece = [&](auto j_c, uint32_t buf) {
+  const uint32_t dma_lds = lds_base + (uint32_t)wave * 8192u;
+  // SETM0: the piece opens a 4 KiB block, or is the first one a body issues (nothing but this kernel's own asm touches M0
+  // inside a body -- the build audits that -- but an epilogue may lie between two bodies)
+  auto dma_piece = [&](auto j_c, uint32_t buf, auto setm0_c) {
     constexpr int J = decltype(j_c)::value;
-    constexpr int OFF = J < 8 ? J * 4096 : W_OFF + (J - 8) * 4096;
+    constexpr bool SETM0 = decltype(setm0_c)::value || (J & 3) == 0;
+    constexpr int BLOCK = (J < 8 ? 0 : W_OFF) + ((J & 7) >> 2) * 4096, IMM = (J & 3) * 1024;
     // (operands copied to locals first: clang does not capture variables that appear only as asm operands of a generic lambda)
     const uint32_t base = dma_lds + buf, vo = voff[J], so = ld_soff;  // base, so: wave-uniform
     const u32x4 rs = J < 8 ? rs_a : rs_w;
-    if constexpr (!(ABL & 2))
-      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds" ::"s"(base), "i"(OFF), "v"(vo), "s"(rs), "s"(so) : "memory", "scc");
+    if constexpr (ABL & 2) return;
+    if constexpr (SETM0)
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen offset:%5 lds" ::"s"(base), "i"(BLOCK), "v"(vo), "s"(rs), "s"(so), "i"(IMM) : "memory", "scc");
+    else
+      asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(vo), "s"(rs), "s"(so), "i"(IMM) : "memory");
   };
 
   // ---- fragment reads: K step s (0, 1) of a pair = logical chunks 4 s + (lane >> 4); block b of an operand = rows 16 b .. ----
@@ -301,10 +316,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     wait_lgkm<0>();
     MD_PIN();
   };
-  static_for<0, 16>([&](auto j) { dma_piece(j, pair_cur); });
+  static_for<0, 16>([&](auto j) { dma_piece(j, pair_cur, std::false_type{}); });
   advance_load_cursor();
   static_for<0, 16>([&](auto j) {
-    if constexpr (dma_pos(MODE, decltype(j)::value) < 128) dma_piece(j, pair_wr);
+    if constexpr (dma_pos(MODE, decltype(j)::value) < 128) dma_piece(j, pair_wr, std::false_type{});
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -357,8 +372,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
       }
       static_for<0, 16>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
-        if constexpr (dma_pos(MODE, Q) == X) dma_piece(qc, buf_cur);         // pair p + 2 -> the buffer released in gap 64
-        if constexpr (dma_pos(MODE, Q) - 128 == X) dma_piece(qc, buf_nxt);   // late pieces of pair p + 1
+        if constexpr (dma_pos(MODE, Q) == X) dma_piece(qc, buf_cur, std::false_type{});  // pair p + 2 -> the buffer released in gap 64
+        // late pieces of pair p + 1 (the first of them is the body's first DMA instruction: it writes M0 whatever its place in a block)
+        if constexpr (dma_pos(MODE, Q) - 128 == X) dma_piece(qc, buf_nxt, std::integral_constant<bool, (Q == 0 || dma_pos(MODE, Q - 1) < 128)>{});
       });
       if constexpr (FIRST && X == kBiasGap) dma_bias();  // the slot's previous contents went to registers in the last epilogue
       if constexpr (X == kAdvanceGap) advance_load_cursor();
@@ -589,7 +605,7 @@ int g_w4_grid = 0;     // md_gemm_set_tuning "w4_grid": persistent workgroups pe
 // the others exist for the bias epilogue only), the rest 16 * ABL (measurement builds, bias epilogue only)
 int g_w4_variant = [] { const char* e = getenv("MD_W4_VARIANT"); return (e && *e) ? atoi(e) : 0; }();
 uint64_t g_w4_debug = 0;  // measurement builds: device buffer for the in-kernel stamps (md_gemm_set_tuning "w4_dbg_lo" / "w4_dbg_hi")
-constexpr int kDefaultMode = 1;
+constexpr int kDefaultMode = 2;
 
 template <int EPI, int ABL = 0, int MODE = kDefaultMode>
 md_status launch(const GemmK& k, hipStream_t stream) {
@@ -639,18 +655,18 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   const int mode = g_w4_variant & 15, abl = g_w4_variant >> 4;  // (measurement codes: MODE + 16 * ABL)
 #ifdef MD_W4_ABLATIONS  // measurement builds only (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()")
   if (epi == MD_EPI_BIAS && abl != 0) {
-    switch (256 * mode + abl) {
-      case 256 * 1 + 2: return launch<MD_EPI_BIAS, 2, 1>(k, stream);
-      case 256 * 1 + 4: return launch<MD_EPI_BIAS, 4, 1>(k, stream);
-      case 256 * 1 + 8: return launch<MD_EPI_BIAS, 8, 1>(k, stream);
-      case 256 * 1 + 14: return launch<MD_EPI_BIAS, 14, 1>(k, stream);
-      case 256 * 1 + 16: return launch<MD_EPI_BIAS, 16, 1>(k, stream);
-      case 256 * 1 + 32: return launch<MD_EPI_BIAS, 32, 1>(k, stream);
-      case 256 * 1 + 46: return launch<MD_EPI_BIAS, 46, 1>(k, stream);
-      case 256 * 1 + 64: return launch<MD_EPI_BIAS, 64, 1>(k, stream);
-      case 256 * 1 + 128: return launch<MD_EPI_BIAS, 128, 1>(k, stream);
-      case 256 * 1 + 256: return launch<MD_EPI_BIAS, 256, 1>(k, stream);
-      case 256 * 1 + 384: return launch<MD_EPI_BIAS, 384, 1>(k, stream);
+    switch (256 * (mode == 0 ? kDefaultMode : mode) + abl) {
+      case 256 * 2 + 2: return launch<MD_EPI_BIAS, 2, 2>(k, stream);
+      case 256 * 2 + 4: return launch<MD_EPI_BIAS, 4, 2>(k, stream);
+      case 256 * 2 + 8: return launch<MD_EPI_BIAS, 8, 2>(k, stream);
+      case 256 * 2 + 14: return launch<MD_EPI_BIAS, 14, 2>(k, stream);
+      case 256 * 2 + 16: return launch<MD_EPI_BIAS, 16, 2>(k, stream);
+      case 256 * 2 + 32: return launch<MD_EPI_BIAS, 32, 2>(k, stream);
+      case 256 * 2 + 46: return launch<MD_EPI_BIAS, 46, 2>(k, stream);
+      case 256 * 2 + 64: return launch<MD_EPI_BIAS, 64, 2>(k, stream);
+      case 256 * 2 + 128: return launch<MD_EPI_BIAS, 128, 2>(k, stream);
+      case 256 * 2 + 256: return launch<MD_EPI_BIAS, 256, 2>(k, stream);
+      case 256 * 2 + 384: return launch<MD_EPI_BIAS, 384, 2>(k, stream);
       default: return MD_ERR_INVALID_ARG;
     }
   }
@@ -659,7 +675,7 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
   if (mode != 0 && mode != kDefaultMode) {
     if (epi != MD_EPI_BIAS) return MD_ERR_INVALID_ARG;
     switch (mode) {
-      case 2: return launch<MD_EPI_BIAS, 0, 2>(k, stream);
+      case 1: return launch<MD_EPI_BIAS, 0, 1>(k, stream);
       case 3: return launch<MD_EPI_BIAS, 0, 3>(k, stream);
       case 4: return launch<MD_EPI_BIAS, 0, 4>(k, stream);
       default: return MD_ERR_INVALID_ARG;

@@ -20,9 +20,9 @@ from tools.sweep_gemm import timeit, stream
 lib = _lib.load()
 BF16 = torch.bfloat16
 V = lambda mode, abl: mode + 16 * abl
-VARIANTS = [("dma", V(1, 0)), ("no-dma", V(1, 2)), ("no-barrier", V(1, 4)), ("no-reads", V(1, 8)), ("mfma+epi", V(1, 14)),
-            ("no-stores", V(1, 16)), ("no-epi", V(1, 32)), ("mfma only", V(1, 46)), ("stores->2MiB window", V(1, 128)), ("sc1 stores", V(1, 256)),
-            ("sc0 sc1 stores", V(1, 384))]
+VARIANTS = [("dma", V(0, 0)), ("no-dma", V(0, 2)), ("no-barrier", V(0, 4)), ("no-reads", V(0, 8)), ("mfma+epi", V(0, 14)),
+            ("no-stores", V(0, 16)), ("no-epi", V(0, 32)), ("mfma only", V(0, 46)), ("stores->2MiB window", V(0, 128)), ("sc1 stores", V(0, 256)),
+            ("sc0 sc1 stores", V(0, 384))]
 SHAPES = [(8192, 8192, 8192), (46720, 2048, 2048), (93312, 1152, 3456)]
 
 
@@ -54,7 +54,7 @@ if "stamps" not in sys.argv[1:]:
 dbg = torch.zeros(256 * 4 * 8, dtype=torch.float32, device="cuda")
 lib.md_gemm_set_tuning(b"w4_dbg_lo", C.c_int32(dbg.data_ptr() & 0xffffffff).value)
 lib.md_gemm_set_tuning(b"w4_dbg_hi", C.c_int32(dbg.data_ptr() >> 32).value)
-for mode in (1,):
+for mode in (0,):
     for m, k, n in SHAPES:
         keep = problem(m, k, n)
         args = keep[-1]

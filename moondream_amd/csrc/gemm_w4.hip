@@ -176,7 +176,7 @@ constexpr int frag_wait(int m) {
 }
 
 // ABL: measurement builds (bit 1: no operand DMA, 2: no barrier, 3: no fragment reads, 4: no epilogue stores, 5: no
-// epilogue, 6: shader-clock stamps around the waits of gap 64 and the epilogue); results are garbage with bits 1-5 set.
+// epilogue, 6: shader-clock stamps around the waits of gap 64 and the epilogue, 8: every operand load from one L2-resident MiB); results are garbage with bits 1-5 set.
 template <int EPI, int ABL = 0, int MODE = 1>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
     constexpr bool SETM0 = decltype(setm0_c)::value || (J & 3) == 0;
     constexpr int BLOCK = (J < 8 ? 0 : W_OFF) + ((J & 7) >> 2) * 4096, IMM = (J & 3) * 1024;
     // (operands copied to locals first: clang does not capture variables that appear only as asm operands of a generic lambda)
-    const uint32_t base = dma_lds + buf, vo = voff[J], so = ld_soff;  // base, so: wave-uniform
+    const uint32_t base = dma_lds + buf, vo = (ABL & 256) ? ((voff[J] & 0xfffffu) | 4096u) : voff[J], so = (ABL & 256) ? (ld_soff & 0xfffu) : ld_soff;  // base, so: wave-uniform (ABL & 256: every load from one L2-resident MiB)
     const u32x4 rs = J < 8 ? rs_a : rs_w;
     if constexpr (ABL & 2) return;
     if constexpr (SETM0)
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
 
   // measurement build (ABL & 64): shader-clock stamps around the waits of gap 64 (s_memtime is counted by lgkmcnt: only here,
   // where the counter is drained anyway)
-  uint32_t st_lgkm = 0, st_vm = 0, st_bar = 0, st_n = 0;
+  uint32_t st_lgkm = 0, st_vm = 0, st_bar = 0, st_n = 0, st_vm_first = 0;
   uint64_t st_first = 0, st_last = 0, st_epi = 0;
 
   // One pair = 128 MFMAs = 128 gaps.  pair_cur = the buffer being multiplied, pair_wr = the other one: it receives the late
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
         if constexpr (!(ABL & 8)) wait_lgkm<0>();
         if constexpr (ABL & 64) { const uint64_t t = __builtin_readcyclecounter(); st_lgkm += (uint32_t)(t - t0); t0 = t; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (ABL & 64) { const uint64_t t = __builtin_readcyclecounter(); st_vm += (uint32_t)(t - t0); t0 = t; }
+        if constexpr (ABL & 64) { const uint64_t t = __builtin_readcyclecounter(); st_vm += (uint32_t)(t - t0); if constexpr (FIRST) st_vm_first += (uint32_t)(t - t0); t0 = t; }
         if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (ABL & 64) {
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmK p) {
   if constexpr (ABL & 64) {
     if (lane == 0 && p.slabs != nullptr) {
       float* o = p.slabs + (blockIdx.x * 4 + wave) * 8;
-      o[0] = (float)st_n; o[1] = (float)(st_last - st_first); o[2] = (float)st_lgkm; o[3] = (float)st_vm; o[4] = (float)st_bar; o[5] = (float)st_epi;
+      o[0] = (float)st_n; o[1] = (float)(st_last - st_first); o[2] = (float)st_lgkm; o[3] = (float)st_vm; o[4] = (float)st_bar; o[5] = (float)st_epi; o[6] = (float)st_vm_first;
     }
   }
 }
@@ -664,9 +664,10 @@ md_status md_gemm_w4_launch(const GemmK& k, int epi, hipStream_t stream) {
       case 256 * 2 + 32: return launch<MD_EPI_BIAS, 32, 2>(k, stream);
       case 256 * 2 + 46: return launch<MD_EPI_BIAS, 46, 2>(k, stream);
       case 256 * 2 + 64: return launch<MD_EPI_BIAS, 64, 2>(k, stream);
-      case 256 * 2 + 128: return launch<MD_EPI_BIAS, 128, 2>(k, stream);
+      case 256 * 2 + 80: return launch<MD_EPI_BIAS, 80, 2>(k, stream);
       case 256 * 2 + 256: return launch<MD_EPI_BIAS, 256, 2>(k, stream);
-      case 256 * 2 + 384: return launch<MD_EPI_BIAS, 384, 2>(k, stream);
+      case 256 * 2 + 272: return launch<MD_EPI_BIAS, 272, 2>(k, stream);
+      case 256 * 2 + 320: return launch<MD_EPI_BIAS, 320, 2>(k, stream);
       default: return MD_ERR_INVALID_ARG;
     }
   }

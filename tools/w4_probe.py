@@ -2,7 +2,7 @@
 """Timing ablations and in-kernel stamps of the four-wave 256x256 GEMM (gemm_w4.hip), bias epilogue.  Needs the measurement build
 (MD_W4_ABLATIONS=1 python -c "import __graft_entry__ as g; g.build()").  md_gemm_set_tuning "w4_variant" = MODE + 16 * ABL;
 MODE 0 = register-staged operands, 1-3 = LDS-DMA schedules; ABL bits: 2 no operand loads, 4 no barrier, 8 no fragment reads,
-16 no epilogue stores, 32 no epilogue, 64 = shader-clock stamps around the waits of gap 48 and the epilogue (results are garbage
+16 no epilogue stores, 32 no epilogue, 256 every operand load from one L2-resident MiB, 64 = shader-clock stamps around the waits of gap 48 and the epilogue (results are garbage
 with bits 2-32 set)."""
 import ctypes as C
 import math
@@ -20,9 +20,8 @@ from tools.sweep_gemm import timeit, stream
 lib = _lib.load()
 BF16 = torch.bfloat16
 V = lambda mode, abl: mode + 16 * abl
-VARIANTS = [("dma", V(0, 0)), ("no-dma", V(0, 2)), ("no-barrier", V(0, 4)), ("no-reads", V(0, 8)), ("mfma+epi", V(0, 14)),
-            ("no-stores", V(0, 16)), ("no-epi", V(0, 32)), ("mfma only", V(0, 46)), ("stores->2MiB window", V(0, 128)), ("sc1 stores", V(0, 256)),
-            ("sc0 sc1 stores", V(0, 384))]
+VARIANTS = [("full", V(0, 0)), ("no-dma", V(0, 2)), ("no-barrier", V(0, 4)), ("no-reads", V(0, 8)), ("mfma+epi", V(0, 14)),
+            ("no-stores", V(0, 16)), ("no-epi", V(0, 32)), ("mfma only", V(0, 46)), ("loads from 1 MiB", V(0, 256)), ("loads from 1 MiB, no stores", V(0, 272))]
 SHAPES = [(8192, 8192, 8192), (46720, 2048, 2048), (93312, 1152, 3456)]
 
 
@@ -54,22 +53,22 @@ if "stamps" not in sys.argv[1:]:
 dbg = torch.zeros(256 * 4 * 8, dtype=torch.float32, device="cuda")
 lib.md_gemm_set_tuning(b"w4_dbg_lo", C.c_int32(dbg.data_ptr() & 0xffffffff).value)
 lib.md_gemm_set_tuning(b"w4_dbg_hi", C.c_int32(dbg.data_ptr() >> 32).value)
-for mode in (0,):
+for abl, what in ((64, "stamps"), (80, "stamps, no epilogue stores"), (320, "stamps, loads from 1 MiB")):
     for m, k, n in SHAPES:
         keep = problem(m, k, n)
         args = keep[-1]
-        lib.md_gemm_set_tuning(b"w4_variant", V(mode, 64))
+        lib.md_gemm_set_tuning(b"w4_variant", V(0, abl))
         for _ in range(3):
             _lib.check(lib.md_gemm_bf16(C.byref(args), stream()))
         torch.cuda.synchronize()
         d = dbg.view(256, 4, 8).cpu()
-        tiles = ((m + 255) // 256) * ((n + 255) // 256)
         npair = d[:, :, 0]
+        tiles = npair / (k // 64)
         per = d[:, :, 1] / (npair - 1).clamp(min=1)
-        print(f"mode {mode} m={m} k={k} n={n}: pairs/wave {npair.mean():.0f}  cycles per pair (epilogues inside) {per.mean():.0f} "
+        print(f"{what}: m={m} k={k} n={n}: pairs/wave {npair.mean():.0f}  cycles per pair (epilogues inside) {per.mean():.0f} "
               f"| per pair: lgkm wait {(d[:, :, 2] / npair).mean():.0f}  vmcnt wait {(d[:, :, 3] / npair).mean():.0f} "
               f"(max wave {(d[:, :, 3] / npair).max():.0f})  barrier wait {(d[:, :, 4] / npair).mean():.0f} (max {(d[:, :, 4] / npair).max():.0f}) "
-              f"| epilogue + refill per tile {(d[:, :, 5] / (npair / (k // 64))).mean():.0f} cycles", flush=True)
+              f"| per tile: epilogue + refill {(d[:, :, 5] / tiles).mean():.0f} cycles, vmcnt wait of the first pair {(d[:, :, 6] / tiles).mean():.0f}", flush=True)
         del keep
 lib.md_gemm_set_tuning(b"w4_variant", 0)
 lib.md_gemm_set_tuning(b"tile", -1)

@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--vit-chunk", type=int, default=128, help="crops per ViT launch group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-oracle", action="store_true",
+                    help="skip the parity calibration: the reference's own ATen calls through torch-ROCm on the 64 bench images")
     ap.add_argument("--latency-runs", type=int, default=5)
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the auxiliary FP8-decode-weights leg")
     ap.add_argument("--no-fp8-full-leg", action="store_true", help="skip the auxiliary full-FP8 leg (fp8 MFMA for ViT / projector / prefill + fp8 decode weights)")
@@ -214,13 +216,61 @@ def cpu_baseline(cfg, sd, seed, T, budget_s=25.0):
     return 1.0 / est_total, cores, note
 
 
-def check_parity(model, images, prompts, ids_per_image, cfg_name, seed, prompt_kind, tokens):
+def second_oracle(cfg, sd, seed, tokens, device):
+    """Parity CALIBRATION (SURVEY 8c's second oracle): the oracle in ``fast`` mode = the reference's own ATen calls (bf16
+    F.linear, F.scaled_dot_product_attention under the bool mask over all 2048 slots, F.layer_norm, tanh-GELU) in the
+    reference's order, B = 1 sequential like the reference -- executed by torch-ROCm's kernels on THIS GPU instead of the
+    CPU kernels that wrote tests/golden/md2b_bench64.npz.  Same code, same weights, same images; only the BLAS / attention
+    backend differs.  Teacher-forced on the fixture's ids it yields (a) how many of the 64 sequences that second, equally
+    correct evaluation would have kept (every decision's argmax equal to the reference's token) and (b) its logit error at
+    the reference's top-8 candidates: the noise floor this build's own count and error are judged against.  A checker,
+    outside every timed region."""
+    from moondream_amd import synth
+    from oracle import moondream_oracle as O
+
+    path = os.path.join(REPO, "tests", "golden", "md2b_bench64.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    n, t = g["tokens"].shape[0], min(tokens, g["tokens"].shape[1])
+    aten_was, O.ATEN_CALLS = O.ATEN_CALLS, True
+    t0 = time.perf_counter()
+    try:
+        orc = O.Oracle(cfg, sd, fast=True, device=device)
+        prompt = g["prompt"].tolist()
+        exact, errs, first_div_margins = 0, [], []
+        with torch.inference_mode():
+            for i in range(n):
+                img = synth.synthetic_image_array(i, seed, (378, 378))
+                pos, kv = orc.encode_image(np.stack([img, img]), (1, 1))
+                run = orc.generate(prompt, pos, kv, max_tokens=t, eos_id=-1, forced=g["tokens"][i, :t].tolist())
+                lg = torch.stack([x.float().cpu() for x in run.logits[: t + 1]])  # [t + 1, V]
+                got = torch.gather(lg, 1, torch.as_tensor(g["top8_idx"][i, : t + 1], dtype=torch.int64)).numpy()
+                errs.append(np.abs(got - g["top8_val"][i, : t + 1])[np.isfinite(g["top8_val"][i, : t + 1])])
+                own = lg[:t].argmax(dim=1).numpy()  # (CPU argmax: lowest index among ties, like the reference's)
+                diff = np.nonzero(own != g["tokens"][i, :t])[0]
+                if len(diff) == 0:
+                    exact += 1
+                else:
+                    first_div_margins.append(float(g["margins"][i, diff[0]]))
+        e = np.concatenate(errs)
+        return {"exact": exact, "of": n, "max_logit_err": float(e.max()), "p99_logit_err": float(np.quantile(e, 0.99)),
+                "max_divergence_margin": max(first_div_margins, default=0.0), "seconds": round(time.perf_counter() - t0, 1),
+                "what": "oracle fast mode (the reference's own ATen calls, B=1) run by torch-ROCm on this GPU, teacher-forced on the "
+                        "reference's ids: sequences whose every argmax equals the reference's token / logit error at its top-8 candidates"}
+    finally:
+        O.ATEN_CALLS = aten_was
+
+
+def check_parity(model, images, prompts, ids_per_image, cfg_name, seed, prompt_kind, tokens, floor_from=None):
     """The ids this run generated against the REFERENCE's ids for the same images (tests/golden/md2b_bench64.npz,
     written by oracle/make_golden.py bench64 from the unmodified reference), with a MEASURED licence
     (moondream_amd/parity.py): the HIP path is run teacher-forced on the reference's ids and its logits at the
     reference's top-8 ids of all 64 x 33 decisions are compared with the reference's; a sequence may leave the
-    reference's stream only at a decision whose reference margin is <= 2 x the largest logit error measured there,
-    and at least 40 of the 64 sequences must be identical (a sanity floor: the fixture itself has 9 sequences with an exact tie and only 12 whose smallest margin exceeds 0.25, so the count moves by a few with any last-bit change -- 52 before, 46 after the RoPE products were un-contracted in round 3).  Outside the timed region."""
+    reference's stream only at a decision whose reference margin is <= min(2 x the largest logit error measured there, 0.5)
+    and which the errors measured on its own two logits cover; the count of identical sequences has a floor calibrated by the
+    second oracle of this very run (``exact_floor``; the fixture has 9 sequences with an exact tie and only 12 whose smallest
+    margin exceeds 0.25, so the count is a noisy statistic).  Outside the timed region."""
     from moondream_amd import parity as P
 
     path = os.path.join(REPO, "tests", "golden", "md2b_bench64.npz")
@@ -231,7 +281,20 @@ def check_parity(model, images, prompts, ids_per_image, cfg_name, seed, prompt_k
     t = min(tokens, g["tokens"].shape[1])
     got_topk = model.teacher_forced_logits(images[:n], prompts[:n], g["tokens"][:n, :t], g["top8_idx"][:n, : t + 1]).numpy()
     return P.parity_report([ids[:t] for ids in ids_per_image[:n]], g["tokens"][:n, :t].tolist(), g["margins"][:n],
-                           got_topk, g["top8_val"][:n, : t + 1], tokens=t, min_exact=(40 * n) // 64 if t == 32 else None)
+                           got_topk, g["top8_val"][:n, : t + 1], tokens=t, min_exact=exact_floor(n, t, floor_from),
+                           ref_topk_idx=g["top8_idx"][:n, : t + 1])
+
+
+def exact_floor(n, t, second):
+    """The floor on identical sequences.  With the second oracle's count N2 (of 64) from THIS run: N2 minus two binomial standard
+    deviations of a 64-trial count at that rate -- a build is not asked to agree with the reference more often than the
+    reference's own code does under another BLAS.  Without it (second oracle skipped): the flat 40 of round 3."""
+    if t != 32:
+        return None
+    if not second or second.get("of") != 64 or n != 64:
+        return (40 * n) // 64
+    n2 = second["exact"]
+    return max(0, int(n2 - np.ceil(2.0 * np.sqrt(max(n2 * (64 - n2), 1) / 64.0))))
 
 
 def detect13_leg(model, cfg, args, dev, fp8=False):
@@ -395,7 +458,14 @@ def main():
     parity = None
     if rank == 0 and out and out[-1] is not None and not args.only_timed_steps:
         ids_all = torch.cat([b.cpu() for b in out[-1]], 0).tolist()
-        parity = check_parity(model, images, prompts, ids_all[: len(images)], args.model, args.seed, args.prompt, T)
+        second = None
+        if world == 1 and not args.no_second_oracle and args.model == "2b" and args.seed == 1 and args.prompt == "caption":
+            second = second_oracle(cfg, sd, args.seed, T, dev)
+        parity = check_parity(model, images, prompts, ids_all[: len(images)], args.model, args.seed, args.prompt, T, floor_from=second)
+        if second is not None:
+            parity["parity_second_oracle"] = second
+            parity["parity_second_oracle_exact"] = second["exact"]
+            parity["parity_min_exact"] = exact_floor(len(images), T, second)
 
     if args.only_timed_steps:
         if rank == 0:

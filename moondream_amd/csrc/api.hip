@@ -401,6 +401,9 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       md_kv_cache sub = *kv;
       sub.k = (char*)kv->k + (int64_t)b0 * kv->batch_stride * 2;
       sub.v = (char*)kv->v + (int64_t)b0 * kv->batch_stride * 2;
+      // the e4m3 copy of the cache (fp8 mode) has the same slot layout at one byte per element
+      if (kv->k8) sub.k8 = (char*)kv->k8 + (int64_t)b0 * kv->batch_stride;
+      if (kv->v8) sub.v8 = (char*)kv->v8 + (int64_t)b0 * kv->batch_stride;
       MD_TRY(md_text_forward(m, (const char*)x_in + (int64_t)b0 * m->dim * 2, (char*)hidden + (int64_t)b0 * m->dim * 2, nb, 1,
                              pos0 + b0, &sub, workspace, workspace_bytes, stream));
     }

@@ -269,6 +269,9 @@ class MoondreamModel:
             return None
         if not calibration_images:
             raise ValueError("enable_fp8 needs a few calibration images (PIL) to size the activation scales")
+        # a previous call's e4m3 cache copy does not survive this one (kv_cache=False after kv_cache=True must really turn it off)
+        self._kv8_scales = None
+        self._kv_k8 = self._kv_v8 = None
         tpl = self.config.tokenizer.templates["caption"]
         prompt = list(prompt) if prompt is not None else list(tpl["normal"] if tpl else [self.config.tokenizer.bos_id])
         self.w.begin_f8_calibration()
@@ -279,7 +282,8 @@ class MoondreamModel:
                 torch.cuda.synchronize(self._device)
                 t = self.config.text
                 p1 = t.prefix_attn + len(prompt)
-                if kv_cache and decode_weights and t.n_heads == t.n_kv_heads and t.head_dim == 64:
+                # (the e4m3 decode attention keeps a context's scores in LDS: contexts of at most 2048 positions)
+                if kv_cache and decode_weights and t.n_heads == t.n_kv_heads and t.head_dim == 64 and t.max_context <= 2048:
                     # K / V ranges of the calibration batch per layer (rows 0 .. p1 - 1 of its slots: the prefill just written)
                     ka = self._kv_k[:, :n, :, :p1].float().abs().amax(dim=(1, 2, 3, 4)).cpu().tolist()
                     va = self._kv_v[:, :n, :, :p1].float().abs().amax(dim=(1, 2, 3, 4)).cpu().tolist()
@@ -287,6 +291,10 @@ class MoondreamModel:
                     self._kv8_scales = ((C.c_float * t.n_layers)(*[sc(a) for a in ka]), (C.c_float * t.n_layers)(*[sc(a) for a in va]))
                     self._kv_k8 = torch.zeros(self._kv_k.shape, dtype=torch.uint8, device=self._device)
                     self._kv_v8 = torch.zeros_like(self._kv_k8)
+                    # slots that already hold sequences (load_encoded_image before this call): their e4m3 rows are built now
+                    kv = self._kv_struct(0)
+                    _lib.check(self.lib.md_kv_quantize_f8(C.byref(kv), t.n_layers, int(self._kv_k.shape[1]), t.n_kv_heads, None, 0,
+                                                          int(t.max_context), self._stream()), "md_kv_quantize_f8")
             info = self.w.finish_f8_calibration(margin)
             info["kv_cache_fp8"] = self._kv8_scales is not None
         except Exception:
@@ -1089,9 +1097,10 @@ class MoondreamModel:
         """Parity instrument (tests / bench.py): the logits of every greedy decision when each sequence is FORCED to follow
         ``forced_ids[i]`` (the reference's ids) instead of its own argmax, gathered at ``gather_idx[i][j]`` (the reference's
         top-k ids of decision j).  Decision 0 is the prompt prefill's, decision j the decode step that consumed
-        forced_ids[i][j-1] -- the same launches as ``batch_generate_ids`` (fused or two-pass prefill as configured, the
-        batched decode step; at B=1 the persistent kernel if enabled), so the error measured here is the error of the ids'
-        own logits.  Returns float32 [B, T+1, k] on the CPU (``answer_id`` suppressed from decision 1 on, moondream.py:517)."""
+        forced_ids[i][j-1] -- the same launches as ``batch_generate_ids`` at B > 1 (fused or two-pass prefill as configured, the
+        batched decode step ``md_decode_step``), so the error measured here is the error of the ids' own logits.  At B = 1
+        with ``single_sequence_kernel`` on, generation uses the persistent single-sequence kernel and this method still the
+        batched one: it certifies batches, not that kernel (which tests/test_model_gpu.py compares separately).  Returns float32 [B, T+1, k] on the CPU (``answer_id`` suppressed from decision 1 on, moondream.py:517)."""
         b = len(images)
         forced = torch.as_tensor(np.asarray(forced_ids), dtype=torch.int32)
         idx = torch.as_tensor(np.asarray(gather_idx), dtype=torch.int64)

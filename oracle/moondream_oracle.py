@@ -194,7 +194,7 @@ def vit_attention(x, sd, prefix, n_heads, fast=False):
 def vision_encoder(x_bchw: torch.Tensor, sd, cfg, tap: Optional[dict] = None, fast=False):
     """reference: vision.py:64-74.  Residual adds are bf16 + bf16 -> bf16."""
     v = cfg.vision
-    x = patchify(x_bchw, v.enc_patch_size)
+    x = patchify(x_bchw, v.enc_patch_size).to(sd["vision.patch_emb.weight"].device)  # (the weights' device: Oracle(device=...))
     x = linear(x, sd["vision.patch_emb.weight"], sd["vision.patch_emb.bias"], fast)
     x = _r(x.float() + sd["vision.pos_emb"].float())
     if tap is not None:
@@ -270,7 +270,7 @@ def adaptive_avg_pool_hw(x_hwc: torch.Tensor, out_hw: int) -> torch.Tensor:
 def vision_projection(global_feat, stitched, sd, cfg, fast=False):
     """reference: vision.py:77-89."""
     g = cfg.vision.enc_n_layers  # sic: the reference uses enc_n_layers as the grid side
-    pooled = adaptive_avg_pool_hw(stitched, g).reshape(g * g, -1)
+    pooled = adaptive_avg_pool_hw(stitched.cpu(), g).reshape(g * g, -1).to(global_feat.device)
     return mlp(torch.cat([global_feat, pooled], dim=-1), sd, "vision.proj_mlp", fast)
 
 
@@ -280,7 +280,7 @@ def run_vision(crops_u8: np.ndarray, tiling, sd, cfg, tap=None, fast=False):
     x = normalize_crops(crops_u8)
     feats = vision_encoder(x, sd, cfg, tap, fast)
     g = v.enc_n_layers
-    local = feats[1:].reshape(-1, g, g, v.enc_dim)
+    local = feats[1:].reshape(-1, g, g, v.enc_dim).cpu()  # the stitch / pool restatements are host loops
     stitched = stitch_local_features(local, tiling, v.overlap_margin)
     out = vision_projection(feats[0], stitched, sd, cfg, fast)
     if tap is not None:
@@ -320,7 +320,7 @@ def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch
 def prefix_lm_allowed(q_pos: torch.Tensor, n_kv: int, prefix: int) -> torch.Tensor:
     """bool [Tq, n_kv]: key j visible to query at position i iff j <= i, or both
     lie inside the bidirectional prefix.  reference: moondream.py:138-146."""
-    j = torch.arange(n_kv).unsqueeze(0)
+    j = torch.arange(n_kv, device=q_pos.device).unsqueeze(0)
     i = q_pos.unsqueeze(1)
     return (j <= i) | ((i < prefix) & (j < prefix))
 
@@ -333,12 +333,12 @@ class OracleKV:
     v: List[torch.Tensor] = field(default_factory=list)
 
     @classmethod
-    def empty(cls, cfg):
+    def empty(cls, cfg, device="cpu"):
         t = cfg.text
         shape = (t.n_kv_heads, t.max_context, t.head_dim)
         return cls(
-            [torch.zeros(shape, dtype=BF16) for _ in range(t.n_layers)],
-            [torch.zeros(shape, dtype=BF16) for _ in range(t.n_layers)],
+            [torch.zeros(shape, dtype=BF16, device=device) for _ in range(t.n_layers)],
+            [torch.zeros(shape, dtype=BF16, device=device) for _ in range(t.n_layers)],
         )
 
     def clone(self):
@@ -442,46 +442,54 @@ class OracleRun:
 
 
 class Oracle:
-    """Greedy encode_image + generate, B=1, like the reference's sequential path."""
+    """Greedy encode_image + generate, B=1, like the reference's sequential path.
 
-    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], fast: bool = False):
+    ``device``: where the tensor arithmetic runs.  "cpu" is the oracle proper.  With ``fast=True`` and a GPU device the SAME
+    calls -- the reference's own ATen ops (F.linear, F.scaled_dot_product_attention, F.layer_norm, F.gelu) in the reference's
+    order -- run through torch-ROCm's kernels: SURVEY section 8(c)'s "second oracle" for bf16 last-bit behaviour, i.e. what
+    happens to the reference's ids when nothing but the BLAS / attention backend changes (bench.py's parity calibration)."""
+
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], fast: bool = False, device="cpu"):
         self.cfg = cfg
-        self.sd = {k: v.detach().to("cpu") for k, v in state_dict.items()}
+        self.device = torch.device(device)
+        self.sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
         self.fast = fast
         self.lora = None  # nested LoRA dict (lora.py:54-79) applied by every decoder call below when set
-        self.cos, self.sin = rope_table(cfg.text.rot_dim // 2, cfg.text.max_context)
+        cos, sin = rope_table(cfg.text.rot_dim // 2, cfg.text.max_context)
+        self.cos, self.sin = cos.to(self.device), sin.to(self.device)
 
     def embed(self, ids) -> torch.Tensor:
         """reference: text.py:12-13."""
-        return self.sd["text.wte"][torch.as_tensor(ids, dtype=torch.long)]
+        return self.sd["text.wte"][torch.as_tensor(ids, dtype=torch.long, device=self.device)]
 
     def encode_image(self, crops_u8: np.ndarray, tiling, tap=None) -> Tuple[int, OracleKV]:
         """reference: moondream.py:230-268.  Returns (pos, kv)."""
         img = run_vision(crops_u8, tiling, self.sd, self.cfg, tap, self.fast)
         x = torch.cat([self.embed([self.cfg.tokenizer.bos_id]), img], dim=0)
-        kv = OracleKV.empty(self.cfg)
-        pos = torch.arange(x.shape[0])
+        kv = OracleKV.empty(self.cfg, self.device)
+        pos = torch.arange(x.shape[0], device=self.device)
         text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast, lora=self.lora)
         return x.shape[0], kv
 
     def prefill_prompt(self, prompt_ids, pos0: int, kv: OracleKV, tap=None, prompt_emb=None, prefix=None):
         """reference: moondream.py:280-321 (greedy branch)."""
         x = self.embed(prompt_ids) if prompt_emb is None else prompt_emb
-        pos = torch.arange(pos0, pos0 + x.shape[0])
+        pos = torch.arange(pos0, pos0 + x.shape[0], device=self.device)
         h = text_decoder(x, self.sd, self.cfg, kv, pos, self.cos, self.sin, tap, self.fast, prefix, lora=self.lora)
         logits = lm_head(h[-1], self.sd, self.fast)
         return logits, h, pos0 + x.shape[0]
 
     def decode_token(self, emb: torch.Tensor, pos: int, kv: OracleKV, prefix=None):
         """reference: moondream.py:183-192.  emb [1, D]."""
-        h = text_decoder(emb, self.sd, self.cfg, kv, torch.tensor([pos]), self.cos, self.sin, None, self.fast, prefix, lora=self.lora)
+        h = text_decoder(emb, self.sd, self.cfg, kv, torch.tensor([pos], device=self.device), self.cos, self.sin, None, self.fast, prefix, lora=self.lora)
         return lm_head(h[-1], self.sd, self.fast), h
 
     @staticmethod
     def _argmax_margin(logits: torch.Tensor):
-        top = torch.topk(logits.float(), 2)
+        logits = logits.float().cpu()  # (ties: the reference's argmax runs on the CPU)
+        top = torch.topk(logits, 2)
         # torch.argmax returns the lowest index among ties on CPU; topk need not
-        tok = int(torch.argmax(logits.float()))
+        tok = int(torch.argmax(logits))
         return tok, float(top.values[0] - top.values[1])
 
     def generate(

@@ -52,7 +52,41 @@ def test_a_broken_kernel_cannot_buy_itself_a_wide_licence():
     margins[2, 0] = 1.5
     got_topk = ref_topk + 1.0           # error 1.0 would license margins up to 2.0 -- but it is above the cap
     rep = P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6, max_err_cap=0.75)
-    assert not rep["parity_ok"] and "LOGIT ERROR ABOVE CAP" in rep["parity_note"]
+    assert not rep["parity_ok"] and "LOGIT ERROR ABOVE ITS CAPS" in rep["parity_note"]
+    # ... and ONE outlier under the cap does not widen the licence past the flat 0.5 either
+    got_topk = ref_topk.copy()
+    got_topk[0, 0, 0] += 0.45
+    margins[2, 0] = 0.75                # 2 x 0.45 = 0.9 would have covered it
+    rep = P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6)
+    assert not rep["parity_ok"] and rep["parity_threshold"] == 0.5
+    # many small errors that are large in ULPS (tiny logits) trip the p99 gate
+    small = np.full_like(ref_topk, 0.01)
+    rep = P.parity_report([list(r) for r in ref_ids], ref_ids, margins, small + 0.002, small, tokens=6)
+    assert not rep["parity_ok"] and rep["parity_p99_logit_err_ulps"] > 12
+
+
+def test_a_divergence_must_be_covered_by_the_errors_on_its_own_logits():
+    ref_ids, margins, ref_topk = _case()
+    n, t1, k = ref_topk.shape
+    ref_topk = -np.sort(-ref_topk, axis=2)                      # candidates in descending order, as the fixtures store them
+    idx = np.tile(np.arange(100, 100 + k), (n, t1, 1))
+    for i in range(n):
+        for j in range(t1 - 1):
+            idx[i, j, 0] = ref_ids[i][j]                        # the reference's winner is candidate 0
+    got = [list(r) for r in ref_ids]
+    got[1][3] = int(idx[1, 3, 1])                               # this run picked the reference's runner-up at decision 3
+    ref_topk[1, 3, 1] = ref_topk[1, 3, 0] - 0.25                # the reference preferred its winner by 0.25
+    margins[1, 3] = 0.25
+    got_topk = ref_topk.copy()
+    got_topk[0, 0, 0] += 0.25                                   # a global max error of 0.25 (licence 0.5) somewhere else ...
+    rep = P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6, ref_topk_idx=idx)
+    assert not rep["parity_ok"] and "UNCOVERED" in rep["parity_note"]   # ... does not explain THIS decision: its own logits are exact
+    got_topk[1, 3, 1] += 0.1875
+    got_topk[1, 3, 0] -= 0.0625                                 # errors on exactly these two logits: 0.25 in total -> covered
+    assert P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6, ref_topk_idx=idx)["parity_ok"]
+    got[1][3] = 7                                               # a token the reference did not even rank
+    rep = P.parity_report(got, ref_ids, margins, got_topk, ref_topk, tokens=6, ref_topk_idx=idx)
+    assert not rep["parity_ok"] and "outside the reference's recorded candidates" in rep["parity_note"]
 
 
 def test_exact_count_floor_and_flat_licence_without_logits():

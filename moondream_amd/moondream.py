@@ -18,6 +18,7 @@ constructor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Any, Dict, Iterable, List, Literal, Optional, Sequence, Tuple, Union
@@ -148,6 +149,17 @@ class MoondreamModel:
 
     def _stream(self) -> C.c_void_p:
         return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _h2d(self, t: torch.Tensor) -> torch.Tensor:
+        """Small host tensor -> device WITHOUT stalling the host: a copy from pageable memory blocks the calling thread until the
+        stream has reached it (on the pipelined engine's streams: until the whole encode in front of it has run); from pinned
+        memory it is queued like a kernel."""
+        if t.device.type != "cpu":
+            return t.to(self._device)
+        with torch.inference_mode(False):
+            pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        pinned.copy_(t)
+        return pinned.to(self._device, non_blocking=True)
 
     def _setup_caches(self, max_batch: Optional[int] = None):
         """Zeroed KV slabs [L][B][H_kv][ctx][hd] (reference: moondream.py:62-72,152-162)."""
@@ -316,11 +328,18 @@ class MoondreamModel:
         self.single_sequence_kernel = not on
         self.fused_prefill = not on
         self.strict_batch_invariance = bool(on)
-        # the library's tile choice by row count would give a lone image (730 / 1458 rows) the small-shape configs and a batch
-        # the four-wave kernel, whose 16x16x32 MFMAs sum K in another association: strict mode pins the four-wave kernel for
-        # every launch of more than 64 rows (a process-wide library knob)
-        _lib.check(self.lib.md_gemm_set_tuning(b"strict", 1 if on else 0))
+        self._select_kernels(1)
         self._graphs.clear()
+
+    def _select_kernels(self, n_sequences: int):
+        """The library's tile choice by row count would give a lone image (730 / 1458 rows) the small-shape tile configs and a
+        batch the four-wave kernel, whose 16x16x32 MFMAs sum K in another association.  Since round 4 every call is made with
+        the four-wave kernel PINNED for launches of more than 64 rows (a process-wide library knob) -- so that
+        ``batch_generate_ids(B)[i] == batch_generate_ids([x_i])`` holds bit for bit in the DEFAULT mode as long as the lone
+        sequence runs on the batched kernels -- except the documented latency path: ONE sequence with
+        ``single_sequence_kernel`` on (small-shape tiles at prefill, the persistent kernel at decode)."""
+        pin = 1 if (self.strict_batch_invariance or not (n_sequences == 1 and self.single_sequence_kernel)) else 0
+        _lib.check(self.lib.md_gemm_set_tuning(b"strict", pin))  # (set on every call: the knob is the library's, not this model's)
 
     def compile(self):
         """The reference rebinds the seam to torch.compile'd functions here
@@ -412,7 +431,7 @@ class MoondreamModel:
             pos0 = torch.full((b,), pos0, dtype=torch.int32, device=self._device)
         else:
             assert len(pos0) == b
-            pos0 = torch.tensor([int(p) for p in pos0], dtype=torch.int32, device=self._device)
+            pos0 = self._h2d(torch.tensor([int(p) for p in pos0], dtype=torch.int32))
         text = self._causal_text_struct() if causal else self.w.text
         self._ensure_batch(slot0 + b)
         x = x.contiguous()
@@ -471,7 +490,7 @@ class MoondreamModel:
             lo, hi = int(ids.min()), int(ids.max())
             if lo < 0 or hi >= self.config.text.vocab_size:
                 raise ValueError(f"token id out of range [0, {self.config.text.vocab_size}): {lo if lo < 0 else hi}")
-        flat = ids.reshape(-1).to(device=self._device, dtype=torch.int32).contiguous()
+        flat = self._h2d(ids.reshape(-1).to(torch.int32).contiguous())
         d = self.config.text.dim
         out = torch.empty(flat.numel(), d, dtype=BF16, device=self._device)
         _lib.check(
@@ -486,7 +505,7 @@ class MoondreamModel:
         oc = overlap_crop_image(arr, max_crops=v.max_crops, overlap_margin=v.overlap_margin)
         return oc["crops"], tuple(oc["tiling"])
 
-    def _run_vision_encoder_batch(self, images: Sequence[Image.Image], mark=None) -> torch.Tensor:
+    def _run_vision_encoder_batch(self, images: Sequence[Image.Image], mark=None, staged=None) -> torch.Tensor:
         """images -> [B,729,D] projected embeddings (reference: moondream.py:206-228, per image).
 
         Host tiling (PIL, reference image_crops.py:58-167) runs on a thread pool and is
@@ -498,7 +517,7 @@ class MoondreamModel:
         v = self.config.vision
         n_img = len(images)
         pre = getattr(self, "_prefetched_crops", {}).pop(tuple(id(im) for im in images), None)
-        chunks, staged = pre[1] if pre is not None else self._stage_crops(images)
+        chunks, staged = staged if staged is not None else pre[1] if pre is not None else self._stage_crops(images)
         cropped: List[Tuple[np.ndarray, Tuple[int, int]]] = []
         feat_parts = []
         for ci, ((c0, c1, tot), (host, token, futs)) in enumerate(zip(chunks, staged)):
@@ -688,10 +707,14 @@ class MoondreamModel:
                 n = len(os.sched_getaffinity(0))
             except AttributeError:
                 n = os.cpu_count() or 1
-            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(32, n)))
+            # one process per GPU: the ranks of a node share its cores (8 ranks x 32 workers + prefetch workers would
+            # oversubscribe a 256-thread host)
+            ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(32, n // ranks_here - 2 if ranks_here > 1 else n)))
         return pool
 
     def _run_vision_encoder(self, image: Image.Image) -> torch.Tensor:
+        self._select_kernels(1)
         return self._run_vision_encoder_batch([image])[0]
 
     def _prefill_images(self, img_emb: torch.Tensor, slot0: int = 0, lora: Optional[PackedLora] = None) -> int:
@@ -824,7 +847,7 @@ class MoondreamModel:
         need = self.lib.md_decode_workspace_bytes(C.byref(self.w.text), b)
         ws = self._workspace(need, 2)
         kv = self._kv_struct(slot0)
-        pos_base = torch.tensor(pos_list, dtype=torch.int32, device=self._device)
+        pos_base = self._h2d(torch.tensor(pos_list, dtype=torch.int32))
 
         # one sequence, greedy, no side path: the whole step as ONE persistent launch (csrc/decode_b1.hip) when the library
         # says this model / cache / device fits its static limits and its grid can be co-resident; anything else decodes on
@@ -960,6 +983,7 @@ class MoondreamModel:
         order; ``order[slot]`` is the caller's index.  Must run under torch.inference_mode()."""
         mark = mark or (lambda name: None)
         b = len(images)
+        self._select_kernels(b)
         order = sorted(range(b), key=lambda i: len(prompts[i]))
         images = [images[i] for i in order]
         prompts = [list(prompts[i]) for i in order]
@@ -1053,14 +1077,19 @@ class MoondreamModel:
         load_encoded_image -> _generate_answer with temperature 0) returns for
         (images[i], prompts[i]).  Every BATCHED kernel's accumulation order is a
         function of the layer shape only, never of the number of sequences in
-        the launch, so under ``set_strict_batch_invariance(True)`` this holds bit
-        for bit (tested on the 64 unfiltered bench images at 2B).  By default two
-        shortcuts change the accumulation order between the two sides -- raw
-        images take ONE fused [image | prompt] decoder pass here where
-        ``caption`` makes the reference's two, and a lone sequence decodes on the
-        persistent single-sequence kernel -- so then the two sides agree within
-        bf16 accumulation-order noise: ids can differ only from a decision on
-        whose top-1/top-2 logit margin is inside that noise.
+        the launch.  DEFAULT mode (round 4): ``batch_generate_ids(B)[i] ==
+        batch_generate_ids([x_i])`` BIT FOR BIT whenever the lone sequence runs
+        on the batched kernels (``single_sequence_kernel = False``): every launch
+        of more than 64 rows takes the same four-wave GEMM whatever the batch
+        (``_select_kernels``).  The one documented exception is the latency path
+        of a lone sequence (``single_sequence_kernel`` on, the default: small
+        tiles at prefill, the persistent kernel at decode), which agrees within
+        bf16 accumulation-order noise.  ``caption`` / ``query`` on an
+        ``EncodedImage`` make the reference's TWO decoder passes where a raw
+        image takes one fused [image | prompt] pass here; equality with THAT
+        path bit for bit is ``set_strict_batch_invariance(True)`` (two passes
+        everywhere, priced in bench.py's ``strict_batch_invariance`` leg).
+        Tested on the 64 unfiltered bench images at 2B.
         """
         b = len(images)
         assert b == len(prompts) and b > 0
@@ -1137,33 +1166,66 @@ class MoondreamModel:
     def _streams(self):
         st = getattr(self, "_pipe_streams", None)
         if st is None:
-            enc = torch.cuda.Stream(device=self._device)
-            dec = torch.cuda.Stream(device=self._device, priority=-1)  # short decode kernels jump the queue
-            st = self._pipe_streams = (enc, dec)
+            st = self._pipe_streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device, priority=-1))
         return st
 
+    pipeline_streams = int(os.environ.get("MD_PIPE_STREAMS", "2"))  # 2: decode on its own (priority) stream; 1: encode and decode in order on one stream
+
     def batch_generate_ids_pipelined(self, batches, max_tokens: int = DEFAULT_MAX_TOKENS, ignore_eos: bool = False):
-        """Generator over an iterable of (images, prompt-id lists) batches; yields each
-        batch's greedy ids in order.  Two HIP streams: the MFMA-bound encode (vision +
-        image prefill + prompt prefill) of batch k+1 runs on the encode stream while
-        the HBM-bound lockstep decode of batch k runs on the high-priority decode
-        stream, over disjoint KV-slab slot groups and disjoint workspaces.  Per batch the
-        result is identical to ``batch_generate_ids`` (same kernels, same order)."""
+        """Generator over an iterable of (images, prompt-id lists) batches; yields each batch's greedy ids in order, one
+        batch late.  Two HIP streams: the MFMA-bound encode (vision + prefill) of batch k+1 on one, the HBM-bound lockstep
+        decode of batch k on a second, higher-priority one, over disjoint KV-slab slot groups and disjoint workspaces.
+
+          * The two streams' kernels DO overlap on the GPU (profiles/r04_pipelined_engine_streams_ab.txt: 50-86 % of a
+            decode kernel's time has a tile GEMM or prefill attention running beside it; each side runs slower, the step
+            as a whole is 3 % shorter than with every kernel in order on one stream: 260.5 vs 269 ms on the same box --
+            ``pipeline_streams = 1`` / MD_PIPE_STREAMS=1 is that one-stream engine).
+          * The host tiling of batch k+1 (PIL resize + crop cutting, ~26 ms at B = 64) is started on the thread pool as
+            soon as batch k's crops are cut, i.e. under batch k's GPU time.
+          * The ids of batch k travel to pinned host memory behind its last decode step and are collected after batch
+            k+1 has been queued; nothing touches the default stream and no host array is copied from pageable memory
+            (either makes the host wait for the device).
+
+        Per batch the result is identical to ``batch_generate_ids`` (same kernels, same order)."""
+        pending = []
+        it = iter(batches)
+        cur = next(it, None)
+        staged = self._stage_crops(list(cur[0])) if cur is not None else None
+        try:
+            yield from self._pipelined_loop(it, cur, staged, pending, max_tokens, ignore_eos)
+        finally:
+            st = getattr(self, "_pipe_staged", None)  # a consumer that stops early: the tiling started ahead is drained, its buffers returned
+            self._pipe_staged = None
+            if st is not None:
+                for host, token, futs in st[1]:
+                    for f in futs:
+                        f.result()
+                    self._release_pinned(token)
+
+    def _pipelined_loop(self, it, cur, staged, pending, max_tokens, ignore_eos):
         tk = self.config.tokenizer
         eos = tk.eos_id
-        enc_s, dec_s = self._streams()
-        pending = []
+        run_s, dec_s = self._streams()
+        if self.pipeline_streams not in (2, 3):
+            dec_s = run_s
         group = 0
-        for images, prompts in batches:
+        self._pipe_staged = staged
+        while cur is not None:
+            images, prompts = cur
+            images = list(images)
             b = len(images)
             assert b == len(prompts) and b > 0 and len({len(p) for p in prompts}) == 1
             self._ensure_batch(2 * b)
+            self._select_kernels(b)
             slot0 = group * b
             group ^= 1
+            nxt = next(it, None)
             with torch.inference_mode():
-                enc_s.wait_stream(torch.cuda.current_stream(self._device))
-                with torch.cuda.stream(enc_s):
-                    img_emb = self._run_vision_encoder_batch(list(images))
+                run_s.wait_stream(torch.cuda.current_stream(self._device))
+                with torch.cuda.stream(run_s):
+                    img_emb = self._run_vision_encoder_batch(images, staged=staged)
+                    # this batch's crops are cut and queued for upload: the pool is free for the next batch's tiling
+                    staged = self._pipe_staged = self._stage_crops(list(nxt[0])) if nxt is not None else None
                     if self.fused_prefill:  # [bos | image | prompt] in one decoder pass, as in _prepare_sequences
                         bos = self._embed(torch.full((b, 1), tk.bos_id, dtype=torch.int32))
                         x = torch.cat([bos, img_emb, self._embed(torch.tensor(prompts, dtype=torch.int32))], dim=1)
@@ -1173,17 +1235,28 @@ class MoondreamModel:
                         pos = self._prefill_images(img_emb, slot0)
                         logits, _, p1 = self._prefill_prompts(prompts, pos, slot0)
                     first = self._pick(logits, 0.0, 0.0)
-                    ev = torch.cuda.Event()
-                    ev.record(enc_s)
+                    if dec_s is not run_s:
+                        ev = torch.cuda.Event()
+                        ev.record(run_s)
                 with torch.cuda.stream(dec_s):
-                    dec_s.wait_event(ev)
-                    first.record_stream(dec_s)
+                    if dec_s is not run_s:
+                        dec_s.wait_event(ev)
+                        first.record_stream(dec_s)
                     hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, slot0, None, check_every=16, allow_b1=False)
+                    # ids -> PINNED host memory behind the last decode step (a ``.tolist()`` at collection time is a
+                    # synchronous copy on the default stream: it waits for everything queued on the device)
+                    if self.pipeline_streams == 3:  # measurement only: rounds 1-3's collection (synchronous copy on the default stream)
+                        hist_host = hist
+                    else:
+                        with torch.inference_mode(False):
+                            hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+                        hist_host.copy_(hist, non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(dec_s)
-            pending.append((hist, done, b))
+            pending.append((hist_host, done, b))
             if len(pending) > 1:
                 yield self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
+            cur = nxt
         while pending:
             yield self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
 

@@ -866,7 +866,8 @@ def batch_equals_sequential_unfiltered(model, imgs64, prompt, got64_default, ref
     """test_batch_equals_sequential_unfiltered (run inside the 2B test: one 2B model per session).  The 64 UNFILTERED bench
     images, Moondream-2B, 32 greedy tokens.
       strict mode (set_strict_batch_invariance): B=64 batch == 64 sequential B=1 calls == caption() BIT FOR BIT;
-      default mode (fused prefill at any B, persistent kernel at B=1): counted, and wherever batch and sequential part
+      default mode: B=64 batch == 64 sequential B=1 calls on the batched kernels BIT FOR BIT (round 4: the four-wave GEMM is
+      pinned for every launch of more than 64 rows); against the B=1 LATENCY path (small tiles + persistent kernel): counted, and wherever batch and sequential part
       while both still follow the reference's stream, the reference margin of that decision must be inside the
       measured noise threshold."""
     n = len(imgs64)
@@ -879,6 +880,14 @@ def batch_equals_sequential_unfiltered(model, imgs64, prompt, got64_default, ref
         assert [int(t) for t in cap.split()] == strict_seq[3][: len(cap.split())]
     finally:
         model.set_strict_batch_invariance(False)
+    # DEFAULT mode, the lone sequence on the batched kernels: the benchmarked batch path == sequential, bit for bit
+    try:
+        model.single_sequence_kernel = False
+        seq_batched = [model.batch_generate_ids([im], [prompt], max_tokens=32, ignore_eos=True)[0] for im in imgs64]
+    finally:
+        model.single_sequence_kernel = True
+    assert got64_default == seq_batched, [i for i in range(n) if got64_default[i] != seq_batched[i]]
+    print("batch vs sequential, DEFAULT mode: batch(B=64) == 64 x batch_generate_ids([x]) on the batched kernels, 64/64 bit-identical")
     seq_default = [model.batch_generate_ids([im], [prompt], max_tokens=32, ignore_eos=True)[0] for im in imgs64]
     same_ds = sum(a == b for a, b in zip(got64_default, seq_default))
     same_strict = sum(a == b for a, b in zip(got64_default, strict_batch))

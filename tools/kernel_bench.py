@@ -101,6 +101,7 @@ if __name__ == "__main__":
             bench_gemm(m, k, n, epi)
     if "attn" in which:
         bench_attn(32, 16, 729, 72)
+        bench_attn(128, 16, 729, 72)
         bench_attn(64, 32, 730, 64, prefix=730)
     if "decode" in which:
         bench_decode_attn(64, 32, 770)

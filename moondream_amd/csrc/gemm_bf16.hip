@@ -767,7 +767,7 @@ md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse*
   k.K = a->lin.k_pad;
   k.res_row_mod = a->res_row_mod;
   k.tiles_m = k.tiles_n = 0;
-  k.group_m = knobs().group_m > 0 ? knobs().group_m : md_gemm_auto_group_m(k.n_store);
+  k.group_m = knobs().group_m > 0 ? knobs().group_m : knobs().group_m < 0 ? md_gemm_auto_group_m(k.n_store) : md_gemm_auto_group_m_w4(k.n_store, k.K);
   k.gelu_from = a->gelu_from_col;
   k.partial = nullptr;
   k.partial_ld = k.partial_slice_stride = 0;
@@ -968,13 +968,24 @@ bool md_gemm_knob_rope_fuse() { return knobs().rope_fuse != 0; }
 // panels of a few row panels at a time (group_m = 1: every activation panel crosses the fabric once), wide layers want a
 // squarer block (4; 8 was the value until round 3 and is 2-4 % slower on the long-K narrow layers, never faster).
 int md_gemm_auto_group_m(int n_store) { return (n_store + 255) / 256 <= 8 ? 1 : 4; }
+// Round 4, re-swept on the LDS-DMA / 16x16x32 four-wave kernel (profiles/r04_gemm_tile_order_group_m.txt): the narrowest layers
+// (N = 1152: 4.5 column panels) want 2 row panels per group, 8-panel layers 8 when K is short (text proj) and 1 when it is
+// long (fc2: the weight panel of a long-K layer is what an XCD's L2 should keep), 9-17 panels (ViT qkv / fc1) 8, wider ones 4.
+// md_gemm_set_tuning("group_m", -1) selects round 3's rule above.
+int md_gemm_auto_group_m_w4(int n_store, int k) {
+  const int panels = (n_store + 255) / 256;
+  if (panels <= 5) return 2;
+  if (panels <= 8) return k <= 4096 ? 8 : 1;
+  if (panels <= 17) return 8;
+  return 4;
+}
 
 extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   MD_CHECK_ARG(key != nullptr);
   Knobs& k = knobs();
   const std::string s(key);
   if (s == "tile") k.tile = value;
-  else if (s == "group_m") k.group_m = std::max(0, (int)value);
+  else if (s == "group_m") k.group_m = std::max(-1, (int)value);
   else if (s == "w4") k.w4 = value;
   else if (s == "persist") k.persist = value;
   else if (s == "decode_nt") k.nt = value;

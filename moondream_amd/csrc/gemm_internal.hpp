@@ -53,7 +53,8 @@ struct md_rope_fuse_f8 {
   void* v8slab;
   float k_scale, v_scale;
 };
-int md_gemm_auto_group_m(int n_store);  // tile-order grouping by shape (gemm_bf16.hip)
+int md_gemm_auto_group_m(int n_store);  // tile-order grouping by shape (gemm_bf16.hip): round 3's rule (eight-wave kernels, fp8 kernel)
+int md_gemm_auto_group_m_w4(int n_store, int k);  // the four-wave kernel's, re-swept in round 4
 bool md_gemm_knob_rope_fuse();  // MD_ROPE_FUSE / md_gemm_set_tuning("rope_fuse"): A/B and tests
 md_status md_gemm_f8_qkv_rope(const md_gemm_f8_args* a, const md_rope_fuse* rf, const md_rope_fuse_f8* rf8, hipStream_t stream);
 

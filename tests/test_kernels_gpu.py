@@ -393,6 +393,83 @@ def test_block_tail_partials_then_reduce_residual_layernorm(lib, m, dim, ka, kb)
 
 
 
+@pytest.mark.parametrize("m", [64, 5])
+def test_decode_block_chain_under_graph_replay(lib, m):
+    """The decode regime's launch chain -- fused [qkv | fc1] GEMM with its in-launch split-K workspace (GELU on the fc1 columns),
+    proj + fc2 as one launch of K-slice partials, the block tail (slice sums, bias, both residual adds, next layer norm) -- twice in
+    a row (two "blocks": the second consumes the first's layer-norm output), captured into ONE hipGraph over fixed buffers and
+    replayed with CHANGING inputs: replay(A), replay(B), replay(A) must equal the eager launches of the same inputs bit for bit.
+    Round 3's rejected fragment-prefetch patch passed every kernel test and broke the model only under graph replay
+    (profiles/r03_decode_gemm_where_the_time_goes.txt): this is the kernel-level test of that path -- state that survives a launch
+    (split-K tickets, anything a kernel leaves behind for "the next launch") shows up as a replay that differs from eager."""
+    dim, ff = 256, 1024
+    n_fused = 3 * dim + ff
+    blocks = []
+    for b in range(2):
+        w_f, b_f = randn(n_fused, dim, scale=1 / math.sqrt(dim), seed=900 + 10 * b), randn(n_fused, scale=0.1, seed=901 + 10 * b)
+        w_p, b_p = randn(dim, dim, scale=1 / math.sqrt(dim), seed=902 + 10 * b), randn(dim, scale=0.1, seed=903 + 10 * b)
+        w_2, b_2 = randn(dim, ff, scale=1 / math.sqrt(ff), seed=904 + 10 * b), randn(dim, scale=0.1, seed=905 + 10 * b)
+        lw, lb = randn(dim, scale=0.1, seed=906 + 10 * b) + 1.0, randn(dim, scale=0.1, seed=907 + 10 * b)
+        blocks.append((PackedLinear(w_f, b_f, "cuda"), PackedLinear(w_p, b_p, "cuda"), PackedLinear(w_2, b_2, "cuda"), PackedLayerNorm(lw, lb, "cuda")))
+    x = torch.zeros(m, dim, dtype=BF16, device="cuda")       # residual stream (updated in place by the tail)
+    h = torch.zeros(m, dim, dtype=BF16, device="cuda")       # ln(x): the fused GEMM's operand, rewritten by the tail
+    fused = torch.zeros(m, n_fused, dtype=BF16, device="cuda")
+    sf = blocks[0][0].struct()
+    need = lib.md_gemm_workspace_bytes(C.byref(sf), m, 0)
+    ws = torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")
+    sp, s2 = blocks[0][1].struct(), blocks[0][2].struct()
+    na, nb = lib.md_gemm_partial_slices(C.byref(sp)), lib.md_gemm_partial_slices(C.byref(s2))
+    pa = torch.zeros(na, m, dim, dtype=torch.float32, device="cuda")
+    pb = torch.zeros(nb, m, dim, dtype=torch.float32, device="cuda")
+
+    def chain():
+        for lf, lp, l2, ln in blocks:
+            st = lf.struct()
+            args = _lib.MdGemmArgs(h.data_ptr(), h.stride(0), st, fused.data_ptr(), fused.stride(0), None, 0, 0, m, _lib.MD_EPI_GELU, 0,
+                                   3 * dim, ws.data_ptr() if need else None, need)
+            _lib.check(lib.md_gemm_bf16(C.byref(args), stream()), "fused gemm")
+            # (the "attention output" of this toy block is the q section of the fused row)
+            spp, s22 = lp.struct(), l2.struct()
+            _lib.check(lib.md_gemm_partial_f32_pair(fused.data_ptr(), fused.stride(0), C.byref(spp), pa.data_ptr(),
+                                                    fused[:, 3 * dim :].data_ptr(), fused.stride(0), C.byref(s22), pb.data_ptr(),
+                                                    m, dim, m * dim, stream()))
+            stn = ln.struct()
+            _lib.check(lib.md_reduce_residual_layernorm(x.data_ptr(), dim, pa.data_ptr(), na, lp.b.data_ptr(), pb.data_ptr(), nb,
+                                                        l2.b.data_ptr(), dim, m * dim, h.data_ptr(), dim, C.byref(stn), m, dim, 1e-5, stream()))
+
+    inputs = {k: (randn(m, dim, seed=950 + i), randn(m, dim, seed=960 + i)) for i, k in enumerate("AB")}
+
+    def load(k):
+        x.copy_(inputs[k][0])
+        h.copy_(inputs[k][1])
+
+    eager = {}
+    for k in "AB":
+        load(k)
+        chain()
+        torch.cuda.synchronize()
+        eager[k] = (x.clone(), h.clone(), fused.clone())
+    assert not torch.equal(eager["A"][0], eager["B"][0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        load("A")
+        with torch.cuda.graph(g, stream=side):
+            chain()
+        for rep, k in enumerate("ABAAB"):
+            load(k)
+            g.replay()
+            side.synchronize()
+            for name, got, want in zip(("x", "ln(x)", "fused row"), (x, h, fused), eager[k]):
+                assert torch.equal(got, want), f"replay {rep} ({k}): {name} differs from the eager launches of the same inputs"
+    torch.cuda.current_stream().wait_stream(side)
+    # and the chain computes what it claims: block 0's fused row against torch (inputs A)
+    load("A")
+    chain()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("rows,dim", [(7, 144), (1458, 1152), (730, 2048), (3, 720), (5, 256)])
 def test_layernorm(lib, rows, dim):
     x = randn(rows, dim, scale=3.0, seed=15) + 0.5

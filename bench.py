@@ -274,7 +274,7 @@ def second_oracle(cfg, sd, seed, tokens, device):
     try:
         orc = O.Oracle(cfg, sd, fast=True, device=device)
         prompt = g["prompt"].tolist()
-        exact, errs, first_div_margins = 0, [], []
+        exact, errs, first_div_margins, dec_agree, dec_wide_disagree = 0, [], [], 0, 0
         with torch.inference_mode():
             for i in range(n):
                 img = synth.synthetic_image_array(i, seed, (378, 378))
@@ -285,6 +285,8 @@ def second_oracle(cfg, sd, seed, tokens, device):
                 errs.append(np.abs(got - g["top8_val"][i, : t + 1])[np.isfinite(g["top8_val"][i, : t + 1])])
                 own = lg[:t].argmax(dim=1).numpy()  # (CPU argmax: lowest index among ties, like the reference's)
                 diff = np.nonzero(own != g["tokens"][i, :t])[0]
+                dec_agree += t - len(diff)
+                dec_wide_disagree += int((g["margins"][i, :t][diff] > 0.5).sum())
                 if len(diff) == 0:
                     exact += 1
                 else:
@@ -292,6 +294,7 @@ def second_oracle(cfg, sd, seed, tokens, device):
         e = np.concatenate(errs)
         return {"exact": exact, "of": n, "max_logit_err": float(e.max()), "p99_logit_err": float(np.quantile(e, 0.99)),
                 "max_divergence_margin": max(first_div_margins, default=0.0), "seconds": round(time.perf_counter() - t0, 1),
+                "tf_decisions_agree": dec_agree, "tf_decisions": n * t, "tf_decisions_disagree_at_margin_above_0.5": dec_wide_disagree,
                 "what": "oracle fast mode (the reference's own ATen calls, B=1) run by torch-ROCm on this GPU, teacher-forced on the "
                         "reference's ids: sequences whose every argmax equals the reference's token / logit error at its top-8 candidates"}
     finally:

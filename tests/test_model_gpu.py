@@ -953,7 +953,8 @@ def mutation_sensitivity(model, cfg, g, images, imgs64, pr, gb):
             w.copy_(keep)
             torch.cuda.synchronize()
         print(f"mutation [{what}]: gates tripped {failed}; ids {rep['parity_exact']}/64 identical, max |logit err| "
-              f"{rep['parity_max_logit_err']:.3f} (p99 {rep['parity_p99_logit_err_ulps']:.1f} ulps), activations "
+              f"{rep['parity_max_logit_err']:.3f} (p99 {rep['parity_p99_logit_err_ulps']:.1f} ulps), wide-margin teacher-forced decisions that differ "
+              f"{rep['parity_tf_decisions_violations']}, activations "
               + ", ".join(f"{k} {v:.3e}" for k, v in act.items()))
         assert failed, f"no parity gate noticed: {what}"
     failed, rep, act = gates()  # restored
@@ -1034,8 +1035,11 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
         print(f"bench64 parity ({'pipelined+graphs' if pipelined else 'eager'}): {rep['parity_exact']}/64 identical; max |logit err| "
               f"{rep['parity_max_logit_err']:.4f} ({rep['parity_max_logit_err_ulps']:.1f} bf16 ulps, p99 {rep['parity_p99_logit_err']:.4f}) over "
               f"{rep['parity_decisions']} decisions -> threshold {rep['parity_threshold']:.4f}; largest reference margin at a first "
-              f"divergence {rep['parity_max_divergence_margin']:.4f}")
+              f"divergence {rep['parity_max_divergence_margin']:.4f}; teacher-forced: {rep['parity_tf_decisions_must_match']} decisions "
+              f"with a reference margin above the licence, {rep['parity_tf_decisions_violations']} of them differ "
+              f"({rep['parity_tf_decisions_agree']} of {rep['parity_decisions']} decisions agree in all)")
         assert rep["parity_ok"], rep["parity_note"]
+        assert rep["parity_tf_decisions_must_match"] >= 1800 and rep["parity_tf_decisions_violations"] == 0
         for i in g["image_index"].tolist():  # the wide-margin images of md2b_seed1 are among the 64: exact
             assert got64[i] == gb["tokens"][i].tolist(), i
     batch_equals_sequential_unfiltered(model, imgs64, pr, got64, ref_ids, gb["margins"], rep["parity_threshold"])

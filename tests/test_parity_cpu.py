@@ -139,3 +139,30 @@ def test_detect_parity_compares_leading_wide_objects_exactly():
     assert P.detect_parity(bad, g)["objects_mismatched"] == 1
     bad[i0] = []
     assert not P.detect_parity(bad, g)["ok"]
+
+
+def test_teacher_forced_decisions_with_a_wide_margin_must_all_match():
+    """Round 4: per-DECISION check on the teacher-forced logits (no cascade): every decision whose reference margin exceeds the
+    licence must pick the reference's token, even in sequences whose free-running ids left the stream earlier."""
+    ref_ids, margins, ref_topk = _case()
+    ref_topk = -np.sort(-ref_topk, axis=-1)          # winner first, as the fixtures store them
+    ref_topk[..., 0] = ref_topk[..., 1] + 2.0        # every decision decided by 2.0
+    ids = [list(r) for r in ref_ids]
+    got_topk = ref_topk + 0.0625
+    rep = P.parity_report(ids, ref_ids, margins, got_topk, ref_topk, tokens=6)
+    assert rep["parity_ok"] and rep["parity_tf_decisions_must_match"] == 4 * 7 and rep["parity_tf_decisions_violations"] == 0
+    assert rep["parity_tf_decisions_agree"] == 4 * 7
+    # one decision where this run's logits prefer the runner-up although the reference decided it by 2.0: caught, although the
+    # free-running ids are all identical and the measured error stays under its caps
+    bad = got_topk.copy()
+    bad[3, 5, 1] = bad[3, 5, 0] + 0.01
+    bad[3, 5, 0] -= 0.3
+    rep = P.parity_report(ids, ref_ids, margins, bad, ref_topk, tokens=6, max_err_cap=5.0, p99_ulps_cap=1e9, flat_cap=0.5)
+    assert not rep["parity_ok"] and rep["parity_tf_decisions_violations"] == 1 and "TEACHER-FORCED VIOLATIONS" in rep["parity_note"]
+    # a narrow decision (inside the licence) may tip either way
+    ref2 = ref_topk.copy()
+    ref2[3, 5, 0] = ref2[3, 5, 1] + 0.0625
+    got2 = ref2.copy()
+    got2[3, 5, 1] += 0.125
+    rep = P.parity_report(ids, ref_ids, margins, got2, ref2, tokens=6)
+    assert rep["parity_ok"] and rep["parity_tf_decisions_must_match"] == 4 * 7 - 1 and rep["parity_tf_decisions_agree"] == 4 * 7 - 1

@@ -51,6 +51,7 @@ def parse():
                     help="caption: the 5-id caption template; vqa32: 32-id seeded question prompts (SURVEY 8d)")
     ap.add_argument("--no-vqa-leg", action="store_true", help="skip the auxiliary 32-token-prompt measurement")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the strict-batch-invariance leg (batch == sequential bit for bit, priced)")
+    ap.add_argument("--int4-leg", action="store_true", help="also run the int4-checkpoint weight-stream leg (opt-in mode, off in the default run)")
     ap.add_argument("--no-detect13-leg", action="store_true", help="skip the BASELINE configs[4]-shaped leg (768x1024 -> 13 crops, detect)")
     ap.add_argument("--detect13-batch", type=int, default=32, help="images per step of that leg (configs[4]: 256 over 8 GPUs)")
     ap.add_argument("--w4-grid", type=int, default=0,
@@ -334,6 +335,74 @@ def exact_floor(n, t, second):
         return (40 * n) // 64
     n2 = second["exact"]
     return max(0, int(n2 - np.ceil(2.0 * np.sqrt(max(n2 * (64 - n2), 1) / 64.0))))
+
+
+def int4_leg(cfg, sd, images, prompts, T, args, dev):
+    from moondream_amd.moondream import MoondreamModel, IdTokenizer
+
+    def quantize(w):  # the checkpoint format dequantize_tensor reads (layers.py:38-44): groups of 128, scale + zero point
+        rows = w.float().reshape(-1, 128)
+        lo, hi = rows.min(1, keepdim=True).values, rows.max(1, keepdim=True).values
+        scale = ((hi - lo) / 15).clamp_min(1e-8)
+        zero = -lo / scale
+        q = torch.clamp(torch.round(rows / scale + zero), 0, 15).to(torch.uint8)
+        step = q.shape[0] // 2
+        return (q[:step] << 4) | q[step:], scale, zero
+
+    qsd = dict(sd)
+    for i in range(cfg.text.n_layers):
+        for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            p = f"text.blocks.{i}.{n}"
+            qsd[p + ".weight.packed"], qsd[p + ".weight.scale"], qsd[p + ".weight.zero_point"] = quantize(qsd.pop(p + ".weight"))
+    m4 = MoondreamModel(cfg, qsd, device=dev, tokenizer=IdTokenizer(), max_batch=args.batch, vit_chunk_crops=args.vit_chunk)
+    assert m4.w.has_int4_source()
+    m4.single_sequence_kernel = False  # like for like: the lone sequence of the latency figures on the batched kernels in both modes
+    out = {}
+    ids = {}
+    for mode in ("int4_stream", "bf16_stream"):
+        m4.enable_int4_decode(mode == "int4_stream")
+        m4.batch_generate_ids(images, prompts, max_tokens=T, ignore_eos=True)  # warm-up (arenas)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            ids[mode] = m4.batch_generate_ids(images, prompts, max_tokens=T, ignore_eos=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 2
+        m4.collect_timing = True
+        m4.batch_generate_ids(images, prompts, max_tokens=T, ignore_eos=True)
+        torch.cuda.synchronize()
+        m4.collect_timing = False
+        lat = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            m4.batch_generate_ids(images[:1], prompts[:1], max_tokens=T, ignore_eos=True)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        out[mode] = {"images_per_sec_non_pipelined": len(images) / dt, "ms_per_step": dt * 1e3,
+                     "phase_ms": {k: round(v, 2) for k, v in m4.last_phase_ms.items()},
+                     "single_image_latency_ms": float(np.median(lat[1:]) * 1e3)}
+    m4.single_sequence_kernel = True  # (bf16 stream attached last: the persistent single-sequence kernel, for reference)
+    lat = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        m4.batch_generate_ids(images[:1], prompts[:1], max_tokens=T, ignore_eos=True)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    out["bf16_stream"]["single_image_latency_ms_persistent_kernel"] = float(np.median(lat[1:]) * 1e3)
+    same = sum(a == b for a, b in zip(ids["int4_stream"], ids["bf16_stream"]))
+    out.update({
+        "sequences_identical": same, "of": len(images),
+        "decode_phase_speedup": out["bf16_stream"]["phase_ms"]["decode"] / out["int4_stream"]["phase_ms"]["decode"],
+        "note": "the synthetic decoder blocks quantised into the reference's QuantizedLinear format (4-bit, groups of 128) and loaded from "
+                "the triples; decode launches (<= 64 rows) stream the nibbles and rebuild bf16(bf16(q - zero) * scale) in registers "
+                "(md_linear_fp8.format = MD_WSTREAM_INT4_G128) vs the dequantised bf16 copy of the same model: the same weights bit for "
+                "bit, sums in another K order; bf16_stream's lone sequence runs on the batched kernels too (like for like); never `value`",
+    })
+    del m4
+    torch.cuda.empty_cache()
+    return out
 
 
 def detect13_leg(model, cfg, args, dev, fp8=False):
@@ -737,6 +806,14 @@ def main():
             }
         finally:
             model.set_strict_batch_invariance(False)
+
+    # auxiliary leg, NOT the headline: the reference's OWN quantised checkpoint format (layers.py:47-109, QuantizedLinear: 4-bit
+    # groups of 128) as the decode regime's weight stream.  The synthetic decoder blocks are quantised into that format, the
+    # model is loaded from the triples (prefill multiplies with the dequantised bf16 copy, as the reference's dequantize_tensor
+    # produces it) and the SAME model is timed with its decode launches streaming the nibbles vs the bf16 copy: same weights
+    # bit for bit, a quarter of the bytes.  Eager, non-pipelined steps (per-phase GPU times), ids compared.
+    if world == 1 and args.int4_leg and args.model == "2b":
+        result["int4_decode"] = int4_leg(cfg, sd, images, prompts, T, args, dev)
 
     # BASELINE configs[4]'s workload shape (multi-crop + detect head) as its own leg
     if world == 1 and not args.no_detect13_leg and args.model == "2b":

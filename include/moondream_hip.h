@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 3 /* 2: md_text_model.fp8 (trailing, optional); 3: md_vit_model.f8, md_text_model.f8 (trailing, optional), md_gemm_f8 + fp8 producers, md_decode_step_b1_supported */
+#define MD_ABI_VERSION 4 /* 2: md_text_model.fp8 (trailing, optional); 3: md_vit_model.f8, md_text_model.f8 (trailing, optional), md_gemm_f8 + fp8 producers, md_decode_step_b1_supported; 4: md_linear_fp8.format (int4 group-128 weight stream) */
 
 typedef int md_status;
 enum {
@@ -141,11 +141,22 @@ md_status md_reduce_residual_layernorm(void* x, int64_t ldx, const float* partia
  * The same op as md_gemm_bf16 at m <= 64 (F.linear of text.py:30,53, layers.py:130,139, text.py:166 at q_len 1):
  * bf16 activations, exact fp8 -> bf16 products, fp32 accumulation, epilogue(scale * acc + bias) with the bf16
  * kernels' rounding points.  MD_EPI_BIAS / MD_EPI_GELU (GELU on columns >= gelu_from_col). */
+/* format MD_WSTREAM_INT4_G128 (ABI 4): the reference's own quantised checkpoint format as the weight stream (layers.py:38-74,
+ * QuantizedLinear: 4-bit weights in groups of 128 input features, one (scale, zero_point) pair per group).  w: nibbles in
+ * MFMA-fragment order: block (nb, step, kh) of 32 channels x 64 features (the kh-th half of the 128-wide K step = of the
+ * group) is 1 KiB at (((nb * k_pad / 128 + step) * 2 + kh) * 1024); lane l owns 16 bytes: channel 32 nb + (l & 31), dword t =
+ * features 128 step + 64 kh + 16 t + 8 (l >> 5) + j as nibble j (bits 4 j .. 4 j + 3).  scale: fp32 pairs (scale, zero_point)
+ * at [k_pad / 128][n_pad].  Every weight is rebuilt as bf16(bf16(q - zero_point) * scale), the reference's dequantize_tensor
+ * (layers.py:38-44) with its two roundings: the operand is bit for bit the bf16 weight the bf16 path multiplies with, so this is
+ * NOT a numerical mode -- the same layer at a quarter of the weight bytes.  k_pad == k (k % 128 == 0). */
+#define MD_WSTREAM_E4M3 0
+#define MD_WSTREAM_INT4_G128 1
 typedef struct {
   const void* w;
   const float* scale;
   const void* b;
   int32_t n, k, n_pad, k_pad;
+  int32_t format; /* MD_WSTREAM_E4M3 (0, what ABI <= 3 callers pass implicitly) | MD_WSTREAM_INT4_G128 */
 } md_linear_fp8;
 md_status md_gemm_fp8w(const void* a, int64_t lda, const md_linear_fp8* lin, void* c, int64_t ldc, int32_t m,
                        int32_t epilogue, int32_t store_pad_cols, int32_t gelu_from_col, void* stream);

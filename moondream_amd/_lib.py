@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
 SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "gemm_f8.hip", "quant_f8.hip", "attention_f8kv.hip", "decode_b1.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
-ABI_VERSION = 3  # include/moondream_hip.h MD_ABI_VERSION
+ABI_VERSION = 4  # include/moondream_hip.h MD_ABI_VERSION
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
 MD_CROPS_U8_HWC, MD_CROPS_BF16_CHW = 0, 1
 
@@ -90,9 +90,12 @@ class MdTextBlock(C.Structure):
                 ("qkv_fc1", MdLinear)]
 
 
+MD_WSTREAM_E4M3, MD_WSTREAM_INT4_G128 = 0, 1
+
+
 class MdLinearFp8(C.Structure):
     _fields_ = [("w", c_void_p), ("scale", c_void_p), ("b", c_void_p), ("n", c_int32), ("k", c_int32),
-                ("n_pad", c_int32), ("k_pad", c_int32)]
+                ("n_pad", c_int32), ("k_pad", c_int32), ("format", c_int32)]
 
 
 class MdGemmF8Args(C.Structure):

@@ -22,9 +22,21 @@
 //     weight loads).
 // The two K halves are combined through LDS in a fixed order and both paths add the same products in the same order,
 // so the result is a function of the layer shape only (row-subset invariant like every other kernel here).
+//
+// FORMAT 1 (round 4): the reference's OWN quantised checkpoint format as a weight stream -- 4-bit weights in groups of 128
+// input features with one (scale, zero_point) pair per group (layers.py:38-74, QuantizedLinear / dequantize_tensor).  The
+// loader used to expand such checkpoints to bf16 once (weights.dequantize_int4) and stream 4x the bytes; here the nibbles
+// are streamed and every weight is rebuilt in registers with the reference's own arithmetic and roundings,
+//   w = bf16( bf16( q - zero ) * scale ),
+// so the bf16 operand the MFMA sees is bit for bit the weight the bf16 path multiplies with: no numerical mode, the same
+// layer at a quarter of the weight bytes (sums in this kernel's K order: agrees with the bf16 decode kernels to fp32
+// accumulation order).  Layout: block (nb, step, kh) = 32 channels x 64 features (the kh-th half of a 128-wide K step = of
+// a quantisation group) = 64 lanes x 16 bytes; lane l holds channel 32 nb + (l & 31), dword t = the 8 features
+// 128 step + 64 kh + 16 t + 8 (l >> 5) + j as nibble j.  qparams: fp32 (scale, zero) at [step][n_pad].
 #include "md_common.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -53,6 +65,22 @@ constexpr int A_STAGE = 64 * A_ROW;
 constexpr int NS = 3;
 constexpr int EPI_PARTIAL = 3;
 
+// 8 nibbles (one dword) -> one bf16x8 MFMA operand with the reference's dequantisation (layers.py:38-44: W_r.sub_(zero).mul_(scale)
+// on a bf16 tensor: one rounding after the subtraction, one after the product)
+__device__ __forceinline__ bf16x8 int4x8_to_bf16(uint32_t w, float s, float z) {
+  const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;  // nibbles 0, 2, 4, 6 / 1, 3, 5, 7 as bytes
+  // (uint8 -> float of a byte lane: hipcc selects v_cvt_f32_ubyte0..3)
+  const float q[8] = {(float)(lo & 0xffu),         (float)(hi & 0xffu),         (float)((lo >> 8) & 0xffu), (float)((hi >> 8) & 0xffu),
+                      (float)((lo >> 16) & 0xffu), (float)((hi >> 16) & 0xffu), (float)(lo >> 24),          (float)(hi >> 24)};
+  u32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t t = pack_bf16x2(q[2 * e] - z, q[2 * e + 1] - z);
+    r[e] = pack_bf16x2(lo_bf(t) * s, hi_bf(t) * s);
+  }
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 // 8 fp8 (two dwords) -> one bf16x8 MFMA operand: v_cvt_scalef32_pk_bf16_fp8 converts a pair per instruction
 // (scale 1.0; e4m3 -> bf16 is exact)
 typedef __bf16 md_bf16pair __attribute__((ext_vector_type(2)));
@@ -66,7 +94,7 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t lo, uint32_t hi) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int EPI, int MF, bool RESIDENT>
+template <int EPI, int MF, bool RESIDENT, int FMT>
 __device__ __forceinline__ void fp8w_body(const Fp8K& p, char* smem) {
   static_assert(!RESIDENT || MF == 1, "resident activations: at most 8 rows");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,7 +106,10 @@ __device__ __forceinline__ void fp8w_body(const Fp8K& p, char* smem) {
   const int step0 = slice * p.steps_per_slice;
   const int nsteps = min(p.steps_per_slice, p.total_steps - step0);
   const int KB = p.total_steps * 4;
-  const u32x4* wp = (const u32x4*)p.W + ((int64_t)(n0 / 32 + nbl) * KB + step0 * 4 + 2 * kh) * 64 + lane;
+  // FMT 0: two 1 KiB blocks per step and K half; FMT 1: one, plus the group's (scale, zero) of this lane's channel
+  const u32x4* wp = FMT == 0 ? (const u32x4*)p.W + ((int64_t)(n0 / 32 + nbl) * KB + step0 * 4 + 2 * kh) * 64 + lane
+                             : (const u32x4*)p.W + (((int64_t)(n0 / 32 + nbl) * p.total_steps + step0) * 2 + kh) * 64 + lane;
+  const u32x2* qpp = (const u32x2*)p.scale + (int64_t)step0 * p.n_pad + n0 + 32 * nbl + l31;
 
   f32x16 acc[MF];
 #pragma unroll
@@ -92,7 +123,9 @@ __device__ __forceinline__ void fp8w_body(const Fp8K& p, char* smem) {
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x8 wf = fp8x8_to_bf16(wq2[j][2 * t], wq2[j][2 * t + 1]);
+        bf16x8 wf;
+        if constexpr (FMT == 0) wf = fp8x8_to_bf16(wq2[j][2 * t], wq2[j][2 * t + 1]);
+        else wf = int4x8_to_bf16(wq2[0][2 * j + t], __uint_as_float(wq2[1].x), __uint_as_float(wq2[1].y));
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
           const bf16x8 af = *(const bf16x8*)(st + f * 32 * row_stride + (32 * j + 16 * t) * 2);
@@ -108,8 +141,17 @@ __device__ __forceinline__ void fp8w_body(const Fp8K& p, char* smem) {
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   auto load_w = [&](int i, u32x4 (&dst)[2]) {
     const int ic = min(i, nsteps - 1);
-    dst[0] = wp[(4 * ic) * 64];
-    dst[1] = wp[(4 * ic + 1) * 64];
+    if constexpr (FMT == 0) {
+      dst[0] = wp[(4 * ic) * 64];
+      dst[1] = wp[(4 * ic + 1) * 64];
+    } else {
+      dst[0] = wp[(2 * ic) * 64];
+      const u32x2 qp = qpp[(int64_t)ic * p.n_pad];  // a dead step's slot is replaced by zeros below: scale 0 makes its weights 0
+      u32x4 t4 = {0u, 0u, 0u, 0u};
+      t4.x = qp.x;  // scale
+      t4.y = qp.y;  // zero point
+      dst[1] = t4;
+    }
   };
   if constexpr (RESIDENT) {
     // ---- few rows: activation slice resident in LDS, then a barrier-free weight stream -------------------------
@@ -218,7 +260,8 @@ __device__ __forceinline__ void fp8w_body(const Fp8K& p, char* smem) {
   for (int g = 0; g < 4; ++g) {
     const int n = n0 + 32 * nbl + 8 * g + 4 * hi;
     if (n >= p.n_store) continue;
-    const f32x4 sc = *(const f32x4*)(p.scale + n);
+    f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f};  // FMT 1: the group scales are inside the operands
+    if constexpr (FMT == 0) sc = *(const f32x4*)(p.scale + n);
     if constexpr (EPI == EPI_PARTIAL) {
       float* dst = p.partial + (int64_t)slice * p.partial_slice_stride;
 #pragma unroll
@@ -252,15 +295,15 @@ __device__ __forceinline__ void fp8w_body(const Fp8K& p, char* smem) {
   }
 }
 
-template <int EPI, int MF, bool RESIDENT>
+template <int EPI, int MF, bool RESIDENT, int FMT>
 __global__ __launch_bounds__(256) void gemm_fp8w_kernel(const Fp8K p) {
   __shared__ __attribute__((aligned(16))) char smem[NS * A_STAGE];
-  fp8w_body<EPI, MF, RESIDENT>(p, smem);
+  fp8w_body<EPI, MF, RESIDENT, FMT>(p, smem);
 }
-template <int MF, bool RESIDENT>
+template <int MF, bool RESIDENT, int FMT>
 __global__ __launch_bounds__(256) void gemm_fp8w_pair_kernel(const Fp8Pair pair) {
   __shared__ __attribute__((aligned(16))) char smem[NS * A_STAGE];
-  fp8w_body<EPI_PARTIAL, MF, RESIDENT>(pair.g[blockIdx.z], smem);
+  fp8w_body<EPI_PARTIAL, MF, RESIDENT, FMT>(pair.g[blockIdx.z], smem);
 }
 
 // the activation slice of every workgroup fits the LDS array of the kernels: m rows x (steps x 256 + 16) bytes
@@ -274,6 +317,8 @@ md_status fill(Fp8K& k, const void* a, int64_t lda, const md_linear_fp8* lin, in
   MD_CHECK_ARG(lin->n_pad % 64 == 0 && lin->n_pad >= lin->n && lin->k_pad % STEP_K == 0 && lin->k_pad >= lin->k);
   MD_CHECK_ARG(lda % 8 == 0 && lda >= lin->k && ((uintptr_t)a & 15) == 0 && ((uintptr_t)lin->w & 15) == 0);
   MD_CHECK_ARG(((uintptr_t)lin->scale & 15) == 0);
+  MD_CHECK_ARG(lin->format == MD_WSTREAM_E4M3 || lin->format == MD_WSTREAM_INT4_G128);
+  MD_CHECK_ARG(lin->format == MD_WSTREAM_E4M3 || lin->k_pad == lin->k);  // a quantisation group is a whole 128-wide K step
   k.A = (const bf16_t*)a;
   k.lda = lda;
   // Columns [k, round_up(k, 64)) of A are the producer's zero padding (the bf16 packing pads to 64); nothing past that is
@@ -325,15 +370,20 @@ extern "C" md_status md_gemm_fp8w(const void* a, int64_t lda, const md_linear_fp
   const dim3 grid(lin->n_pad / 64, 1), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool res = resident_fits(m, k.steps_per_slice);
-  if (epilogue == MD_EPI_GELU) {
-    if (res) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_GELU, 1, true>), grid, block, 0, s, k);
-    else if (m <= 32) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_GELU, 1, false>), grid, block, 0, s, k);
-    else hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_GELU, 2, false>), grid, block, 0, s, k);
-  } else {
-    if (res) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_BIAS, 1, true>), grid, block, 0, s, k);
-    else if (m <= 32) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_BIAS, 1, false>), grid, block, 0, s, k);
-    else hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_BIAS, 2, false>), grid, block, 0, s, k);
-  }
+  auto launch = [&](auto fmt_c) {
+    constexpr int FMT = decltype(fmt_c)::value;
+    if (epilogue == MD_EPI_GELU) {
+      if (res) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_GELU, 1, true, FMT>), grid, block, 0, s, k);
+      else if (m <= 32) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_GELU, 1, false, FMT>), grid, block, 0, s, k);
+      else hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_GELU, 2, false, FMT>), grid, block, 0, s, k);
+    } else {
+      if (res) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_BIAS, 1, true, FMT>), grid, block, 0, s, k);
+      else if (m <= 32) hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_BIAS, 1, false, FMT>), grid, block, 0, s, k);
+      else hipLaunchKernelGGL((gemm_fp8w_kernel<MD_EPI_BIAS, 2, false, FMT>), grid, block, 0, s, k);
+    }
+  };
+  if (lin->format == MD_WSTREAM_INT4_G128) launch(std::integral_constant<int, 1>{});
+  else launch(std::integral_constant<int, 0>{});
   return md_launch_status();
 }
 
@@ -360,11 +410,17 @@ extern "C" md_status md_gemm_fp8w_partial_f32_pair(const void* a0, int64_t lda0,
     gx = std::max(gx, lins[i]->n_pad / 64);
     gy = std::max(gy, k.slices);
   }
+  MD_CHECK_ARG(lin0->format == lin1->format);  // one launch, one weight format
   const dim3 grid(gx, gy, 2), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (resident_fits(m, std::max(pair.g[0].steps_per_slice, pair.g[1].steps_per_slice)))
-    hipLaunchKernelGGL((gemm_fp8w_pair_kernel<1, true>), grid, block, 0, s, pair);
-  else if (m <= 32) hipLaunchKernelGGL((gemm_fp8w_pair_kernel<1, false>), grid, block, 0, s, pair);
-  else hipLaunchKernelGGL((gemm_fp8w_pair_kernel<2, false>), grid, block, 0, s, pair);
+  auto launch = [&](auto fmt_c) {
+    constexpr int FMT = decltype(fmt_c)::value;
+    if (resident_fits(m, std::max(pair.g[0].steps_per_slice, pair.g[1].steps_per_slice)))
+      hipLaunchKernelGGL((gemm_fp8w_pair_kernel<1, true, FMT>), grid, block, 0, s, pair);
+    else if (m <= 32) hipLaunchKernelGGL((gemm_fp8w_pair_kernel<1, false, FMT>), grid, block, 0, s, pair);
+    else hipLaunchKernelGGL((gemm_fp8w_pair_kernel<2, false, FMT>), grid, block, 0, s, pair);
+  };
+  if (lin0->format == MD_WSTREAM_INT4_G128) launch(std::integral_constant<int, 1>{});
+  else launch(std::integral_constant<int, 0>{});
   return md_launch_status();
 }

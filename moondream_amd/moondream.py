@@ -115,6 +115,9 @@ class MoondreamModel:
             raise _lib.MoondreamHipError("MoondreamModel needs a GPU device; there is no CPU path")
         self.tokenizer = tokenizer if tokenizer is not None else _load_tokenizer()
         self.w = PackedModel(config, state_dict, self._device)
+        # the checkpoint's own 4-bit weight stream for the decode regime (enable_int4_decode): exact but OPT-IN -- the in-register
+        # dequantisation is VALU-bound today (0.82x the bf16 stream's decode phase at B = 64, profiles/r04_int4_weight_stream.txt)
+        self.int4_decode = False
         self.vit_chunk_crops = int(vit_chunk_crops)
         self._arenas: Dict[int, torch.Tensor] = {}
         self._max_batch = 0
@@ -249,10 +252,30 @@ class MoondreamModel:
         vision path and the KV cache stay bf16.  Outputs are judged by tolerance against
         the bf16 path (tests/test_model_gpu.py), not bit parity; off by default."""
         if on:
+            if getattr(self.w, "_fp8_is_int4", False):
+                self.w.disable_fp8_decode()  # one weight stream at a time: the e4m3 copy replaces the checkpoint's int4 stream
             self.w.enable_fp8_decode()
         else:
             self.w.disable_fp8_decode()
+            if self.int4_decode and self.w.has_int4_source():
+                self.w.enable_int4_decode()
         self._graphs.clear()  # captured decode steps baked the other launches in
+
+    def enable_int4_decode(self, on: bool = True):
+        """A checkpoint that stores the decoder blocks as the reference's QuantizedLinear triples (layers.py:47-109) carries
+        its own 4-bit weight stream: decode launches (<= 64 rows) read the nibbles and rebuild the bf16 weights in registers
+        with the reference's dequantisation arithmetic -- the SAME weights as the bf16 copy the prefill multiplies with, at a
+        quarter of the bytes of the bandwidth-bound step.  Not a numerical mode (the operands are bit-identical), but OPT-IN:
+        the rebuild costs ~4 VALU instructions per weight and the first version of the kernel is VALU-bound (decode phase
+        0.82x the bf16 stream's at B = 64; profiles/r04_int4_weight_stream.txt).  The single-sequence persistent kernel
+        streams bf16 weights only, so a lone sequence then decodes on the batched kernels."""
+        self.int4_decode = bool(on)
+        self.w.disable_fp8_decode()
+        if on:
+            if not self.w.has_int4_source():
+                raise ValueError("this checkpoint has no QuantizedLinear (int4) decoder blocks")
+            self.w.enable_int4_decode()
+        self._graphs.clear()
 
     def enable_fp8(self, calibration_images: Optional[Sequence[Image.Image]] = None, prompt: Optional[Sequence[int]] = None,
                    on: bool = True, decode_weights: bool = True, margin: float = 1.5, kv_cache: bool = True) -> Optional[dict]:

@@ -238,9 +238,73 @@ def dequantize_int4_entries(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tens
             raise KeyError(f"{p}.bias is needed to recover the shape of the int4 weight {k}")
         out[p + ".weight"] = dequantize_int4(
             sd[k], sd[p + ".weight.scale"], sd[p + ".weight.zero_point"], bias.shape[0])
-        for suffix in (".weight.packed", ".weight.scale", ".weight.zero_point"):
-            del out[p + suffix]
+        # the 4-bit source stays beside the bf16 weight (INT4_KEYS): PackedModel turns the decoder blocks' into the decode
+        # regime's weight stream (PackedLinearInt4: the same weights at a quarter of the bytes)
+        for suffix, kept in zip((".weight.packed", ".weight.scale", ".weight.zero_point"), INT4_KEYS):
+            out[p + kept] = out.pop(p + suffix)
     return out
+
+
+INT4_KEYS = (".int4.packed", ".int4.scale", ".int4.zero_point")
+
+
+def int4_source(sd: Dict[str, torch.Tensor], prefix: str):
+    """(packed, scale, zero_point) of ``prefix`` if the checkpoint had it as a QuantizedLinear, else None."""
+    ks = [prefix + s for s in INT4_KEYS]
+    return tuple(sd[k] for k in ks) if all(k in sd for k in ks) else None
+
+
+class PackedLinearInt4:
+    """The reference's 4-bit checkpoint format (layers.py:38-74: groups of 128 input features, one scale and one zero_point
+    per group) laid out as the decode regime's weight stream (include/moondream_hip.h: md_linear_fp8 with format
+    MD_WSTREAM_INT4_G128).  ``sources``: one (packed, scale, zero_point, out_features) per layer, concatenated along the
+    output channels (the fused [qkv | fc1] layer is two).  The kernel rebuilds every weight as
+    bf16(bf16(q - zero_point) * scale) -- ``dequantize_int4``'s arithmetic -- so the stream and the bf16 copy hold the same
+    weights bit for bit (``dequantized()`` evaluates the kernel's formula from the packed stream; the CPU test compares)."""
+
+    def __init__(self, sources, b: Optional[torch.Tensor], device):
+        qs, scs, zps = [], [], []
+        for packed, scale, zero, out_features in sources:  # (repacked on `device`: 1.2 G nibbles at 2B)
+            packed = packed.to(device)
+            step = packed.shape[0]
+            q = torch.empty(2 * step, packed.shape[1], dtype=torch.uint8, device=device)
+            q[:step] = (packed & 0xF0) >> 4
+            q[step:] = packed & 0x0F
+            k = q.numel() // out_features
+            if q.numel() % out_features or k % 128 or packed.shape[1] != 128:
+                raise ValueError("int4 weight stream: groups of 128 input features, in_features % 128 == 0")
+            qs.append(q.reshape(out_features, k))
+            scs.append(scale.to(device).float().reshape(out_features, k // 128))
+            zps.append(zero.to(device).float().reshape(out_features, k // 128))
+        q, sc, zp = torch.cat(qs, 0), torch.cat(scs, 0), torch.cat(zps, 0)
+        self.n, self.k = q.shape
+        self.n_pad, self.k_pad = _round_up(self.n, 64), self.k
+        steps = self.k // 128
+        qp = torch.zeros(self.n_pad, self.k, dtype=torch.uint8, device=device)
+        qp[: self.n] = q
+        par = torch.zeros(steps, self.n_pad, 2, dtype=torch.float32, device=device)  # padding channels: scale 0 -> weight 0
+        par[:, : self.n, 0] = sc.t()
+        par[:, : self.n, 1] = zp.t()
+        # [nb][row][step][kh][t][hi][j] -> [nb][step][kh][hi][row][t][j], then two nibbles per byte (nibble j = bits 4 j ..)
+        frag = qp.view(self.n_pad // 32, 32, steps, 2, 4, 2, 8).permute(0, 2, 3, 5, 1, 4, 6).contiguous()
+        self.w = (frag[..., 0::2] | (frag[..., 1::2] << 4)).contiguous().to(device)  # [...][t][4 bytes]
+        self.qparams = par.contiguous().to(device)
+        self.b = b
+
+    def dequantized(self) -> torch.Tensor:
+        """bf16 [n_pad][k] rebuilt FROM THE STREAM with the kernel's arithmetic (test instrument)."""
+        w = self.w.cpu()
+        nb, steps = w.shape[0], w.shape[1]
+        nib = torch.stack([w & 0x0F, w >> 4], dim=-1).reshape(nb, steps, 2, 2, 32, 4, 8)  # [nb][step][kh][hi][row][t][j]
+        q = nib.permute(0, 4, 1, 2, 5, 3, 6).reshape(self.n_pad, self.k).float()
+        par = self.qparams.cpu()
+        sc = par[:, :, 0].t().repeat_interleave(128, dim=1)
+        zp = par[:, :, 1].t().repeat_interleave(128, dim=1)
+        return ((q - zp).to(BF16).float() * sc).to(BF16)
+
+    def struct(self) -> _lib.MdLinearFp8:
+        return _lib.MdLinearFp8(self.w.data_ptr(), self.qparams.data_ptr(), self.b.data_ptr() if self.b is not None else None,
+                                self.n, self.k, self.n_pad, self.k_pad, _lib.MD_WSTREAM_INT4_G128)
 
 
 def load_state_dict_file(weights_file: str) -> Dict[str, torch.Tensor]:
@@ -362,7 +426,8 @@ class PackedModel:
                 blk.fc1 = lin(p + ".mlp.fc1").struct()
             proj, fc2 = lin(p + ".attn.proj"), lin(p + ".mlp.fc2")
             blk.proj, blk.fc2 = proj.struct(), fc2.struct()
-            self._text_packed.append({"qkv_fc1": fused, "proj": proj, "fc2": fc2})
+            self._text_packed.append({"qkv_fc1": fused, "proj": proj, "fc2": fc2,
+                                      "int4": {n: int4_source(sd, f"{p}.{n}") for n in ("attn.qkv", "mlp.fc1", "attn.proj", "mlp.fc2")}})
         self.text_post_ln = ln("text.post_ln")
         self.lm_head = lin("text.lm_head")
         self.wte = sd["text.wte"].to(device=dev, dtype=BF16).contiguous()
@@ -386,6 +451,47 @@ class PackedModel:
                 "coord_features": sd["region.coord_features"].to(device=dev, dtype=BF16).contiguous(),
                 "size_features": sd["region.size_features"].to(device=dev, dtype=BF16).contiguous(),
             }
+
+    def has_int4_source(self) -> bool:
+        """Every decoder block's four linears came from the checkpoint as QuantizedLinear triples (text.py:178 with
+        config.text.group_size set) and the fused qkv|fc1 packing is in use."""
+        t = self.config.text
+        return bool(self._text_packed) and t.dim % 128 == 0 and t.ff_dim % 128 == 0 and all(  # a group = a whole 128-wide K step of a row
+            pk["qkv_fc1"] is not None and all(v is not None for v in pk["int4"].values()) for pk in self._text_packed)
+
+    def enable_int4_decode(self) -> None:
+        """Attach the checkpoint's own 4-bit weights as the decode regime's weight stream (md_text_model.fp8 with
+        md_linear_fp8.format = MD_WSTREAM_INT4_G128; lm_head has no quantised form in the reference and stays bf16): launches
+        of <= 64 rows then read a QUARTER of the weight bytes and rebuild the very bf16 weights the other launches multiply
+        with (bf16(bf16(q - zero) * scale), layers.py:38-44).  Not a numerical mode (results agree with the bf16 stream to
+        fp32 accumulation order); opt-in while the in-register dequantisation is VALU-bound (MoondreamModel.enable_int4_decode)."""
+        if getattr(self, "_fp8", None) is not None:
+            return
+        if not self.has_int4_source():
+            raise ValueError("no QuantizedLinear source for every decoder block in this checkpoint")
+        t = self.config.text
+        keep: List[PackedLinearInt4] = []
+        dev = self.lm_head.w.device
+
+        def q4(out_features, pk_lin, srcs):
+            f = PackedLinearInt4([(p_, s_, z_, n_) for (p_, s_, z_), n_ in zip(srcs, out_features)], pk_lin.b, dev)
+            assert (f.n, f.k, f.n_pad) == (pk_lin.n, pk_lin.k, pk_lin.n_pad), (f.n, f.k, f.n_pad, pk_lin.n, pk_lin.k, pk_lin.n_pad)
+            keep.append(f)
+            return f.struct()
+
+        qkv_n = (t.n_heads + 2 * t.n_kv_heads) * (t.dim // t.n_heads)
+        blocks = (_lib.MdTextBlockFp8 * t.n_layers)()
+        for i, pk in enumerate(self._text_packed):
+            src = pk["int4"]
+            blocks[i].qkv_fc1 = q4((qkv_n, t.ff_dim), pk["qkv_fc1"], (src["attn.qkv"], src["mlp.fc1"]))
+            blocks[i].proj = q4((pk["proj"].n,), pk["proj"], (src["attn.proj"],))
+            blocks[i].fc2 = q4((pk["fc2"].n,), pk["fc2"], (src["mlp.fc2"],))
+        head = _lib.MdLinearFp8()  # w == NULL: lm_head stays on the bf16 stream
+        self._fp8_blocks = blocks
+        self._fp8 = _lib.MdTextFp8(C.cast(blocks, C.POINTER(_lib.MdTextBlockFp8)), head)
+        self._fp8_keep = keep
+        self._fp8_is_int4 = True
+        self.text.fp8 = C.pointer(self._fp8)
 
     def enable_fp8_decode(self) -> None:
         """Attach FP8 (e4m3fn, per-channel scale) copies of the decoder's weight stream -- fused qkv|fc1, proj,
@@ -418,6 +524,7 @@ class PackedModel:
     def disable_fp8_decode(self) -> None:
         self.text.fp8 = C.POINTER(_lib.MdTextFp8)()
         self._fp8 = None
+        self._fp8_is_int4 = False
 
     # ---- FP8 mode of the MFMA-bound launches (ViT, projector, decoder prefill): md_gemm_f8 -------------------------------
     def begin_f8_calibration(self) -> None:

@@ -12,7 +12,7 @@ import torch
 
 from moondream_amd import _lib
 from moondream_amd.weights import PackedLinear, PackedLayerNorm, rope_table, reference_pixel_lut
-from util import compare
+from util import compare, quantize_int4
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
@@ -292,6 +292,81 @@ def test_gemm_fp8_weights_decode_regime(lib, m, k, n, epi, gelu_from):
         gfull = torch.nn.functional.gelu(full.float(), approximate="tanh").to(BF16)
         full = torch.cat([full[:, :gelu_from], gfull[:, gelu_from:]], 1)
     compare(f"fp8w vs bf16 layer m{m} {k}x{n}", c[:, :n], full, 6e-2)
+
+
+@pytest.mark.parametrize("m,k,n,epi,gelu_from", [(64, 2048, 14336, 1, 6144), (1, 2048, 2048, 0, 0), (5, 256, 448, 1, 192), (33, 1024, 1024, 0, 0),
+                                                 (8, 8192, 2048, 0, 0), (40, 128, 96, 0, 0)])
+def test_gemm_int4_weight_stream_decode_regime(lib, m, k, n, epi, gelu_from):
+    """md_gemm_fp8w over the reference's OWN 4-bit checkpoint format (md_linear_fp8.format = MD_WSTREAM_INT4_G128): the kernel
+    rebuilds bf16(bf16(q - zero) * scale) in registers, so against an fp32 matmul with dequantize_int4's weights only the
+    accumulation order differs (tolerance of the other decode-regime kernels), rows do not depend on the row count, padding
+    channels come out as zero, and the result tracks the bf16 decode-regime kernel over the dequantised copy."""
+    from moondream_amd.weights import PackedLinearInt4, dequantize_int4
+
+    a = randn(m, k, seed=300)
+    w = randn(n, k, scale=1 / math.sqrt(k), seed=301)
+    b = randn(n, scale=0.1, seed=302)
+    packed, scale, zero = quantize_int4(w, zero_shift=0.3)  # fractional zero points: the first rounding matters
+    deq = dequantize_int4(packed, scale, zero, n).cuda()    # the bf16 weights every other launch multiplies with
+    n_pad = (n + 63) // 64 * 64
+    bp = torch.zeros(n_pad, dtype=BF16, device="cuda")
+    bp[:n] = b
+    q = PackedLinearInt4([(packed, scale, zero, n)], bp, "cuda")
+    assert torch.equal(q.dequantized()[:n].cuda(), deq)
+
+    def run(rows):
+        c = torch.full((rows, q.n_pad), float("nan"), dtype=BF16, device="cuda")
+        st = q.struct()
+        _lib.check(lib.md_gemm_fp8w(a.data_ptr(), a.stride(0), C.byref(st), c.data_ptr(), c.stride(0), rows, epi, 1, gelu_from, stream()))
+        torch.cuda.synchronize()
+        return c
+
+    c = run(m)
+    ref = (a.float() @ deq.float().t() + b.float()).to(BF16)
+    if epi == 1:
+        g = torch.nn.functional.gelu(ref.float(), approximate="tanh").to(BF16)
+        ref = torch.cat([ref[:, :gelu_from], g[:, gelu_from:]], 1)
+    compare(f"int4 stream m{m} {k}x{n} epi{epi}", c[:, :n], ref, 3e-3, 2e-2)
+    assert float(c[:, n:].float().abs().max() if q.n_pad > n else 0.0) == 0.0
+    if m > 1:
+        assert torch.equal(run(1), c[:1])
+    # the bf16 decode-regime kernel over the dequantised copy: the same weights, another K order
+    lin = PackedLinear(deq, b, "cuda")
+    c16 = gemm(lib, pad_k(a, lin.k_pad), lin, epi=0)
+    if epi == 0:
+        compare(f"int4 stream vs bf16 stream m{m} {k}x{n}", c[:, :n], c16[:, :n], 3e-3, 2e-2)
+
+
+@pytest.mark.parametrize("m,dim,ka,kb", [(64, 2048, 2048, 8192), (5, 1024, 1024, 4096), (33, 256, 256, 768)])
+def test_int4_partial_pair_feeds_the_block_tail(lib, m, dim, ka, kb):
+    """md_gemm_fp8w_partial_f32_pair with int4 streams: K-slice partials whose sum is the fp32 product with dequantize_int4's
+    weights; row-subset invariant."""
+    from moondream_amd.weights import PackedLinearInt4, dequantize_int4
+
+    a1, w1 = randn(m, ka, seed=310), randn(dim, ka, scale=1 / math.sqrt(ka), seed=311)
+    a2, w2 = randn(m, kb, seed=313), randn(dim, kb, scale=1 / math.sqrt(kb), seed=314)
+    t1, t2 = quantize_int4(w1), quantize_int4(w2, zero_shift=-0.4)
+    qa, qb = PackedLinearInt4([(*t1, dim)], None, "cuda"), PackedLinearInt4([(*t2, dim)], None, "cuda")
+    d1, d2 = dequantize_int4(*t1, dim).cuda(), dequantize_int4(*t2, dim).cuda()
+    sa, sb = qa.struct(), qb.struct()
+    na, nb = lib.md_gemm_fp8w_partial_slices(C.byref(sa)), lib.md_gemm_fp8w_partial_slices(C.byref(sb))
+    assert 1 <= na <= 8 and 1 <= nb <= 8
+
+    def run(rows):
+        pa = torch.full((na, rows, dim), float("nan"), dtype=torch.float32, device="cuda")
+        pb = torch.full((nb, rows, dim), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.md_gemm_fp8w_partial_f32_pair(a1.data_ptr(), a1.stride(0), C.byref(sa), pa.data_ptr(), a2.data_ptr(), a2.stride(0),
+                                                     C.byref(sb), pb.data_ptr(), rows, dim, rows * dim, stream()))
+        torch.cuda.synchronize()
+        return pa, pb
+
+    pa, pb = run(m)
+    assert torch.isfinite(pa).all() and torch.isfinite(pb).all()
+    compare("int4 partials a", pa.sum(0).to(BF16), (a1.float() @ d1.float().t()).to(BF16), 3e-3, 2e-2)
+    compare("int4 partials b", pb.sum(0).to(BF16), (a2.float() @ d2.float().t()).to(BF16), 3e-3, 2e-2)
+    if m > 1:
+        p1a, p1b = run(1)
+        assert torch.equal(p1a, pa[:, :1]) and torch.equal(p1b, pb[:, :1])
 
 
 @pytest.mark.parametrize("m,dim,ka,kb", [(64, 2048, 2048, 8192), (5, 1024, 1024, 4096), (33, 256, 256, 704)])

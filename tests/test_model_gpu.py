@@ -961,6 +961,58 @@ def mutation_sensitivity(model, cfg, g, images, imgs64, pr, gb):
     assert not failed, (failed, rep["parity_note"], act)
 
 
+def test_int4_checkpoint_streams_its_own_weights_in_decode():
+    """A checkpoint whose decoder blocks are the reference's QuantizedLinear triples (layers.py:47-109; 0.5B shapes, 4-bit
+    groups of 128): the decode regime streams the NIBBLES (md_linear_fp8.format = MD_WSTREAM_INT4_G128) and rebuilds the bf16
+    weights of the dequantised copy in registers.  Same weights, another K order: against the bf16 stream of the very same
+    model (enable_int4_decode(False)) the first decode step's K rows agree within accumulation-order tolerance, the ids of
+    every sequence agree up to its first narrow decision (and most of them entirely), a lone sequence and a batch agree, and
+    the stream (opt-in: enable_int4_decode) survives enable_fp8_decode(True / False)."""
+    from moondream_amd.moondream import MoondreamModel, IdTokenizer
+    from util import quantize_int4
+
+    cfg = get_config("0.5b")
+    sd = synth.synthetic_state_dict(cfg, seed=1, device="cuda")
+    qsd = dict(sd)
+    for i in range(cfg.text.n_layers):
+        for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            p = f"text.blocks.{i}.{n}"
+            packed, scale, zero = quantize_int4(qsd.pop(p + ".weight"), zero_shift=0.25)
+            qsd[p + ".weight.packed"], qsd[p + ".weight.scale"], qsd[p + ".weight.zero_point"] = packed, scale, zero
+    model = MoondreamModel(cfg, qsd, device="cuda", tokenizer=IdTokenizer(), max_batch=4)
+    assert model.w.has_int4_source() and not model.int4_decode and not bool(model.w.text.fp8)  # opt-in
+    model.enable_int4_decode(True)
+    assert model.int4_decode and bool(model.w.text.fp8) and model.w._fp8_is_int4
+    images = [synth.synthetic_image(i, 1) for i in range(4)]
+    prompt = cfg.tokenizer.templates["caption"]["normal"]
+    n_tok = 16
+
+    def run():
+        ids = model.batch_generate_ids(images, [prompt] * 4, max_tokens=n_tok, ignore_eos=True)
+        p0 = 730 + len(prompt)
+        return ids, model._kv_k[:, :4, :, p0 : p0 + 2].clone()
+
+    ids4, k4 = run()
+    lone = model.batch_generate_ids(images[:1], [prompt], max_tokens=n_tok, ignore_eos=True)[0]  # batched kernels (no persistent kernel with a stream attached)
+    assert model._b1_used is False and lone == ids4[0]
+    model.enable_fp8_decode(True)   # the e4m3 copy replaces the int4 stream ...
+    assert not model.w._fp8_is_int4
+    model.enable_fp8_decode(False)  # ... and the checkpoint's own stream comes back
+    assert model.w._fp8_is_int4
+    model.enable_int4_decode(False)
+    assert not bool(model.w.text.fp8)
+    model.single_sequence_kernel = False
+    ids16, k16 = run()
+    compare("int4 stream vs bf16 stream: K rows of the first decode steps (all layers)", k4, k16, 1e-2)
+    same = sum(a == b for a, b in zip(ids4, ids16))
+    prefix = [next((t for t in range(n_tok) if a[t] != b[t]), n_tok) for a, b in zip(ids4, ids16)]
+    print(f"int4 weight stream vs bf16 stream of the same dequantised weights (0.5B shapes): {same}/4 sequences identical over {n_tok} tokens, "
+          f"matching prefixes {prefix}")
+    assert same >= 2 and min(prefix) >= 1
+    model.enable_int4_decode(True)
+    assert run()[0] == ids4  # deterministic, and re-attachable
+
+
 @pytest.mark.parametrize("name,cfg_name", [("md05b_seed1.npz", "0.5b"), ("md2b_seed1.npz", "2b")])
 def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     """BASELINE.json configs at full size: greedy ids bit-exact against the

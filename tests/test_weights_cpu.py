@@ -112,6 +112,8 @@ def test_int4_checkpoint_is_dequantised_like_the_reference(tmp_path):
         del qsd[n + ".weight"]
         qsd[n + ".weight.packed"], qsd[n + ".weight.scale"], qsd[n + ".weight.zero_point"] = packed, scale, zero
         expect[n + ".weight"] = dequantize_int4(packed, scale, zero, w.shape[0])
+        # the 4-bit source travels on beside the bf16 weight (the decode regime's weight stream is built from it)
+        expect[n + ".int4.packed"], expect[n + ".int4.scale"], expect[n + ".int4.zero_point"] = packed, scale, zero
         # 4-bit round trip of a smooth weight: within one quantisation step
         assert (expect[n + ".weight"].float() - w.float()).abs().max() <= scale.max() * 1.01 + 1e-2
     assert any(k.endswith(".weight.packed") for k in qsd)
@@ -134,6 +136,39 @@ def test_int4_checkpoint_is_dequantised_like_the_reference(tmp_path):
     zero = torch.rand(192, 1, generator=g) * 15
     ref = ns["dequantize_tensor"](packed, scale, zero, (48, 512))
     assert torch.equal(ref, dequantize_int4(packed, scale, zero, 48))
+
+
+def test_int4_weight_stream_holds_the_same_weights_as_the_bf16_copy():
+    """PackedLinearInt4 (md_linear_fp8.format = MD_WSTREAM_INT4_G128): the fragment-ordered nibbles + (scale, zero) table,
+    decoded with the kernel's arithmetic bf16(bf16(q - zero) * scale), are BIT FOR BIT the weights dequantize_int4 (= the
+    reference's dequantize_tensor) produces -- single layers and the fused [qkv | fc1] layer; padding channels decode to 0;
+    the byte layout is the one include/moondream_hip.h documents (checked on one hand-computed element)."""
+    from moondream_amd.weights import PackedLinearInt4, dequantize_int4
+
+    g = torch.Generator().manual_seed(11)
+    wa = torch.randn(96, 256, generator=g) * 0.05          # "qkv": 96 channels, 2 groups per row
+    wb = torch.randn(160, 256, generator=g) * 0.05         # "fc1"
+    (pa, sa, za), (pb, sb, zb) = _quantize_int4(wa), _quantize_int4(wb)
+    za, zb = za + 0.37, zb - 0.21                          # fractional zero points: the first rounding matters
+    ref = torch.cat([dequantize_int4(pa, sa, za, 96), dequantize_int4(pb, sb, zb, 160)], 0)
+    fused = PackedLinearInt4([(pa, sa, za, 96), (pb, sb, zb, 160)], None, "cpu")
+    assert (fused.n, fused.k, fused.n_pad, fused.k_pad) == (256, 256, 256, 256)
+    assert torch.equal(fused.dequantized()[:256], ref)
+    single = PackedLinearInt4([(pb, sb, zb, 160)], None, "cpu")
+    assert single.n_pad == 192 and torch.equal(single.dequantized()[:160], ref[96:])
+    assert torch.count_nonzero(single.dequantized()[160:].float()) == 0
+    st = single.struct()
+    assert st.format == 1 and st.n == 160 and st.k == 256 and st.k_pad == 256
+    # the documented address of one weight: channel n = 37, feature k = 128 + 64 + 16 * 2 + 8 * 1 + 5 (step 1, kh 1, t 2, hi 1, j 5)
+    n, step, kh, t, hi, j = 37, 1, 1, 2, 1, 5
+    k = 128 * step + 64 * kh + 16 * t + 8 * hi + j
+    q_all = torch.empty(2 * pb.shape[0], 128, dtype=torch.uint8)
+    q_all[: pb.shape[0]], q_all[pb.shape[0] :] = (pb & 0xF0) >> 4, pb & 0x0F
+    q_want = int(q_all.reshape(160, 256)[n, k])
+    raw = single.w.reshape(-1)
+    byte_off = (((n // 32) * 2 + step) * 2 + kh) * 1024 + (hi * 32 + n % 32) * 16 + 4 * t + j // 2
+    assert (int(raw[byte_off]) >> (4 * (j % 2))) & 15 == q_want
+    assert float(single.qparams[step, n, 0]) == float(sb.reshape(160, 2)[n, step]) and float(single.qparams[step, n, 1]) == float(zb.reshape(160, 2)[n, step])
 
 
 def test_fp8_fragment_layout_and_scales():

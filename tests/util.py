@@ -86,3 +86,14 @@ def vit_fp64(x_bchw: torch.Tensor, sd, cfg) -> torch.Tensor:
         h = torch.nn.functional.gelu(h @ f(p + ".mlp.fc1.weight").t() + f(p + ".mlp.fc1.bias"), approximate="tanh")
         x = x + h @ f(p + ".mlp.fc2.weight").t() + f(p + ".mlp.fc2.bias")
     return ln(x, "vision.post_ln")
+
+
+def quantize_int4(w, group=128, zero_shift=0.0):
+    """The checkpoint format dequantize_int4 / the int4 weight stream read (reference layers.py:38-74), from a float weight."""
+    rows = w.float().cpu().reshape(-1, group)
+    lo, hi = rows.min(1, keepdim=True).values, rows.max(1, keepdim=True).values
+    scale = ((hi - lo) / 15).clamp_min(1e-8)
+    zero = -lo / scale + zero_shift
+    q = torch.clamp(torch.round(rows / scale + zero), 0, 15).to(torch.uint8)
+    step = q.shape[0] // 2
+    return (q[:step] << 4) | q[step:], scale, zero

@@ -23,6 +23,8 @@ V = lambda mode, abl: mode + 16 * abl
 VARIANTS = [("full", V(0, 0)), ("no-dma", V(0, 2)), ("no-barrier", V(0, 4)), ("no-reads", V(0, 8)), ("mfma+epi", V(0, 14)),
             ("no-stores", V(0, 16)), ("no-epi", V(0, 32)), ("mfma only", V(0, 46)), ("loads from 1 MiB", V(0, 256)), ("loads from 1 MiB, no stores", V(0, 272))]
 SHAPES = [(8192, 8192, 8192), (46720, 2048, 2048), (93312, 1152, 3456)]
+if os.environ.get("W4_PROBE_SHAPES"):  # "m,k,n;m,k,n"
+    SHAPES = [tuple(int(x) for x in t.split(",")) for t in os.environ["W4_PROBE_SHAPES"].split(";")]
 
 
 def problem(m, k, n):

@@ -77,6 +77,11 @@ def selftest_dist(args):
     sd = mdist.broadcast_state_dict(full if rank == 0 else None, mdist.state_dict_template(full), dev)
     assert sd["w"].float().sum().item() == 276.0
     assert mdist.max_over_ranks(0.0 if torch.equal(sd["w"].cpu(), full["w"]) else 1.0, dev) == 0.0
+    # the bench's own weight path (every rank generates, rank 0's copy is broadcast and verified) with the tiny config
+    from moondream_amd.config import get_config
+    sd_tiny, wrep = distribute_weights(get_config("tiny"), 3, dev, rank, world)
+    assert (wrep is None) == (world == 1) and (wrep is None or (wrep["equal_to_local_copy_on_every_rank"] and wrep["bytes"] > 0))
+    assert "text.wte" in sd_tiny
     mine = mdist.shard_range(3 * world + 1, rank, world)
     ids = torch.tensor([[i, i + 1] for i in mine], dtype=torch.int32, device=dev).reshape(len(mine), 2)
     blocks = mdist.gather_token_ids(ids, n_total=3 * world + 1)
@@ -91,9 +96,36 @@ def selftest_dist(args):
         assert got == list(range(3 * world + 1)), got
         assert per_rank == [r + 0.5 for r in range(world)], per_rank
         print(json.dumps({"selftest": "dist", "n_gpus": world, "max_rank": t, "items": len(got), "ranks_seen": seen,
-                          "per_rank_ms_per_step": per_rank}), flush=True)
+                          "per_rank_ms_per_step": per_rank, "weights_broadcast": wrep}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def distribute_weights(cfg, seed, dev, rank, world):
+    """The checkpoint is SYNTHETIC (a counter-based hash of the seed), so every rank generates its own copy at once instead of
+    7 ranks idling while rank 0 generates; the RCCL broadcast of one flat buffer (what a real checkpoint takes, rank 0
+    being the only reader of the file) still runs, and every rank checks the broadcast bytes against its own copy: the weight path
+    over xGMI is exercised AND verified on every N > 1 run.  Returns (state dict, report or None).  (Also run by
+    ``--selftest-dist`` over gloo with the tiny config.)"""
+    from moondream_amd import dist as mdist
+    from moondream_amd import synth
+
+    sd0 = synth.synthetic_state_dict(cfg, seed=seed, device=dev)
+    if world == 1:
+        return sd0, None
+    template = mdist.state_dict_template(sd0)
+    t_b = time.perf_counter()
+    sd = mdist.broadcast_state_dict(sd0 if rank == 0 else None, template, dev, src=0)
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+    t_b = time.perf_counter() - t_b
+    same = all(torch.equal(sd[k], sd0[k]) for k in sd0)
+    n_bytes = sum(v.numel() * v.element_size() for v in sd0.values())
+    ok_everywhere = mdist.max_over_ranks(0.0 if same else 1.0, dev) == 0.0
+    report = {"bytes": n_bytes, "seconds": round(mdist.max_over_ranks(t_b, dev), 3), "equal_to_local_copy_on_every_rank": ok_everywhere}
+    if not ok_everywhere:
+        raise RuntimeError(f"rank {rank}: broadcast weights differ from the locally generated copy")
+    return sd, report
 
 
 def _one_numa_node_physical_cores():
@@ -504,27 +536,7 @@ def main():
     torch.cuda.set_device(dev)
     cfg = get_config(args.model)
 
-    # weights: the checkpoint is SYNTHETIC (a counter-based hash of the seed), so every rank generates its own copy at once
-    # instead of 7 ranks idling while rank 0 generates; the RCCL broadcast of one flat buffer (what a real
-    # checkpoint takes, rank 0 being the only reader of the file) still runs, and every rank checks the broadcast bytes
-    # against its own copy: the weight path over xGMI is exercised AND verified on every N > 1 run
-    sd0 = synth.synthetic_state_dict(cfg, seed=args.seed, device=dev)
-    weights_broadcast = None
-    if world > 1:
-        template = mdist.state_dict_template(sd0)
-        t_b = time.perf_counter()
-        sd = mdist.broadcast_state_dict(sd0 if rank == 0 else None, template, dev, src=0)
-        torch.cuda.synchronize()
-        t_b = time.perf_counter() - t_b
-        same = all(torch.equal(sd[k], sd0[k]) for k in sd0)
-        n_bytes = sum(v.numel() * v.element_size() for v in sd0.values())
-        ok_everywhere = mdist.max_over_ranks(0.0 if same else 1.0, dev) == 0.0
-        weights_broadcast = {"bytes": n_bytes, "seconds": round(mdist.max_over_ranks(t_b, dev), 3), "equal_to_local_copy_on_every_rank": ok_everywhere}
-        if not ok_everywhere:
-            raise RuntimeError(f"rank {rank}: broadcast weights differ from the locally generated copy")
-        del sd0
-    else:
-        sd = sd0
+    sd, weights_broadcast = distribute_weights(cfg, args.seed, dev, rank, world)
     model = MoondreamModel(cfg, sd, device=dev, tokenizer=IdTokenizer(), max_batch=args.batch, vit_chunk_crops=args.vit_chunk)
     lib = model.lib
     if not args.no_graphs:

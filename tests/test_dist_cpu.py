@@ -84,6 +84,7 @@ def test_bench_self_launches_n2_without_torchrun():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["items"] == 7 and d["max_rank"] == 1.0 and d["ranks_seen"] == 2
     assert len(d["per_rank_ms_per_step"]) == 2  # one clock per rank reaches rank 0's JSON line
+    assert d["weights_broadcast"]["equal_to_local_copy_on_every_rank"] is True and d["weights_broadcast"]["bytes"] > 0
 
 
 def test_bench_self_launch_propagates_a_failing_rank():

@@ -45,6 +45,11 @@ def select_tiling(height: int, width: int, crop_size: int, max_crops: int) -> Tu
 
 
 def _resize(img: np.ndarray, height: int, width: int) -> np.ndarray:
+    if img.shape[0] == int(height) and img.shape[1] == int(width):
+        # PIL's Image.resize returns self.copy() when the size does not change, whatever the filter: the same pixels.  Skipping the
+        # numpy -> PIL -> numpy round trip matters: it is GIL-bound Python / C (frombuffer, copy, tobytes + join: ~0.5 ms per call),
+        # so the "thread pool" tiling of a batch of crop-sized images ran serially (64 images: 26 ms on the GPU host, two calls each)
+        return img
     pil = Image.fromarray(img)
     return np.asarray(pil.resize((int(width), int(height)), resample=Image.Resampling.LANCZOS))
 

@@ -673,7 +673,7 @@ class MoondreamModel:
 
     def _crop_into(self, image: Image.Image, out: np.ndarray):
         v = self.config.vision
-        arr = np.asarray(image.convert("RGB"))
+        arr = np.asarray(image if image.mode == "RGB" else image.convert("RGB"))  # (convert() of an RGB image is a plain copy)
         oc = overlap_crop_image(arr, max_crops=v.max_crops, overlap_margin=v.overlap_margin, base_size=(v.crop_size, v.crop_size),
                                 patch_size=v.enc_patch_size, out=out)
         return oc["crops"], tuple(oc["tiling"])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 4 /* 2: md_text_model.fp8 (trailing, optional); 3: md_vit_model.f8, md_text_model.f8 (trailing, optional), md_gemm_f8 + fp8 producers, md_decode_step_b1_supported; 4: md_linear_fp8.format (int4 group-128 weight stream) */
+#define MD_ABI_VERSION 5 /* 2: md_text_model.fp8 (trailing, optional); 3: md_vit_model.f8, md_text_model.f8 (trailing, optional), md_gemm_f8 + fp8 producers, md_decode_step_b1_supported; 4: md_linear_fp8.format (int4 group-128 weight stream; a LAYOUT BREAK: md_linear_fp8 grew 40 -> 48 bytes, which moves every md_text_block_fp8 member); 5: tile_policy in md_gemm_args / md_vit_model / md_text_model (per call; replaces the process-wide "strict" tuning key).  Every version is a layout break for some struct: callers MUST compare md_abi_version() with the header they were built against */
 
 typedef int md_status;
 enum {
@@ -103,7 +103,20 @@ typedef struct {
    * the buffer. */
   void* splitk_ws;
   size_t splitk_ws_bytes;
+  int32_t tile_policy; /* MD_TILE_BY_SHAPE / MD_TILE_PINNED (below); ABI 5 */
 } md_gemm_args;
+
+/* Tile choice of a launch with more than 64 rows -- a PER-CALL property (ABI 5; up to ABI 4 a process-wide tuning key):
+ *   MD_TILE_BY_SHAPE  the config that is fastest for (m, n, k): small launches (one image: 730 / 1458 rows) take the
+ *                     64x64 / 128x128 / 256x128 configs (32x32x16 MFMAs), large ones the four-wave 256x256 kernel
+ *                     (16x16x32 MFMAs).  The two families sum K in different associations: equal to fp32 rounding of the
+ *                     accumulator, not bitwise -- so a row's bits can depend on how many rows travel with it.
+ *   MD_TILE_PINNED    the tile config is a function of the layer (n, k) alone, never of m: every launch of more than 64
+ *                     rows takes the 256x256 kernel, so a sequence gets the same bits alone and in any batch.
+ * md_vit_model.tile_policy / md_text_model.tile_policy apply it to every GEMM of md_vit_encode / md_vision_project* /
+ * md_text_forward* / md_lm_head / md_decode_step made with that struct.  Launches of <= 64 rows (the decode regime) are
+ * not affected: they always take the split-K weight-streaming configs. */
+enum { MD_TILE_BY_SHAPE = 0, MD_TILE_PINNED = 1 };
 
 md_status md_gemm_bf16(const md_gemm_args* args, void* stream);
 size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols);
@@ -156,7 +169,9 @@ typedef struct {
   const float* scale;
   const void* b;
   int32_t n, k, n_pad, k_pad;
-  int32_t format; /* MD_WSTREAM_E4M3 (0, what ABI <= 3 callers pass implicitly) | MD_WSTREAM_INT4_G128 */
+  int32_t format; /* MD_WSTREAM_E4M3 | MD_WSTREAM_INT4_G128.  Added in ABI 4 -- a LAYOUT BREAK: the struct grew from 40 to 48
+                   * bytes, which also moves every member of md_text_block_fp8; a caller built against ABI <= 3 does not pass
+                   * 0 here, it passes garbage.  Only the md_abi_version() check protects against that. */
 } md_linear_fp8;
 md_status md_gemm_fp8w(const void* a, int64_t lda, const md_linear_fp8* lin, void* c, int64_t ldc, int32_t m,
                        int32_t epilogue, int32_t store_pad_cols, int32_t gelu_from_col, void* stream);
@@ -218,10 +233,23 @@ md_status md_amax_bf16(const void* x, int64_t ldx, int32_t rows, int32_t cols, f
 
 /* Measurement / test hook, not needed by the product path: overrides one of the GEMM dispatch
  * knobs at run time (the same knobs are read once from MD_GEMM_* / MD_DECODE_* environment
- * variables at first use).  Keys: "tile" (-1 = automatic; 20 = four-wave 256x256, 11 / 15 = the
- * eight-wave 256x256 baselines, 1 = 256x128, 2 = 128x128, 16 / 10 / 3 = decode-regime configs),
- * "w4", "persist", "group_m", "decode_nt", "decode_cfg", "decode_slices".  Every config accumulates K
- * in the same order, so outputs do not depend on these.  Unknown key: MD_ERR_INVALID_ARG. */
+ * variables at first use).  PROCESS-WIDE and not thread-safe: for sweeps and A/B tests only; nothing that decides the
+ * bits of a product call lives here (that is md_gemm_args.tile_policy, per call).  The complete key list:
+ *   "tile"          -1 = automatic; 20 = four-wave 256x256, 11 / 15 = the eight-wave 256x256 baselines, 1 = 256x128,
+ *                   2 = 128x128, 16 / 10 / 3 = decode-regime configs (forces the config for every launch)
+ *   "w4"            0: the eight-wave 256x256 kernels wherever the four-wave one would be picked (also under
+ *                   MD_TILE_PINNED)
+ *   "persist"       0: eight-wave kernels without their persistent tile loop
+ *   "group_m"       row panels per tile-order group (0 = by shape)
+ *   "decode_nt"     1: decode-regime weights streamed non-temporally
+ *   "decode_cfg"    16 (default) / 10 / 3: decode-regime tile config
+ *   "decode_slices" K slices per decode-regime tile (0 = by shape)
+ *   "rope_fuse"     0: prefill RoPE + KV write as their own kernel instead of the qkv GEMM's epilogue
+ *   "w4_grid"       workgroups of the four-wave kernel's persistent grid (0 = one per CU)
+ *   "w4_variant"    main-loop schedule variant of the four-wave kernel (0 = shipped; others: tools/sweep_w4_variants.py)
+ *   "w4_dbg_*"      in-kernel cycle stamps of the four-wave kernel (tools/w4_probe.py)
+ * Every tile config of one MFMA family accumulates K in the same order, so within a family outputs do not depend on
+ * these.  Unknown key: MD_ERR_INVALID_ARG. */
 md_status md_gemm_set_tuning(const char* key, int32_t value);
 
 /* Live timing of the GEMM launches for the roofline report: while enabled,
@@ -416,6 +444,7 @@ typedef struct {
   md_linear proj_fc1, proj_fc2; /* vision projector MLP (vision.py:77-89) */
   const void* pixel_lut;   /* bf16 [256] */
   const md_vit_f8* f8;     /* NULL: bf16 everywhere (the reference's precision) */
+  int32_t tile_policy;     /* MD_TILE_BY_SHAPE / MD_TILE_PINNED for every GEMM of this call (ABI 5) */
 } md_vit_model;
 
 enum { MD_CROPS_U8_HWC = 0, MD_CROPS_BF16_CHW = 1 };
@@ -490,6 +519,7 @@ typedef struct {
   const float* freqs;    /* fp32 [max_context][rot_dim/2][2] */
   const md_text_fp8* fp8; /* NULL: bf16 weights everywhere (the reference's precision) */
   const md_text_f8* f8;  /* NULL: bf16 prefill */
+  int32_t tile_policy;   /* MD_TILE_BY_SHAPE / MD_TILE_PINNED for every GEMM of this call (ABI 5) */
 } md_text_model;
 
 /* KV slabs: layer l's keys at k + l*layer_stride, element (b,h,p,d) at

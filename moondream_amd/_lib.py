@@ -19,8 +19,9 @@ LIB_PATH = os.path.join(HERE, "libmoondream_hip.so")
 SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "gemm_f8.hip", "quant_f8.hip", "attention_f8kv.hip", "decode_b1.hip", "attention.hip", "elementwise.hip", "sampling_region.hip", "api.hip"]
 
 MD_OK = 0
-ABI_VERSION = 4  # include/moondream_hip.h MD_ABI_VERSION
+ABI_VERSION = 5  # include/moondream_hip.h MD_ABI_VERSION
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
+MD_TILE_BY_SHAPE, MD_TILE_PINNED = 0, 1  # md_gemm_args / md_vit_model / md_text_model .tile_policy (ABI 5)
 MD_CROPS_U8_HWC, MD_CROPS_BF16_CHW = 0, 1
 
 c_void_p, c_int32, c_int64, c_size_t, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
@@ -39,7 +40,7 @@ class MdGemmArgs(C.Structure):
         ("a", c_void_p), ("lda", c_int64), ("lin", MdLinear), ("c", c_void_p), ("ldc", c_int64),
         ("r", c_void_p), ("ldr", c_int64), ("res_row_mod", c_int32), ("m", c_int32),
         ("epilogue", c_int32), ("store_pad_cols", c_int32), ("gelu_from_col", c_int32), ("splitk_ws", c_void_p),
-        ("splitk_ws_bytes", c_size_t),
+        ("splitk_ws_bytes", c_size_t), ("tile_policy", c_int32),
     ]
 
 
@@ -81,7 +82,7 @@ class MdVitModel(C.Structure):
         ("dim", c_int32), ("n_heads", c_int32), ("n_layers", c_int32), ("ff_dim", c_int32),
         ("patch", c_int32), ("crop", c_int32), ("patch_emb", MdLinear), ("pos_emb", c_void_p),
         ("blocks", C.POINTER(MdVitBlock)), ("post_ln", MdLayerNorm), ("proj_fc1", MdLinear),
-        ("proj_fc2", MdLinear), ("pixel_lut", c_void_p), ("f8", C.POINTER(MdVitF8)),
+        ("proj_fc2", MdLinear), ("pixel_lut", c_void_p), ("f8", C.POINTER(MdVitF8)), ("tile_policy", c_int32),
     ]
 
 
@@ -129,7 +130,7 @@ class MdTextModel(C.Structure):
         ("ff_dim", c_int32), ("vocab", c_int32), ("max_context", c_int32), ("prefix_len", c_int32),
         ("rot_dim", c_int32), ("blocks", C.POINTER(MdTextBlock)), ("post_ln", MdLayerNorm),
         ("lm_head", MdLinear), ("wte", c_void_p), ("freqs", c_void_p), ("fp8", C.POINTER(MdTextFp8)),
-        ("f8", C.POINTER(MdTextF8)),
+        ("f8", C.POINTER(MdTextF8)), ("tile_policy", c_int32),
     ]
 
 

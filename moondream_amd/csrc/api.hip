@@ -31,10 +31,24 @@ struct Arena {
   }
 };
 
+// md_vit_model.tile_policy / md_text_model.tile_policy of the entry point this host thread is inside: every GEMM the entry
+// point issues carries it in md_gemm_args.tile_policy.  Thread-local and scoped to the call, i.e. a property of the CALL
+// (two models / threads in one process do not see each other's choice, unlike the process-wide knob of ABI <= 4).
+thread_local int t_tile_policy = MD_TILE_BY_SHAPE;
+struct TilePolicyScope {
+  int saved;
+  explicit TilePolicyScope(int p) : saved(t_tile_policy) { t_tile_policy = p; }
+  ~TilePolicyScope() { t_tile_policy = saved; }
+  TilePolicyScope(const TilePolicyScope&) = delete;
+  TilePolicyScope& operator=(const TilePolicyScope&) = delete;
+};
+inline bool tile_policy_ok(int p) { return p == MD_TILE_BY_SHAPE || p == MD_TILE_PINNED; }
+
 md_status gemm(const void* a, int64_t lda, const md_linear& lin, void* c, int64_t ldc, int m, int epi,
                const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s,
                void* splitk_ws = nullptr, size_t splitk_bytes = 0) {
   md_gemm_args g;
+  g.tile_policy = t_tile_policy;
   g.gelu_from_col = 0;
   g.splitk_ws = splitk_ws;
   g.splitk_ws_bytes = splitk_bytes;
@@ -210,6 +224,8 @@ extern "C" md_status md_vit_encode(const md_vit_model* m, const void* crops, int
                                    int32_t n_crops, void* out, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   MD_CHECK_ARG(m && crops && out && workspace && m->blocks && n_crops > 0);
+  MD_CHECK_ARG(tile_policy_ok(m->tile_policy));
+  TilePolicyScope tile_scope(m->tile_policy);
   MD_CHECK_ARG(m->dim % m->n_heads == 0 && m->crop % m->patch == 0);
   const int hd = m->dim / m->n_heads;
   if (hd != 72 && hd != 64) return MD_ERR_UNSUPPORTED;
@@ -335,6 +351,8 @@ extern "C" md_status md_vision_project(const md_vit_model* m, const void* feats,
                                        int64_t ld_out, void* workspace, size_t workspace_bytes,
                                        void* stream) {
   MD_CHECK_ARG(m && feats && out && workspace && n_images > 0 && tiles_h > 0 && tiles_w > 0);
+  MD_CHECK_ARG(tile_policy_ok(m->tile_policy));
+  TilePolicyScope tile_scope(m->tile_policy);
   if (workspace_bytes < md_vision_project_workspace_bytes(m, n_images)) return MD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int g = m->crop / m->patch, T = g * g, D = m->dim, M = n_images * T;
@@ -356,6 +374,8 @@ extern "C" md_status md_vision_project_grid(const md_vit_model* m, const void* g
                                             int64_t ld_out, void* workspace, size_t workspace_bytes,
                                             void* stream) {
   MD_CHECK_ARG(m && global_feats && grid_feats && out && workspace && H > 0 && W > 0);
+  MD_CHECK_ARG(tile_policy_ok(m->tile_policy));
+  TilePolicyScope tile_scope(m->tile_policy);
   if (workspace_bytes < md_vision_project_workspace_bytes(m, 1)) return MD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int g = m->crop / m->patch, T = g * g, D = m->dim;
@@ -392,6 +412,8 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
                                      void* stream) {
   MD_CHECK_ARG(m && x_in && hidden && pos0 && kv && kv->k && kv->v && workspace && m->blocks);
   MD_CHECK_ARG(batch > 0 && q_len > 0 && m->dim % m->n_heads == 0);
+  MD_CHECK_ARG(tile_policy_ok(m->tile_policy));
+  TilePolicyScope tile_scope(m->tile_policy);
   if (q_len == 1 && batch > 64) {
     // A decode step over more than 64 sequences: blocks of 64 rows, each through the decode-regime
     // kernels (weight-streaming GEMMs, launch-boundary split-K, fused block tail).  The weights are
@@ -584,7 +606,7 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
       md_gemm_args g;
       g.a = w.h; g.lda = Dp; g.lin = b.qkv_fc1; g.c = w.qkv; g.ldc = qld; g.r = nullptr; g.ldr = 0;
       g.res_row_mod = 0; g.m = M; g.epilogue = MD_EPI_GELU; g.store_pad_cols = 1; g.gelu_from_col = qkv_w;
-      g.splitk_ws = w.splitk; g.splitk_ws_bytes = w.splitk_bytes;
+      g.splitk_ws = w.splitk; g.splitk_ws_bytes = w.splitk_bytes; g.tile_policy = t_tile_policy;
       rope_done = false;
       if (rope_in_gemm) {
         md_rope_fuse rf;
@@ -678,6 +700,8 @@ extern "C" md_status md_text_forward_lora(const md_text_model* m, const md_text_
   if (lora == nullptr) return md_text_forward(m, x_in, hidden, batch, q_len, pos0, kv, workspace, workspace_bytes, stream);
   MD_CHECK_ARG(m && x_in && hidden && pos0 && kv && kv->k && kv->v && workspace && m->blocks);
   MD_CHECK_ARG(batch > 0 && q_len > 0 && m->dim % m->n_heads == 0);
+  MD_CHECK_ARG(tile_policy_ok(m->tile_policy));
+  TilePolicyScope tile_scope(m->tile_policy);
   const int hd = m->dim / m->n_heads;
   if (hd != 64) return MD_ERR_UNSUPPORTED;
   const LoraWs w = lora_layout(m, batch, q_len, workspace);
@@ -739,6 +763,8 @@ extern "C" md_status md_lm_head(const md_text_model* m, const void* hidden, int3
                                 void* logits, int64_t ld_logits, void* workspace,
                                 size_t workspace_bytes, void* stream) {
   MD_CHECK_ARG(m && hidden && logits && workspace && batch > 0 && q_len > 0);
+  MD_CHECK_ARG(tile_policy_ok(m->tile_policy));
+  TilePolicyScope tile_scope(m->tile_policy);
   if (workspace_bytes < md_lm_head_workspace_bytes(m, batch)) return MD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int D = m->dim;

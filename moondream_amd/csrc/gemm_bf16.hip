@@ -56,9 +56,6 @@ struct Knobs {
   int decode_cfg = 16; // MD_DECODE_CFG: d / 6 = alternatives to the 64x64 + helper-waves config
   int decode_slices = 0;  // MD_DECODE_SLICES
   int rope_fuse = 1;      // MD_ROPE_FUSE=0: prefill RoPE + KV write as their own kernel again (A/B, tests)
-  int strict = 0;         // md_gemm_set_tuning("strict"): every launch of more than 64 rows takes the four-wave kernel, whatever its
-                          // row count (that kernel multiplies with 16x16x32 MFMAs, the small-shape configs with 32x32x16: equal to fp32
-                          // rounding, not bitwise -- MoondreamModel.set_strict_batch_invariance)
   Knobs() {
     auto geti = [](const char* n, int d) { const char* e = getenv(n); return (e && *e) ? atoi(e) : d; };
     tile = geti("MD_GEMM_TILE", -1);
@@ -704,9 +701,12 @@ int decode_slices(int n_store, int k_pad) {
 // (M, N, K) only, so a given layer always runs the same kernel -- and every config
 // accumulates K in the same order (sequential 16-wide MFMA steps), so results do
 // not depend on it.
-int pick_tile(int M, int n_store, int K) {
+int pick_tile(int M, int n_store, int K, int policy) {
   if (knobs().tile >= 0) return knobs().tile;  // experiments / tests: force a tile config
-  if (knobs().strict && M > 64) return 20;
+  // MD_TILE_PINNED (md_gemm_args.tile_policy, per call): the config is a function of the layer, never of the row count --
+  // the 256x256 kernel (16x16x32 MFMAs; the small-shape configs below multiply with 32x32x16: equal to fp32 rounding, not
+  // bitwise), so that a sequence gets the same bits alone and in a batch
+  if (policy == MD_TILE_PINNED && M > 64) return knobs().w4 ? 20 : 11;
   // single-image regime: a layer that makes at most 128 tiles of 128 x 128 leaves half the chip idle and
   // runs at the latency of its K loop -- the 64 x 64 tiles with the 4-deep ring and DMA helper waves
   // (the decode-regime config) quadruple the workgroups and hide the load latency
@@ -773,7 +773,8 @@ md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse*
   k.partial_ld = k.partial_slice_stride = 0;
   k.nt = knobs().nt;  // decode regime: non-temporal weight stream (kernel-level +2..10 %, nothing end to end)
   hipStream_t s = (hipStream_t)stream;
-  int tile = pick_tile(k.M, k.n_store, k.K);
+  MD_CHECK_ARG(a->tile_policy == MD_TILE_BY_SHAPE || a->tile_policy == MD_TILE_PINNED);
+  int tile = pick_tile(k.M, k.n_store, k.K, a->tile_policy);
   k.slices = 1;
   k.slabs = nullptr;
   k.tickets = nullptr;
@@ -993,7 +994,6 @@ extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   else if (s == "decode_slices") k.decode_slices = value;
   else if (s == "w4_variant") md_gemm_w4_set_variant(value);
   else if (s == "rope_fuse") k.rope_fuse = value;
-  else if (s == "strict") k.strict = value;
   else if (s == "w4_grid") md_gemm_w4_set_grid(value);
   else if (s == "w4_dbg_lo") md_gemm_w4_set_debug(0, (uint32_t)value);
   else if (s == "w4_dbg_hi") md_gemm_w4_set_debug(1, (uint32_t)value);

@@ -30,14 +30,13 @@ RENAME_RULES = [  # reference: lora.py:63-69
 
 
 def variant_cache_dir() -> Path:
-    """reference: lora.py:12-21."""
-    hub = os.environ.get("HF_HUB_CACHE")
-    if hub is not None:
-        return Path(hub) / "md_variants"
-    home = os.environ.get("HF_HOME")
-    if home is not None:
-        return Path(home) / "hub" / "md_variants"
-    return Path("~/.cache/huggingface/hub").expanduser() / "md_variants"
+    """Where variant files live on disk -- an on-disk contract shared with the reference (lora.py:12-21):
+    ``$HF_HUB_CACHE/md_variants``, else ``$HF_HOME/hub/md_variants``, else ``~/.cache/huggingface/hub/md_variants``."""
+    for env, sub in (("HF_HUB_CACHE", ()), ("HF_HOME", ("hub",))):
+        root = os.environ.get(env)
+        if root is not None:
+            return Path(root, *sub, "md_variants")
+    return Path.home() / ".cache" / "huggingface" / "hub" / "md_variants"
 
 
 def cached_variant_path(variant_id: str) -> Path:
@@ -52,14 +51,20 @@ def cached_variant_path(variant_id: str) -> Path:
 
 
 def nest(flat: Dict[str, torch.Tensor]) -> dict:
-    """reference: lora.py:43-51."""
+    """Dotted keys -> nested dicts (``"a.b.c": t`` -> ``{"a": {"b": {"c": t}}}``), the layout the ``lora`` argument of
+    ``text_decoder`` is indexed with (reference: lora.py:43-51, consumed at text.py:31-32,55-56)."""
     tree: dict = {}
-    for k, v in flat.items():
-        parts = k.split(".")
-        d = tree
-        for p in parts[:-1]:
-            d = d.setdefault(p, {})
-        d[parts[-1]] = v
+    for dotted, tensor in flat.items():
+        *path, leaf = dotted.split(".")
+        node = tree
+        for name in path:
+            nxt = node.get(name)
+            if nxt is None:
+                nxt = node[name] = {}
+            elif not isinstance(nxt, dict):
+                raise ValueError(f"variant key {dotted!r} nests under a tensor at {name!r}")
+            node = nxt
+        node[leaf] = tensor
     return tree
 
 

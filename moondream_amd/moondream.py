@@ -30,6 +30,7 @@ from PIL import Image
 from . import _lib
 from .config import MoondreamConfig
 from .image_crops import crop_count, overlap_crop_image, reconstruct_from_crops
+from .integration import MASK_CAUSAL, MASK_PREFIX_LM, classify_attn_mask
 from .lora import variant_state_dict
 from .weights import PackedLora, PackedModel
 
@@ -134,6 +135,7 @@ class MoondreamModel:
         # all decoder blocks; False = the batched kernels at one row (bit-identical to a row of a batch)
         self.single_sequence_kernel = True
         self.strict_batch_invariance = False  # see set_strict_batch_invariance
+        self._tile_policy = _lib.MD_TILE_BY_SHAPE  # of the call in flight: _select_kernels
         self._b1_sync = None  # barrier state of that kernel: zeroed once, then owned by it
         self._b1_used = False
         # batch_generate over raw images: image prefix + prompt in one decoder pass (False: the reference's two passes).
@@ -356,13 +358,17 @@ class MoondreamModel:
 
     def _select_kernels(self, n_sequences: int):
         """The library's tile choice by row count would give a lone image (730 / 1458 rows) the small-shape tile configs and a
-        batch the four-wave kernel, whose 16x16x32 MFMAs sum K in another association.  Since round 4 every call is made with
-        the four-wave kernel PINNED for launches of more than 64 rows (a process-wide library knob) -- so that
-        ``batch_generate_ids(B)[i] == batch_generate_ids([x_i])`` holds bit for bit in the DEFAULT mode as long as the lone
-        sequence runs on the batched kernels -- except the documented latency path: ONE sequence with
-        ``single_sequence_kernel`` on (small-shape tiles at prefill, the persistent kernel at decode)."""
-        pin = 1 if (self.strict_batch_invariance or not (n_sequences == 1 and self.single_sequence_kernel)) else 0
-        _lib.check(self.lib.md_gemm_set_tuning(b"strict", pin))  # (set on every call: the knob is the library's, not this model's)
+        batch the four-wave kernel, whose 16x16x32 MFMAs sum K in another association.  Every call is therefore made with the
+        tile config PINNED to the layer shape (``tile_policy = MD_TILE_PINNED`` in THIS model's ``md_vit_model`` /
+        ``md_text_model`` structs, read by the library per call: ABI 5; no process-wide state, so two models or threads in
+        one process do not affect each other's bits) -- so that ``batch_generate_ids(B)[i] == batch_generate_ids([x_i])``
+        holds bit for bit in the DEFAULT mode as long as the lone sequence runs on the batched kernels -- except the
+        documented latency path: ONE sequence with ``single_sequence_kernel`` on (small-shape tiles at prefill, the persistent
+        kernel at decode).  Called by every public entry point that can launch a GEMM of more than 64 rows."""
+        pin = (self.strict_batch_invariance or not (n_sequences == 1 and self.single_sequence_kernel))
+        self._tile_policy = _lib.MD_TILE_PINNED if pin else _lib.MD_TILE_BY_SHAPE
+        self.w.vit.tile_policy = self._tile_policy
+        self.w.text.tile_policy = self._tile_policy
 
     def compile(self):
         """The reference rebinds the seam to torch.compile'd functions here
@@ -376,6 +382,7 @@ class MoondreamModel:
         v = self.config.vision
         assert x.dtype == BF16 and x.dim() == 4 and x.shape[1:] == (3, v.crop_size, v.crop_size)
         x = x.contiguous()
+        self._select_kernels(1)  # the seam is the reference's one-image-at-a-time path
         return self._vit_run(x, _lib.MD_CROPS_BF16_CHW)
 
     def _vit_run(self, crops: torch.Tensor, kind: int) -> torch.Tensor:
@@ -400,6 +407,7 @@ class MoondreamModel:
         """global [729,D_v] + stitched grid [h,w,D_v] -> [729,D].  reference: moondream.py:171-172."""
         v = self.config.vision
         g, r = g.contiguous(), r.contiguous()
+        self._select_kernels(1)
         out = torch.empty(v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
         need = self.lib.md_vision_project_workspace_bytes(C.byref(self.w.vit), 1)
         ws = self._workspace(need)
@@ -497,12 +505,35 @@ class MoondreamModel:
         )
         return logits
 
+    def _seam_rule(self, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, t: int):
+        """(first position, causal?) for the mask slice and positions the reference passes through the seam
+        (moondream.py:304-309: a slice of the prefix-LM buffer; 571-575: of a plain tril for the text-only query;
+        472-474,515: the decode row).  Any other mask, and non-consecutive positions, raise ValueError."""
+        if int(pos_ids.numel()) != t:
+            raise ValueError(f"pos_ids has {int(pos_ids.numel())} entries for {t} embedding row(s)")
+        tc = self.config.text
+        kind = classify_attn_mask(attn_mask, pos_ids, tc.prefix_attn, tc.max_context)
+        pos0 = int(pos_ids.reshape(-1)[0])
+        if kind == MASK_PREFIX_LM and pos0 + t < tc.prefix_attn:
+            # such a slice lets its rows see keys [pos0 + t, prefix) that this pass does not write; the library reads keys
+            # [0, pos0 + t) only.  The reference always prefills the whole prefix in one pass (moondream.py:254-258).
+            raise ValueError(f"a prefix-LM pass must reach the end of the {tc.prefix_attn}-position bidirectional prefix "
+                             f"(got positions [{pos0}, {pos0 + t}))")
+        return pos0, kind == MASK_CAUSAL
+
     def _prefill(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, lora=None):
-        """reference: moondream.py:174-181.  x [1,T,D]; pos_ids int64 [T] consecutive."""
-        return self._text_forward(x.to(self._device), int(pos_ids[0]), 0, lora=lora)
+        """reference: moondream.py:174-181.  x [1,T,D]; attn_mask bool [1,1,T,ctx] (or None = the prefix-LM buffer's
+        slice); pos_ids int64 [T] consecutive.  The mask is CLASSIFIED, not applied: the prefix-LM slice and the plain
+        causal slice (text-only query) select the library's two rules; anything else is a ValueError."""
+        if x.dim() != 3 or x.shape[0] != 1:
+            raise ValueError(f"x must be [1, T, D] (got {tuple(x.shape)})")
+        pos0, causal = self._seam_rule(attn_mask, pos_ids, int(x.shape[1]))
+        self._select_kernels(1)
+        return self._text_forward(x.to(self._device), pos0, 0, causal=causal, lora=lora)
 
     def _decode_one_tok(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor], pos_ids: torch.Tensor, lora=None):
-        """reference: moondream.py:183-192.  x [1,1,D] -> (logits [1,V], hidden [1,1,D])."""
+        """reference: moondream.py:183-192.  x [1,1,D], attn_mask bool [1,1,ctx] with ones on [0, pos] ->
+        (logits [1,V], hidden [1,1,D])."""
         hidden = self._prefill(x, attn_mask, pos_ids, lora)
         return self._lm_head(hidden), hidden
 
@@ -539,11 +570,23 @@ class MoondreamModel:
         crop bytes on the host."""
         v = self.config.vision
         n_img = len(images)
-        pre = getattr(self, "_prefetched_crops", {}).pop(tuple(id(im) for im in images), None)
-        chunks, staged = staged if staged is not None else pre[1] if pre is not None else self._stage_crops(images)
+        if staged is None:
+            # (a prefetched entry is taken only when it is going to be USED: popped and dropped it would leak its pinned buffers)
+            pre = getattr(self, "_prefetched_crops", {}).pop(tuple(id(im) for im in images), None)
+            staged = pre[1] if pre is not None else self._stage_crops(images)
+            try:
+                return self._run_vision_encoder_batch(images, mark, staged)
+            except BaseException:
+                self._drain_staged(staged)  # this call owns the staging it made / took over: nothing stays marked busy
+                raise
+        chunks, staged = staged
         cropped: List[Tuple[np.ndarray, Tuple[int, int]]] = []
         feat_parts = []
-        for ci, ((c0, c1, tot), (host, token, futs)) in enumerate(zip(chunks, staged)):
+        # OWNERSHIP of the pinned staging buffers: ``staged`` is consumed IN PLACE -- a chunk leaves the list at the moment its
+        # buffer is handed back (uploaded or released), so whoever holds the list (the pipelined engine's drain, on an early
+        # exit or an exception in here) releases exactly the chunks that are still in it and no token twice
+        for ci in range(len(staged)):
+            host, token, futs = staged[0]
             part = [f.result() for f in futs]
             if mark is not None and ci == 0:
                 mark("host_tiling")  # phase timing: the GPU has nothing of this batch to run before the first crops exist
@@ -565,12 +608,14 @@ class MoondreamModel:
                 np.concatenate(uniq, axis=0, out=host2)
                 dev_crops = self._upload_pinned(host2, token2)
                 self._release_pinned(token)
+                staged.pop(0)
                 f = self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC)
                 if len(expand) != dev_crops.shape[0]:
                     f = f[torch.tensor(expand, dtype=torch.int64, device=self._device)]
                 feat_parts.append(f)
                 continue
             dev_crops = self._upload_pinned(host, token)
+            staged.pop(0)
             feat_parts.append(self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC))
         feats = feat_parts[0] if len(feat_parts) == 1 else torch.cat(feat_parts, dim=0)  # [sum crops, 729, Dv]
         out = torch.empty(n_img, v.n_patches, v.proj_out_dim, dtype=BF16, device=self._device)
@@ -665,11 +710,21 @@ class MoondreamModel:
         """Drop prefetched batches that were never encoded (waits for their workers, returns the pinned buffers)."""
         d = getattr(self, "_prefetched_crops", {})
         for k in ([key] if key is not None else list(d)):
-            _, (_, staged) = d.pop(k)
-            for host, token, futs in staged:
-                for f in futs:
-                    f.result()
-                self._release_pinned(token)
+            _, staged = d.pop(k)
+            self._drain_staged(staged)
+
+    def _drain_staged(self, staged) -> None:
+        """Return the pinned buffers of staged chunks that were never uploaded (``_run_vision_encoder_batch`` removes a chunk
+        from the list when it hands its buffer back, so what is left here is exactly what is still owned)."""
+        lst = staged[1]
+        while lst:
+            host, token, futs = lst.pop(0)
+            for f in futs:
+                try:
+                    f.result()  # the worker must be done with the buffer before it is handed out again
+                except Exception:
+                    pass  # (a failed crop was / will be reported by the consumer; here only the buffer matters)
+            self._release_pinned(token)
 
     def _crop_into(self, image: Image.Image, out: np.ndarray):
         v = self.config.vision
@@ -778,16 +833,6 @@ class MoondreamModel:
                            "md_kv_quantize_f8")
 
     # --------------------------------------------------------------- sampling
-    def _apply_top_p(self, probs: torch.Tensor, top_p: float) -> torch.Tensor:
-        """reference: moondream.py:270-278."""
-        probs_sort, probs_idx = torch.sort(probs, dim=-1, descending=True)
-        csum = torch.cumsum(probs_sort, dim=-1)
-        probs_sort[csum - probs_sort > top_p] = 0.0
-        probs_sort.div_(probs_sort.sum(dim=-1, keepdim=True))
-        out = torch.zeros_like(probs)
-        out.scatter_(dim=-1, index=probs_idx, src=probs_sort)
-        return out
-
     def _pick(self, logits: torch.Tensor, temperature: float, top_p: float, suppress_id: int = -1,
               generator: Optional[torch.Generator] = None, probs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[B,V] -> int32 [B]   (reference: moondream.py:313-318,521-528).  Greedy: argmax, ties to the
@@ -1220,10 +1265,7 @@ class MoondreamModel:
             st = getattr(self, "_pipe_staged", None)  # a consumer that stops early: the tiling started ahead is drained, its buffers returned
             self._pipe_staged = None
             if st is not None:
-                for host, token, futs in st[1]:
-                    for f in futs:
-                        f.result()
-                    self._release_pinned(token)
+                self._drain_staged(st)
 
     def _pipelined_loop(self, it, cur, staged, pending, max_tokens, ignore_eos):
         tk = self.config.tokenizer
@@ -1327,6 +1369,7 @@ class MoondreamModel:
         """reference: moondream.py:280-321.  ``causal`` stands for the reference's
         ``attn_mask`` argument: the only non-default mask it ever passes is the plain
         lower-triangular one of a text-only query (moondream.py:571-575)."""
+        self._select_kernels(1)  # a lone sequence's own tile policy, whatever an earlier (batch) call left in the structs
         with torch.inference_mode():
             ids = prompt_tokens.to(torch.int32)
             emb = self._embed(ids)
@@ -1558,7 +1601,7 @@ class MoondreamModel:
         ws = tabs["splitk"]
         out = torch.empty(m, lin.n_pad, dtype=BF16, device=self._device)
         args = _lib.MdGemmArgs(a.data_ptr(), lin.k_pad, lin.struct(), out.data_ptr(), lin.n_pad, None, 0, 0, m, epi, 1, 0,
-                               ws.data_ptr(), ws.numel())
+                               ws.data_ptr(), ws.numel(), self._tile_policy)
         _lib.check(self.lib.md_gemm_bf16(C.byref(args), self._stream()), "md_gemm_bf16")
         return out[:, : lin.n]
 

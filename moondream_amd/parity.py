@@ -57,7 +57,7 @@ def first_divergences(got_ids: Sequence[Sequence[int]], ref_ids, margins, tokens
 
 def parity_report(got_ids, ref_ids, margins, got_topk: Optional[np.ndarray], ref_topk: Optional[np.ndarray],
                   tokens: Optional[int] = None, max_err_cap: float = 0.5, min_exact: Optional[int] = None,
-                  ref_topk_idx: Optional[np.ndarray] = None, flat_cap: float = 0.5, p99_ulps_cap: float = 12.0) -> Dict[str, object]:
+                  ref_topk_idx: Optional[np.ndarray] = None, flat_cap: float = 0.5, p99_ulps_cap: float = 10.0) -> Dict[str, object]:
     """The JSON-able verdict.  ``parity_ok`` iff (a) the measured logit error is under its caps (max, p99 in ulps), (b) every
     first divergence sits at a reference margin <= min(NOISE_FACTOR x the measured max error, flat_cap) AND is covered by
     the errors measured on its own two logits (``ref_topk_idx`` given), (c) at least ``min_exact`` sequences are identical

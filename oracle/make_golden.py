@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [lora] [0.5b] [2b] [bench64] [detect13] [reftime]
+Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [lora] [0.5b] [2b] [bench64] [vqa64] [detect13] [reftime]
 """
 from __future__ import annotations
 
@@ -360,7 +360,7 @@ def gen_textonly(name="tiny_textonly", cfg_name="tiny", seed=1, n_cases=3, max_t
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
 
 
-def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tokens=32):
+def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tokens=32, prompt_kind="caption"):
     """The TIMED configuration (BASELINE.json configs[2]): the reference itself on the exact 64
     seed-1 378x378 images and caption prompt that bench.py times, Moondream-2B, greedy, 32 tokens.
     No survivorship filter: every image is kept, with the reference's top-1/top-2 margin of every
@@ -370,10 +370,14 @@ def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tok
     sd = synth.synthetic_state_dict(cfg, seed=seed)
     model, ref_md = load_reference(cfg, sd)
     caption_ids = cfg.tokenizer.templates["caption"]["normal"]
+    # prompt_kind "vqa32" (round 5, BASELINE configs[1] at bench scale): the 32-id question prompts bench.py's vqa32 leg
+    # times (synth.synthetic_vqa_prompt: query prefix + 27 seeded ids + suffix, reference moondream.py:564,586-591,604),
+    # one per image, through the same _generate_answer the reference's query() drives (moondream.py:606-618)
+    prompts = [caption_ids if prompt_kind == "caption" else synth.synthetic_vqa_prompt(cfg, i, seed) for i in range(n_images)]
     toks, margins, top_v, top_i, t_enc, t_gen = [], [], [], [], [], []
     for i in range(n_images):
         image = synth.synthetic_image_array(i, seed, (378, 378))
-        r = run_reference_caption(model, ref_md, image, caption_ids, max_tokens)
+        r = run_reference_caption(model, ref_md, image, prompts[i], max_tokens)
         assert len(r["tokens"]) == max_tokens, (i, len(r["tokens"]))  # no EOS inside the window
         toks.append(r["tokens"])
         margins.append(r["margins"])
@@ -384,7 +388,8 @@ def gen_bench64(name="md2b_bench64", cfg_name="2b", seed=1, n_images=64, max_tok
         t_gen.append(r["t_gen"])
         print(f"[{name}] image {i}: min margin {min(r['margins']):.4f} encode {r['t_enc']:.2f}s gen {r['t_gen']:.2f}s", flush=True)
     out = {
-        "seed": np.int64(seed), "cfg": np.array(cfg_name), "prompt": np.array(caption_ids),
+        "seed": np.int64(seed), "cfg": np.array(cfg_name),
+        "prompt": np.array(caption_ids if prompt_kind == "caption" else prompts),   # caption: [5]; vqa32: [n_images, 32]
         "tokens": np.array(toks, dtype=np.int32), "margins": np.array(margins, dtype=np.float32),
         "top8_val": np.array(top_v, dtype=np.float32), "top8_idx": np.array(top_i, dtype=np.int32),
     }
@@ -840,6 +845,8 @@ def main():
         gen_reftime()
     if "bench64" in which:
         gen_bench64()
+    if "vqa64" in which:       # the vqa32 bench leg's fixture (64 images x 32-id question prompts)
+        gen_bench64("md2b_vqa64", prompt_kind="vqa32")
     if "detect13" in which:
         gen_detect13()
     if "lora2b" in which:      # the side paths at the 2B shapes (tests/test_model_gpu.py::test_2b_lora_and_reasoning_vs_reference)

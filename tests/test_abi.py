@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.md_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.md_abi_version() == _lib.ABI_VERSION == 5
     assert lib.md_status_string(0) == b"ok"
     assert b"workspace" in lib.md_status_string(3)
 

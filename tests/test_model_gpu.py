@@ -339,6 +339,66 @@ def test_text_only_query_vs_reference(tiny, golden_dir):
         model.query(None, "1 2 3", spatial_refs=[(0.5, 0.5)])
 
 
+def test_seam_honours_the_mask_the_reference_passes(tiny, golden_dir):
+    """The reference's text-only query goes THROUGH the seam with a plain tril mask slice (moondream.py:571-575 ->
+    304-309 -> self._prefill(prompt_emb, mask, pos_ids, lora); decode rows 472-474,515).  Driving _prefill /
+    _decode_one_tok with exactly those tensors must reproduce the reference's ids (tiny_textonly.npz) and its
+    logits; the prefix-LM slice for the same positions gives another result (so the mask is really read), and a mask
+    that is neither rule is refused."""
+    g0, cfg, sd, model = tiny
+    g = load_golden(golden_dir, "tiny_textonly.npz")
+    t = cfg.text
+    ctx = t.max_context
+    tril = torch.tril(torch.ones(1, 1, ctx, ctx, dtype=torch.bool)).to(model.device)   # moondream.py:573-575
+    prefix_lm = tril.clone()
+    prefix_lm[..., : t.prefix_attn, : t.prefix_attn] = 1                              # moondream.py:138-146
+    tok = cfg.tokenizer
+    model.caption(golden_image(g0, 0), settings={"temperature": 0, "max_tokens": 2})   # dirty the slabs
+    for i in range(int(g["n_cases"])):
+        want = g[f"q{i}.tokens"].tolist()
+        ref_logits = bits_to_bf16(g[f"q{i}.step_logits"]).float()
+        prompt = [tok.bos_id] + list(tok.templates["query"]["prefix"]) + g[f"q{i}.question"].tolist() + list(tok.templates["query"]["suffix"])
+        n = len(prompt)
+        emb = model._embed(torch.tensor([prompt]))
+        pos_ids = torch.arange(0, n, dtype=torch.long)
+        hidden = model._prefill(emb, tril[:, :, 0:n, :], pos_ids, None)
+        logits = model._lm_head(hidden)
+        mask = torch.zeros(1, 1, ctx, dtype=torch.bool, device=model.device)           # moondream.py:472-474
+        mask[:, :, :n] = 1
+        pos, got = n, []
+        for step in range(len(want)):
+            lg = logits[0].float().cpu()
+            if step > 0:
+                lg[tok.answer_id] = float("-inf")
+            ok = torch.isfinite(ref_logits[step])
+            assert float((lg[ok] - ref_logits[step][ok]).abs().max()) <= 0.5, (i, step)
+            nxt = int(torch.argmax(lg))
+            got.append(nxt)
+            mask[:, :, pos] = 1
+            logits, _ = model._decode_one_tok(model._embed(torch.tensor([[nxt]])), mask, torch.tensor([pos], dtype=torch.long), None)
+            pos += 1
+        assert got == want, (i, got, want)
+        # the prefix-LM slice of these rows would let them see keys [n, 730) that the pass does not write: refused
+        with pytest.raises(ValueError):
+            model._prefill(emb, prefix_lm[:, :, 0:n, :], pos_ids, None)
+    # image prefill through the seam with the reference's own slice == the engine's encode_image
+    enc = model.encode_image(golden_image(g0, 0))
+    img_emb = model._run_vision_encoder(golden_image(g0, 0))
+    bos = model._embed(torch.tensor([[tok.bos_id]]))
+    x = torch.cat([bos, img_emb[None]], dim=1)
+    model._prefill(x, prefix_lm[:, :, 0 : x.shape[1], :], torch.arange(x.shape[1], dtype=torch.long), None)
+    assert torch.equal(model._kv_k[:, 0, :, : enc.pos], torch.stack([k[0] for k, _ in enc.caches]))
+    # under the causal slice the same rows give another cache (and it is accepted: it is one of the two rules)
+    model._prefill(x, tril[:, :, 0 : x.shape[1], :], torch.arange(x.shape[1], dtype=torch.long), None)
+    assert not torch.equal(model._kv_k[1:, 0, :, : enc.pos], torch.stack([k[0] for k, _ in enc.caches])[1:])
+    bad = tril[:, :, 0:4, :].clone()
+    bad[0, 0, 3, 1] = False
+    with pytest.raises(ValueError):
+        model._prefill(x[:, :4], bad, torch.arange(4, dtype=torch.long), None)
+    with pytest.raises(ValueError):
+        model._prefill(x[:, :4], None, torch.tensor([0, 1, 3, 4]), None)
+
+
 def test_multicrop_images_vs_reference(golden_dir):
     g = load_golden(golden_dir, "tiny_multicrop.npz")
     cfg, sd, model = build("tiny", 3)
@@ -1044,7 +1104,7 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     idx = torch.from_numpy(g["img0.cap.top8_idx"][0]).long()
     ref_top = torch.from_numpy(g["img0.cap.top8_val"][0])
     err = (logits[0].float().cpu()[idx] - ref_top).abs().max()
-    assert float(err) <= 0.75, float(err)
+    assert float(err) <= 0.5, float(err)  # measured cap on every box so far: 0.3125 (the licence of moondream_amd/parity.py is capped at the same 0.5)
     # margin-aware VQA
     refq = g["img0.vqa.tokens"].tolist()
     gotq = model.batch_generate_ids([images[0]], [g["img0.vqa.prompt"].tolist()], max_tokens=len(refq))[0]
@@ -1073,7 +1133,7 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     floor = bench.exact_floor(64, 32, second)
     print(f"second oracle (reference ATen calls on this GPU): {second['exact']}/64 identical, max |logit err| {second['max_logit_err']:.4f} "
           f"(p99 {second['p99_logit_err']:.4f}), largest margin at a first divergence {second['max_divergence_margin']:.4f} -> floor {floor}")
-    assert second["max_logit_err"] <= 0.5
+    assert second["max_logit_err"] <= 0.5 and second["exact"] >= bench.SECOND_ORACLE_SANITY, second
     for pipelined in (False, True):
         if pipelined:
             model.compile()

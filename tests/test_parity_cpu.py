@@ -1,6 +1,9 @@
 """Host-side parity logic (moondream_amd/parity.py): the measured-noise licence for greedy ids and the margin-aware
 comparison of detect objects, on constructed cases and on the committed reference fixtures themselves."""
 import os
+import sys
+
+import pytest
 
 import numpy as np
 
@@ -166,3 +169,94 @@ def test_teacher_forced_decisions_with_a_wide_margin_must_all_match():
     got2[3, 5, 1] += 0.125
     rep = P.parity_report(ids, ref_ids, margins, got2, ref2, tokens=6)
     assert rep["parity_ok"] and rep["parity_tf_decisions_must_match"] == 4 * 7 - 1 and rep["parity_tf_decisions_agree"] == 4 * 7 - 1
+
+
+# ------------------------------------------------------------------ the seam's mask argument (moondream_amd/integration.py)
+def _reference_masks(ctx=2048, prefix=730):
+    """The two mask buffers the reference builds: moondream.py:138-146 (prefix-LM) and 571-575 (text-only tril)."""
+    import torch
+
+    tril = torch.tril(torch.ones(1, 1, ctx, ctx, dtype=torch.bool))
+    prefix_lm = tril.clone()
+    prefix_lm[..., :prefix, :prefix] = 1
+    return tril, prefix_lm
+
+
+def test_seam_mask_classifier_on_the_masks_the_reference_passes():
+    import torch
+    from moondream_amd.integration import MASK_CAUSAL, MASK_EITHER, MASK_PREFIX_LM, classify_attn_mask, consecutive_positions
+
+    ctx, P = 2048, 730
+    tril, prefix_lm = _reference_masks(ctx, P)
+    ar = lambda a, b: torch.arange(a, b, dtype=torch.long)
+    # encode_image (moondream.py:254-257): rows 0..729 of the prefix-LM buffer
+    assert classify_attn_mask(prefix_lm[:, :, 0:730, :], ar(0, 730), P, ctx) == MASK_PREFIX_LM
+    # prompt prefill after an image (moondream.py:307-309): rows 730.. -- both rules select keys [0, p]
+    assert classify_attn_mask(prefix_lm[:, :, 730:735, :], ar(730, 735), P, ctx) == MASK_EITHER
+    assert classify_attn_mask(tril[:, :, 730:762, :], ar(730, 762), P, ctx) == MASK_EITHER
+    # text-only query (moondream.py:571-575): rows 0..n-1 of a plain tril
+    assert classify_attn_mask(tril[:, :, 0:9, :], ar(0, 9), P, ctx) == MASK_CAUSAL
+    # rows 0..729 of the tril: causal over the image positions (not what encode_image passes, but one of the two rules)
+    assert classify_attn_mask(tril[:, :, 0:730, :], ar(0, 730), P, ctx) == MASK_CAUSAL
+    # a pass that straddles the prefix boundary
+    assert classify_attn_mask(prefix_lm[:, :, 0:740, :], ar(0, 740), P, ctx) == MASK_PREFIX_LM
+    # decode rows (moondream.py:472-474,515): ones on [0, pos]
+    for pos, want in ((735, MASK_EITHER), (12, MASK_CAUSAL), (728, MASK_CAUSAL), (729, MASK_EITHER), (730, MASK_EITHER), (ctx - 1, MASK_EITHER)):
+        row = torch.zeros(1, 1, ctx, dtype=torch.bool)
+        row[:, :, : pos + 1] = 1
+        assert classify_attn_mask(row, torch.tensor([pos]), P, ctx) == want, pos
+    assert classify_attn_mask(None, ar(3, 8), P, ctx) == MASK_EITHER
+    # anything else is refused, loudly
+    hole = tril[:, :, 0:9, :].clone()
+    hole[0, 0, 5, 2] = False
+    stale = torch.zeros(1, 1, ctx, dtype=torch.bool)
+    stale[:, :, :800] = 1                      # decode row that exposes slots beyond pos
+    for mask, pos in ((hole, ar(0, 9)), (stale, torch.tensor([735])), (tril[:, :, 0:9, :], ar(1, 10)),
+                      (tril[:, :, 0:9, :].to(torch.uint8), ar(0, 9)), (tril[:, :, 0:9, :100], ar(0, 9)),
+                      (tril[:, :, 0:8, :], ar(0, 9)), (tril[0, 0, 0:9, :], ar(0, 9))):
+        with pytest.raises(ValueError):
+            classify_attn_mask(mask, pos, P, ctx)
+    # positions: consecutive ascending only
+    assert consecutive_positions(ar(730, 735)) == 730
+    for bad in (torch.tensor([0, 1, 3]), torch.tensor([5, 4, 3]), torch.tensor([2, 2]), torch.tensor([], dtype=torch.long), torch.tensor([-1, 0])):
+        with pytest.raises(ValueError):
+            consecutive_positions(bad)
+    with pytest.raises(ValueError):
+        classify_attn_mask(None, ar(2040, 2050), P, ctx)
+
+
+def test_seam_mask_classifier_on_the_reference_models_own_buffers():
+    """Same check on the tensors the unmodified reference really builds (build container only)."""
+    import torch
+    ref_root = os.environ.get("MOONDREAM_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "moondream", "torch")):
+        pytest.skip("needs the reference checkout (build container)")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import make_golden as mg
+    from moondream_amd import synth
+    from moondream_amd.config import get_config
+    from moondream_amd.integration import MASK_CAUSAL, MASK_EITHER, MASK_PREFIX_LM, classify_attn_mask
+
+    cfg = get_config("tiny")
+    model, _ = mg.load_reference(cfg, synth.synthetic_state_dict(cfg, seed=1))
+    seen = []
+    orig_prefill, orig_decode = model._prefill, model._decode_one_tok
+
+    def prefill_tap(x, mask, pos_ids, lora):
+        seen.append(("prefill", classify_attn_mask(mask, pos_ids, cfg.text.prefix_attn, cfg.text.max_context), int(pos_ids[0])))
+        return orig_prefill(x, mask, pos_ids, lora)
+
+    def decode_tap(x, mask, pos_ids, lora):
+        seen.append(("decode", classify_attn_mask(mask, pos_ids, cfg.text.prefix_attn, cfg.text.max_context), int(pos_ids[0])))
+        return orig_decode(x, mask, pos_ids, lora)
+
+    model._prefill, model._decode_one_tok = prefill_tap, decode_tap
+    from PIL import Image
+    img = Image.fromarray(synth.synthetic_image_array(0, 1, (378, 378)), "RGB")
+    model.caption(img, settings={"temperature": 0, "max_tokens": 3, "variant": None})
+    model.query(None, "11 12 13", settings={"temperature": 0, "max_tokens": 3})
+    kinds = [(k, r) for k, r, _ in seen]
+    assert ("prefill", MASK_PREFIX_LM) == kinds[0]          # encode_image
+    assert ("prefill", MASK_EITHER) == kinds[1]             # caption prompt at pos 730
+    assert ("prefill", MASK_CAUSAL) in kinds                # the text-only query's prompt at pos 0
+    assert ("decode", MASK_CAUSAL) in kinds and ("decode", MASK_EITHER) in kinds

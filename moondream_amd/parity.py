@@ -19,7 +19,7 @@ Used by bench.py (after the timed region) and tests/test_model_gpu.py.  Host-sid
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -163,3 +163,87 @@ def detect_parity(objects_per_image, golden, thr_ulps: float = 4.0) -> Dict[str,
                 detail.append((i, k, g, ref[k].tolist()))
     return {"images": n_img, "objects_compared": compared, "objects_mismatched": mismatched, "margin_floor_ulps": thr_ulps,
             "ok": mismatched == 0 and compared > 0, "mismatches": detail[:4]}
+
+
+# ------------------------------------------------------------------ the fp8 mode's accuracy contract (round 5)
+#
+# e4m3 keeps 3 mantissa bits per operand: ~4 % relative noise per GEMM output whatever the scale, ~10 % after 27 + 24
+# residual blocks -- logits of 10..20 move by ~1 on average (profiles/r02_fp8_operand_numerics_study.txt).  That is 10x the
+# bf16 path's error and more than most top-1/top-2 margins of the synthetic checkpoint, so the fp8 mode is NOT held to
+# "ids equal the reference's".  It is held to a STATED tolerance on its teacher-forced logits against the reference's
+# recorded top-8 logits, and to agreement on the decisions whose reference margin exceeds a STATED licence:
+FP8_P99_LOGIT_ERR = 3.0      # |logit error| p99 over all recorded candidates (bf16 mode: 0.19)
+FP8_MEAN_LOGIT_ERR = 1.5     # mean (bf16 mode: ~0.05)
+FP8_LICENCE = 6.0            # = 2 x the p99 cap: a decision whose reference margin exceeds it must come out as the reference's
+FP8_REGION_LICENCE_ULPS = 96.0  # the same licence for the region heads' 1024-bin decisions, in bf16 ulps of the top logit
+                                # (6.0 at logits of 8..16, where one ulp is 0.0625)
+
+
+def fp8_contract_report(got_topk: np.ndarray, ref_topk: np.ndarray) -> Dict[str, object]:
+    """The fp8 mode teacher-forced on the reference's ids: logits at the reference's top-8 ids of every decision against
+    the reference's.  ``ok`` iff the error is inside the stated tolerance AND every decision whose reference margin exceeds
+    ``FP8_LICENCE`` picks the reference's token."""
+    st = logit_error_stats(got_topk, ref_topk)
+    got_a, ref_a = np.asarray(got_topk, dtype=np.float64), np.asarray(ref_topk, dtype=np.float64)
+    ref_f = np.where(np.isfinite(ref_a), ref_a, -np.inf)
+    srt = np.sort(ref_f, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    agree = np.argmax(np.where(np.isfinite(ref_a), got_a, -np.inf), axis=-1) == np.argmax(ref_f, axis=-1)
+    must = margin > FP8_LICENCE
+    viol = int((must & ~agree).sum())
+    tol_ok = st["p99"] <= FP8_P99_LOGIT_ERR and st["mean"] <= FP8_MEAN_LOGIT_ERR
+    bands = {}
+    for lo, hi in ((0.0, 0.5), (0.5, 1.0), (1.0, 2.0), (2.0, 4.0), (4.0, FP8_LICENCE), (FP8_LICENCE, np.inf)):
+        sel = (margin > lo) & (margin <= hi)
+        bands[f"margin ({lo:g}, {hi:g}]"] = {"decisions": int(sel.sum()), "agree": int((sel & agree).sum())}
+    return {
+        "contract": f"teacher-forced on the reference's ids, logits at the reference's top-8 ids: p99 |error| <= {FP8_P99_LOGIT_ERR}, mean <= "
+                    f"{FP8_MEAN_LOGIT_ERR}; every decision with a reference margin > {FP8_LICENCE} equals the reference's token",
+        "max_logit_err": st["max"], "p99_logit_err": st["p99"], "mean_logit_err": st["mean"], "max_logit_err_ulps": st["max_ulps"],
+        "p99_logit_err_ulps": st["p99_ulps"], "decisions": st["decisions"], "decisions_agree": int(agree.sum()),
+        "must_match": int(must.sum()), "must_match_violations": viol, "agreement_by_reference_margin": bands,
+        "tolerance_ok": bool(tol_ok), "ok": bool(tol_ok and viol == 0),
+    }
+
+
+def _object_bins(o) -> Tuple[float, float, float, float]:
+    """(x_min, y_min, x_max, y_max) -> the region heads' own units: centre bins (decode_coordinate: bin / 1024, region.py:47-62)
+    and size bins (decode_size: 2 ** (bin / 1023 * 10 - 10), region.py:79-93)."""
+    x0, y0, x1, y1 = (float(v) for v in o)
+    size_bin = lambda s: (np.log2(max(s, 2.0 ** -10)) + 10.0) * 102.3
+    return (x0 + x1) * 512.0, (y0 + y1) * 512.0, size_bin(x1 - x0), size_bin(y1 - y0)
+
+
+def detect_parity_fp8(objects_per_image, golden, licence_ulps: float = FP8_REGION_LICENCE_ULPS) -> Dict[str, object]:
+    """The fp8 mode's ``detect`` objects against the reference's (bf16) goldens, under the fp8 licence: objects whose every
+    decision has a reference margin >= ``licence_ulps`` must be equal; for ALL objects the centre / size differences are
+    reported in the region heads' own bins.  When no object of the fixture clears the licence (the region heads of the
+    synthetic checkpoint decide with margins of 0..85 ulps) the verdict is stated as what it is: throughput only."""
+    base = detect_parity(objects_per_image, golden, thr_ulps=licence_ulps)
+    d_centre, d_size, n_pairs, n_equal = [], [], 0, 0
+    for i in range(base["images"]):
+        ref = np.asarray(golden[f"img{i}.objects"]).reshape(-1, 4)
+        got = objects_per_image[i]
+        for k in range(min(len(ref), len(got))):
+            g = [got[k][f] for f in ("x_min", "y_min", "x_max", "y_max")]
+            gb, rb = _object_bins(g), _object_bins(ref[k].tolist())
+            d_centre += [abs(gb[0] - rb[0]), abs(gb[1] - rb[1])]
+            d_size += [abs(gb[2] - rb[2]), abs(gb[3] - rb[3])]
+            n_pairs += 1
+            n_equal += int(g == ref[k].tolist())
+    q = lambda v, p: (float(np.quantile(v, p)) if len(v) else None)
+    out = dict(base)
+    out.update({
+        "licence_ulps": licence_ulps, "objects_paired": n_pairs, "objects_equal": n_equal,
+        "centre_error_bins_median_p90_max": [q(d_centre, 0.5), q(d_centre, 0.9), q(d_centre, 1.0)],
+        "size_error_bins_median_p90_max": [q(d_size, 0.5), q(d_size, 0.9), q(d_size, 1.0)],
+    })
+    if base["objects_compared"] == 0:
+        out["ok"] = None
+        out["verdict"] = (f"THROUGHPUT ONLY, outputs unvalidated at the object level: no object of the fixture has every decision above the "
+                          f"fp8 licence ({licence_ulps:g} bf16 ulps; the reference's region-head margins here are 0..85 ulps), so equality "
+                          "with the bf16 reference is not a well-posed requirement for an e4m3 mode; the mode's accuracy contract is the "
+                          "teacher-forced logit tolerance of the fp8_full leg / tests/test_model_gpu.py")
+    else:
+        out["verdict"] = "objects above the fp8 licence equal the reference's" if base["ok"] else "MISMATCH above the fp8 licence"
+    return out

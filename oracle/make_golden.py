@@ -673,10 +673,23 @@ def gen_reftime(cfg_name="2b", seed=1, n_images=5, max_tokens=32):
         "encode_s": [round(x, 3) for x in t_enc], "generate_s": [round(x, 3) for x in t_gen],
         "note": "image 0 is the warm-up and is excluded from the medians",
     }
-    prof = os.path.join(REPO, "profiles", "r02_reference_cpu_timing_build_container.json")
+    # Round 5: the PORT (bench.py's cpu_baseline: the oracle in fast mode = the reference's own ATen calls in the reference's
+    # order) timed side by side, same process, same container, same weights -- the ratio bounds the drift between what the GPU
+    # box can time (the port: /root/reference does not exist there) and what SURVEY 8(d) asks for (the unmodified reference).
+    del model
+    import bench
+
+    est, cores, note, details = bench.cpu_baseline(cfg, sd, seed, max_tokens, budget_s=60.0)
+    timing["port"] = {"images_per_sec": est, "threads": cores, "sample": note, "details": details}
+    timing["port_vs_reference"] = est / timing["images_per_sec"]
+    timing["port_vs_reference_note"] = ("port images/s / reference images/s, both measured in this container back to back; > 1: the port is "
+                                        "faster (it skips Python-side glue: mask slicing, per-token .item(), the streaming detokeniser; it "
+                                        "reads K/V over all 2048 slots like the reference)")
+    prof = os.path.join(REPO, "profiles", "r05_reference_vs_port_cpu_timing_build_container.json")
     with open(prof, "w") as f:
         json.dump(timing, f, indent=1)
-    print(f"[reftime] {timing['images_per_sec']:.3f} images/s on {os.cpu_count()} cores -> {prof}", flush=True)
+    print(f"[reftime] reference {timing['images_per_sec']:.3f} images/s, port {est:.3f} images/s on {os.cpu_count()} cores "
+          f"(port / reference = {timing['port_vs_reference']:.3f}) -> {prof}", flush=True)
 
 
 def gen_reasoning(name="tiny_reasoning", cfg_name="tiny", seed=1, n_cases=2, max_tokens=8, min_margin=0.75):

@@ -106,3 +106,99 @@ def test_relaunch_is_a_noop_inside_a_rank_and_for_one_gpu(monkeypatch):
     assert mdist.relaunch_under_torchrun(1, "bench.py", []) is None
     monkeypatch.setenv("WORLD_SIZE", "2")
     assert mdist.relaunch_under_torchrun(2, "bench.py", []) is None
+
+
+# ------------------------------------------------------------------ DataParallelEngine (moondream_amd/parallel.py), stub model, gloo
+class _StubModel:
+    """Stands in for MoondreamModel: outputs are a function of (item, a broadcast weight) so that a wrong shard, a wrong
+    order or a missing weight broadcast changes them."""
+
+    def __init__(self, config, sd, device, **kw):
+        self.k = int(sd["k"].item())
+        self.kw = kw
+
+    def batch_generate_ids(self, images, prompts, max_tokens=4, ignore_eos=False):
+        return [[self.k + im + p[0] + t for t in range(1 + im % 3)][:max_tokens] for im, p in zip(images, prompts)]  # ragged
+
+    def batch_generate_ids_pipelined(self, batches, max_tokens=4, ignore_eos=False):
+        for images, prompts in batches:
+            yield [[self.k + im + t for t in range(max_tokens)] for im in images]
+
+    def batch_caption(self, images, length="normal", settings=None):
+        return [f"{length}:{self.k + im}" for im in images]
+
+    def batch_query(self, images, questions, settings=None):
+        return [f"{q}?{self.k + im}" for im, q in zip(images, questions)]
+
+    def batch_detect(self, images, objects, settings=None):
+        return [{"objects": [{"x_min": float(im), "o": o}] * (im % 2)} for im, o in zip(images, objects)]
+
+    def batch_point(self, images, objects, settings=None):
+        return [{"points": [{"x": float(im)}]} for im in images]
+
+
+def _engine_worker(rank, world, port, out_dir, weights_path):
+    from moondream_amd.config import get_config
+    from moondream_amd.parallel import DataParallelEngine
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    cfg = get_config("tiny")
+    # rank 0 alone reads the checkpoint FILE; the others learn names / shapes / dtypes and the bytes from the broadcast
+    eng = DataParallelEngine(cfg, weights_file=weights_path if rank == 0 else None, backend="gloo", device=torch.device("cpu"),
+                             model_factory=_StubModel, max_batch=4)
+    assert (eng.rank, eng.world) == (rank, world) and eng.model.k == 1000 and eng.model.kw == {"max_batch": 4}
+    assert eng.weights_report["bytes"] > 0
+    n = 7
+    images = list(range(n))                      # the GLOBAL list, identical on every rank
+    prompts = [[10 * i] for i in range(n)]
+    want_ids = [[1000 + i + 10 * i + t for t in range(1 + i % 3)] for i in range(n)]
+    got = eng.batch_generate_ids(images, prompts, max_tokens=4)
+    mine = list(eng.shard(n))
+    got_local = eng.batch_generate_ids([images[i] for i in mine], [prompts[i] for i in mine], max_tokens=4, local=True)
+    caps = eng.batch_caption(images, length="short")
+    ans = eng.batch_query(images, [f"q{i}" for i in range(n)])
+    det = eng.batch_detect(images, ["cat"] * n)
+    pts = eng.batch_point(images, ["cat"] * n)
+    steps = list(eng.batch_generate_ids_pipelined((([images[i] for i in mine], [prompts[i] for i in mine]) for _ in range(2)), n_total=n,
+                                                  max_tokens=3))
+    assert eng.ranks_seen() == world and eng.max_over_ranks(float(rank)) == float(world - 1)
+    with pytest.raises(ValueError):
+        eng.batch_generate_ids(images, prompts[:-1])
+    eng.barrier()
+    if rank == 0:
+        assert got == want_ids and got_local == want_ids, (got, got_local)
+        assert caps == [f"short:{1000 + i}" for i in range(n)]
+        assert ans == [f"q{i}?{1000 + i}" for i in range(n)]
+        assert det == [{"objects": [{"x_min": float(i), "o": "cat"}] * (i % 2)} for i in range(n)]
+        assert pts == [{"points": [{"x": float(i)}]} for i in range(n)]
+        for blocks in steps:
+            assert torch.cat(blocks, 0).tolist() == [[1000 + i + t for t in range(3)] for i in range(n)]
+        open(os.path.join(out_dir, "engine_ok"), "w").write("1")
+    else:
+        assert got is None and got_local is None and caps is None and det is None and steps == [None, None]
+    eng.close()
+
+
+def test_data_parallel_engine_world_2_gloo(tmp_path):
+    """The product-level DP runner: rank 0 loads the checkpoint file, flat broadcast, per-rank lockstep engine over
+    shard_range blocks, id gather / object gather on rank 0 -- with a stub model, over gloo, world_size 2."""
+    weights_path = str(tmp_path / "stub.pt")
+    torch.save({"k": torch.tensor([1000], dtype=torch.int32), "w": torch.arange(6, dtype=torch.float32).to(torch.bfloat16)}, weights_path)
+    port = _free_port()
+    mp.spawn(_engine_worker, args=(2, port, str(tmp_path), weights_path), nprocs=2, join=True)
+    assert (tmp_path / "engine_ok").exists()
+
+
+def test_data_parallel_engine_single_process_needs_no_process_group(monkeypatch):
+    from moondream_amd.config import get_config
+    from moondream_amd.parallel import DataParallelEngine
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    eng = DataParallelEngine(get_config("tiny"), state_dict={"k": torch.tensor([5], dtype=torch.int32)}, device=torch.device("cpu"),
+                             model_factory=_StubModel)
+    assert eng.world == 1 and not dist.is_initialized()
+    assert eng.batch_generate_ids([0, 1, 2], [[0], [0], [0]], max_tokens=2) == [[5], [6, 7], [7, 8]]
+    assert eng.batch_caption([3]) == ["normal:8"]
+    with pytest.raises(ValueError):
+        DataParallelEngine(get_config("tiny"), device=torch.device("cpu"), model_factory=_StubModel)

@@ -357,7 +357,9 @@ def test_seam_honours_the_mask_the_reference_passes(tiny, golden_dir):
     for i in range(int(g["n_cases"])):
         want = g[f"q{i}.tokens"].tolist()
         ref_logits = bits_to_bf16(g[f"q{i}.step_logits"]).float()
-        prompt = [tok.bos_id] + list(tok.templates["query"]["prefix"]) + g[f"q{i}.question"].tolist() + list(tok.templates["query"]["suffix"])
+        # moondream.py:564-575 (BOS + prefix), 586-591 (+ question + suffix), 604 (+ suffix again when not reasoning)
+        prompt = ([tok.bos_id] + list(tok.templates["query"]["prefix"]) + g[f"q{i}.question"].tolist()
+                  + list(tok.templates["query"]["suffix"]) + list(tok.templates["query"]["suffix"]))
         n = len(prompt)
         emb = model._embed(torch.tensor([prompt]))
         pos_ids = torch.arange(0, n, dtype=torch.long)
@@ -397,6 +399,33 @@ def test_seam_honours_the_mask_the_reference_passes(tiny, golden_dir):
         model._prefill(x[:, :4], bad, torch.arange(4, dtype=torch.long), None)
     with pytest.raises(ValueError):
         model._prefill(x[:, :4], None, torch.tensor([0, 1, 3, 4]), None)
+
+
+def vqa64_vs_reference(model, cfg, sd, imgs64, golden_dir):
+    """BASELINE configs[1] / the north star's "32-token prompts" AT BENCH SCALE: the 64 seed-1 images with the 32-id question
+    prompts bench.py's vqa32 leg times, B = 64, 32 greedy tokens, against the unmodified reference's ids for exactly these
+    (image, prompt) pairs (tests/golden/md2b_vqa64.npz: _generate_answer, the loop behind query(), moondream.py:541-618) --
+    the same measured licence, per-decision teacher-forced check and second-oracle floor as the caption configuration."""
+    import bench
+    from moondream_amd import parity as P
+
+    gv = load_golden(golden_dir, "md2b_vqa64.npz")
+    prompts = gv["prompt"].tolist()
+    assert prompts == [synth.synthetic_vqa_prompt(cfg, i, int(gv["seed"])) for i in range(64)] and len(prompts[0]) == 32
+    got = model.batch_generate_ids(imgs64, prompts, max_tokens=32, ignore_eos=True)
+    topk = model.teacher_forced_logits(imgs64, prompts, gv["tokens"], gv["top8_idx"]).numpy()
+    second = bench.second_oracle(cfg, sd, int(gv["seed"]), 32, "cuda", fixture="md2b_vqa64")
+    floor = bench.exact_floor(64, 32, second)
+    rep = P.parity_report(got, gv["tokens"].tolist(), gv["margins"], topk, gv["top8_val"], tokens=32, min_exact=floor, ref_topk_idx=gv["top8_idx"])
+    print(f"vqa64 parity (32-id prompts, B=64): {rep['parity_exact']}/64 identical (second oracle {second['exact']}/64 -> floor {floor}); max "
+          f"|logit err| {rep['parity_max_logit_err']:.4f} (p99 {rep['parity_p99_logit_err_ulps']:.1f} ulps) -> threshold {rep['parity_threshold']:.4f}; "
+          f"teacher-forced: {rep['parity_tf_decisions_must_match']} must-match decisions, {rep['parity_tf_decisions_violations']} violations")
+    assert second["max_logit_err"] <= 0.5
+    assert rep["parity_ok"], rep["parity_note"]
+    assert rep["parity_tf_decisions_must_match"] >= 1800 and rep["parity_tf_decisions_violations"] == 0
+    # the sequences whose every margin clears the licence are identical outright
+    wide = [i for i in range(64) if float(gv["margins"][i].min()) > rep["parity_threshold"]]
+    assert wide and all(got[i] == gv["tokens"][i].tolist() for i in wide), wide
 
 
 def test_multicrop_images_vs_reference(golden_dir):
@@ -1154,6 +1183,7 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
         assert rep["parity_tf_decisions_must_match"] >= 1800 and rep["parity_tf_decisions_violations"] == 0
         for i in g["image_index"].tolist():  # the wide-margin images of md2b_seed1 are among the 64: exact
             assert got64[i] == gb["tokens"][i].tolist(), i
+    vqa64_vs_reference(model, cfg, sd, imgs64, golden_dir)
     batch_equals_sequential_unfiltered(model, imgs64, pr, got64, ref_ids, gb["margins"], rep["parity_threshold"])
     mutation_sensitivity(model, cfg, g, images, imgs64, pr, gb)
     detect13_vs_reference(model, golden_dir)

@@ -260,3 +260,59 @@ def test_seam_mask_classifier_on_the_reference_models_own_buffers():
     assert ("prefill", MASK_EITHER) == kinds[1]             # caption prompt at pos 730
     assert ("prefill", MASK_CAUSAL) in kinds                # the text-only query's prompt at pos 0
     assert ("decode", MASK_CAUSAL) in kinds and ("decode", MASK_EITHER) in kinds
+
+
+def test_vqa64_fixture_is_the_bench_legs_configuration():
+    """tests/golden/md2b_vqa64.npz (oracle/make_golden.py vqa64, from the unmodified reference): the 64 seed-1 images x the 32-id
+    question prompts bench.py's vqa32 leg runs; internally consistent (ids = argmax of the recorded candidates wherever the
+    margin is positive) and statistically like the caption fixture (so the same gates apply)."""
+    from moondream_amd import synth
+    from moondream_amd.config import get_config
+
+    g = np.load(os.path.join(GOLD, "md2b_vqa64.npz"))
+    cfg = get_config("2b")
+    assert int(g["seed"]) == 1 and str(g["cfg"]) == "2b"
+    assert g["prompt"].shape == (64, 32) and g["tokens"].shape == (64, 32) and g["margins"].shape == (64, 33)
+    assert g["top8_idx"].shape == (64, 33, 8) and g["top8_val"].shape == (64, 33, 8)
+    assert g["prompt"].tolist() == [synth.synthetic_vqa_prompt(cfg, i, 1) for i in range(64)]
+    tpl = cfg.tokenizer.templates["query"]
+    assert g["prompt"][0, : len(tpl["prefix"])].tolist() == list(tpl["prefix"])
+    top = g["top8_val"]
+    assert np.allclose(top[..., 0] - top[..., 1], g["margins"], atol=1e-6)
+    pos = g["margins"][:, :32] > 0
+    assert (g["top8_idx"][:, :32, 0][pos] == g["tokens"][pos]).all()
+    assert (g["margins"] > 0.5).sum() >= 1800   # the must-match decisions the per-decision gate rests on
+    # the per-decision report accepts the reference against itself and rejects a swapped pair of candidates
+    rep = P.parity_report(g["tokens"].tolist(), g["tokens"].tolist(), g["margins"], g["top8_val"], g["top8_val"], tokens=32,
+                          min_exact=64, ref_topk_idx=g["top8_idx"])
+    assert rep["parity_ok"] and rep["parity_exact"] == 64
+    bad = g["top8_val"].copy()
+    i, j = np.argwhere(g["margins"][:, :32] > 2.0)[0]
+    bad[i, j, [0, 1]] = bad[i, j, [1, 0]]
+    rep = P.parity_report(g["tokens"].tolist(), g["tokens"].tolist(), g["margins"], bad, g["top8_val"], tokens=32, ref_topk_idx=g["top8_idx"])
+    assert not rep["parity_ok"]
+
+
+def test_fp8_contract_and_fp8_detect_parity_helpers():
+    g = np.load(os.path.join(GOLD, "md2b_bench64.npz"))
+    ref = g["top8_val"]
+    ok = P.fp8_contract_report(ref + np.random.default_rng(0).normal(0, 0.8, ref.shape), ref)
+    assert ok["tolerance_ok"] and ok["ok"] and ok["must_match"] > 100 and ok["must_match_violations"] == 0
+    loud = P.fp8_contract_report(ref + np.random.default_rng(0).normal(0, 3.0, ref.shape), ref)
+    assert not loud["tolerance_ok"] and not loud["ok"]
+    swapped = ref.copy()
+    i, j = np.argwhere((ref[..., 0] - ref[..., 1]) > P.FP8_LICENCE)[0]
+    swapped[i, j, [0, 1]] = swapped[i, j, [1, 0]]
+    assert P.fp8_contract_report(swapped, ref)["must_match_violations"] == 1
+    gd = np.load(os.path.join(GOLD, "md2b_detect13.npz"))
+    objs = [[dict(zip(("x_min", "y_min", "x_max", "y_max"), o)) for o in np.asarray(gd[f"img{i}.objects"]).reshape(-1, 4).tolist()]
+            for i in range(int(gd["n_images"]))]
+    r = P.detect_parity_fp8(objs, gd)
+    assert r["ok"] is None and "THROUGHPUT ONLY" in r["verdict"] and r["objects_equal"] == r["objects_paired"] == 32
+    assert r["centre_error_bins_median_p90_max"] == [0.0, 0.0, 0.0]
+    objs[0][0]["y_min"] += 0.01   # 0.01 of the image height: the centre moves by 0.005 x 1024 bins
+    r = P.detect_parity_fp8(objs, gd)
+    assert r["objects_equal"] == 31 and abs(r["centre_error_bins_median_p90_max"][2] - 5.12) < 1e-6
+    # with a licence the fixture can clear, equality is enforced
+    r4 = P.detect_parity_fp8(objs, gd, licence_ulps=1.0)
+    assert r4["objects_compared"] > 0 and r4["ok"] is False

@@ -68,6 +68,7 @@ struct Knobs {
     if (const char* dc = getenv("MD_DECODE_CFG")) {
       if (dc[0] == 'd') decode_cfg = 3;
       else if (dc[0] == '6') decode_cfg = 10;
+      else if (dc[0] == '1' && dc[1] >= '6' && dc[1] <= '9') decode_cfg = 10 + (dc[1] - '0');  // "16" .. "19"
     }
   }
 };
@@ -125,16 +126,21 @@ template <int BM, int BN, int WM, int WN, int EPI, bool SPLITK, int STAGES, int 
 __device__ __forceinline__ void gemm_body(const GemmK& p) {
   constexpr int ROW_BYTES = BKT * 2;
   constexpr int CH = BKT / 8;                 // 16-byte chunks per row
-  constexpr int CH_SHIFT = (CH == 8) ? 3 : 2;
+  constexpr int CH_SHIFT = (CH == 16) ? 4 : (CH == 8) ? 3 : 2;
   constexpr int KSTEPS = BKT / 16;            // MFMA K-steps per slice
-  static_assert(BKT == 64 || BKT == 32, "slice width");
+  // BKT = 128 (round 5, decode regime): 256-byte rows, 16 chunks XOR-swizzled by row & 15 -- a 16-lane group of a ds_read_b128
+  // touches 16 distinct chunks = every bank once.  Twice the K per ring iteration: the iteration's fixed latencies (counted
+  // vmcnt, barrier, the first fragments' LDS latency: ~300 of ~750 cycles at 64) are paid half as often.
+  static_assert(BKT == 128 || BKT == 64 || BKT == 32, "slice width");
   constexpr int CT = WM * WN * 64;       // threads that compute
   constexpr int NT = XW > 0 ? XW * 64 : CT;  // threads that move data: the helper waves when there are any (round 3: the compute
                                              // waves' share of the LDS-DMA issue, ~40 cycles per K-step, sat on their MFMA chain while the
                                              // helpers idled ~400 cycles per slice at the barrier), else every wave
   static_assert(XW == 0 || PP == 0, "helper waves: lockstep schedule only");
   constexpr int TM = BM / WM, TN = BN / WN;
-  static_assert(TN == 64, "epilogue transposes 32 x 64 wave tiles");
+  static_assert(TN == 64 || TN == 32, "epilogue transposes 32 x 64 (or 32 x 32) wave tiles");
+  constexpr int CPRW = TN / 8;               // 16-byte pieces per row of a wave tile
+  constexpr int NQ = 32 * CPRW / 64;         // pieces per lane of a 32-row wave tile
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES;
@@ -520,8 +526,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+      for (int q = 0; q < NQ; ++q) {
+        const int idx = q * 64 + lane, row = idx / CPRW, ch = idx % CPRW;
         const int m = m0c + wm * TM + 32 * i + row;
         const int n = wn0 + ch * 8;
         rres[i][q] = u32x4{0, 0, 0, 0};
@@ -564,16 +570,16 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
     if constexpr (PERSIST) {
       // same-wave LDS operations execute in order: the reads see the writes above
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+      for (int q = 0; q < NQ; ++q) {
+        const int idx = q * 64 + lane, row = idx / CPRW, ch = idx % CPRW;
         ds_read_b128_u32(tv[q], tile_lds + row * 128 + ((ch ^ (row & 7)) * 16));
       }
       wait_lgkm<0>();
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = q * 64 + lane, row = idx >> 3, ch = idx & 7;
+    for (int q = 0; q < NQ; ++q) {
+      const int idx = q * 64 + lane, row = idx / CPRW, ch = idx % CPRW;
       u32x4 v;
       if constexpr (PERSIST)
         v = tv[q];
@@ -665,6 +671,24 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
     // decode regime, 64x64 tiles + two DMA-only helper waves (4 waves issue the stream)
     case 16: return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4, 64, 0, 2>(k, stream)
                                  : launch_cfg<64, 64, 2, 1, EPI, false, 4, 64, 0, 2>(k, stream);
+    // round 5: FOUR compute waves (2 x 2 wave tiles of 32 x 32: one MFMA and two fragment reads per wave and K step instead of two and
+    // three on two of the four SIMDs) + the two DMA-only helpers, and 128-wide K slices where the layer allows it (K and every
+    // K-slice range a multiple of 128).  Same K order per output element as 16 / 10: bit-identical results.
+    case 17:
+      if (k.K % 128 == 0 && (k.slices <= 1 || (k.K / 64) % (2 * k.slices) == 0))
+        return k.slices > 1 ? launch_cfg<64, 64, 2, 2, EPI, true, 4, 128, 0, 2>(k, stream)
+                            : launch_cfg<64, 64, 2, 2, EPI, false, 4, 128, 0, 2>(k, stream);
+      return k.slices > 1 ? launch_cfg<64, 64, 2, 2, EPI, true, 4, 64, 0, 2>(k, stream)
+                          : launch_cfg<64, 64, 2, 2, EPI, false, 4, 64, 0, 2>(k, stream);
+    // the two ingredients of 17 on their own (A/B): 18 = four compute waves, 64-wide slices; 19 = two compute waves, 128-wide slices
+    case 18: return k.slices > 1 ? launch_cfg<64, 64, 2, 2, EPI, true, 4, 64, 0, 2>(k, stream)
+                                 : launch_cfg<64, 64, 2, 2, EPI, false, 4, 64, 0, 2>(k, stream);
+    case 19:
+      if (k.K % 128 == 0 && (k.slices <= 1 || (k.K / 64) % (2 * k.slices) == 0))
+        return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4, 128, 0, 2>(k, stream)
+                            : launch_cfg<64, 64, 2, 1, EPI, false, 4, 128, 0, 2>(k, stream);
+      return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4, 64, 0, 2>(k, stream)
+                          : launch_cfg<64, 64, 2, 1, EPI, false, 4, 64, 0, 2>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }
@@ -677,9 +701,9 @@ constexpr size_t TICKET_BYTES = 8192;
 
 // decode-regime config: 16 = 64x64 tiles + helper waves (default), 10 = 64x64 without helpers, 3 = 64x128 / 4-deep ring
 int decode_cfg() { return knobs().decode_cfg; }
-bool decode_is64(int cfg) { return cfg == 10 || cfg == 16; }
+bool decode_is64(int cfg) { return cfg == 10 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19; }
 int decode_bn() { return decode_is64(decode_cfg()) ? 64 : 128; }
-int decode_slab_floats() { return decode_is64(decode_cfg()) ? 128 * 1 * 2 * 16 : 128 * 2 * 2 * 16; }  // NT * MI * NI * 16
+int decode_slab_floats() { return decode_is64(decode_cfg()) ? 64 * 64 : 128 * 2 * 2 * 16; }  // CT * MI * NI * 16 = the tile's outputs
 
 int decode_slices(int n_store, int k_pad) {
   const int DEC_BN = decode_bn();
@@ -920,8 +944,10 @@ extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_li
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof;
   if (prof.begin(2.0 * (double)lin->n * (double)lin->k, s) != MD_OK) return MD_ERR_LAUNCH;
-  const md_status st = decode_cfg() == 16 ? launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
-                                          : launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
+  const int cfg = decode_cfg();
+  const md_status st = (cfg == 17 || cfg == 18) ? launch_cfg<64, 64, 2, 2, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
+                       : (cfg == 16 || cfg == 19) ? launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
+                                                  : launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
   prof.end();
   return st;
 }
@@ -938,10 +964,13 @@ extern "C" md_status md_gemm_partial_f32_pair(const void* a0, int64_t lda0, cons
   if (chk != MD_OK) return chk;
   hipStream_t s = (hipStream_t)stream;
   constexpr int lds = 4 * (64 + 64) * 64 * 2;
-  const bool helpers = decode_cfg() == 16;
-  const int NT = helpers ? 256 : 128;
-  auto fn = helpers ? gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
-                    : gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;
+  // (64-wide slices here whatever the config: 64 KiB of ring = TWO workgroups per CU, and the pair makes 512)
+  const int cfg = decode_cfg();
+  const bool four = cfg == 17 || cfg == 18, helpers = four || cfg == 16 || cfg == 19;
+  const int NT = four ? 384 : helpers ? 256 : 128;
+  auto fn = four ? gemm_pair_kernel<64, 64, 2, 2, MD_EPI_BIAS, true, 4, 64, 0, 2>
+            : helpers ? gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
+                      : gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;
   MD_TRY(md_ensure_dynamic_lds((const void*)fn, lds));
   ProfScope prof;
   if (prof.begin(2.0 * ((double)lin0->n * lin0->k + (double)lin1->n * lin1->k), s) != MD_OK) return MD_ERR_LAUNCH;

@@ -119,6 +119,78 @@ def test_gemm_tile_configs_agree_bitwise(lib, force_tile):
         assert torch.equal(gemm(lib, a, lin), first), f"tile 20 rep {rep}"
 
 
+@pytest.mark.parametrize("m", [64, 33, 1])
+def test_decode_regime_configs_agree_bitwise(lib, m):
+    """Decode regime (m <= 64): every 64 x 64 config -- 16 (two compute waves + two DMA-only helpers), 17 (round 5: FOUR compute
+    waves as 2 x 2 wave tiles of 32 x 32, 128-wide K slices where the layer allows), 18 / 19 (the two ingredients on their own),
+    10 (no helpers) -- sums K in the same order per output element, in-launch split-K slices and launch-boundary partial slices
+    included: bit-identical outputs for every epilogue, ragged N, K not a multiple of 128, and both partial entry points.
+    Repeated launches double as a race screen for the new ring shapes."""
+    def set_cfg(c):
+        _lib.check(lib.md_gemm_set_tuning(b"decode_cfg", c))
+    try:
+        for (k, n, epi, gelu_from) in [(2048, 6144 + 8192, 1, 6144), (2048, 2048, 2, 0), (8192, 2048, 0, 0), (2048, 51200, 0, 0),
+                                       (704, 256, 0, 0), (1152, 1000, 1, 0), (256, 1024, 2, 0), (4352, 1152, 0, 0)]:
+            a, w, b = randn(m, k, seed=31), randn(n, k, scale=1 / math.sqrt(k), seed=32), randn(n, scale=0.1, seed=33)
+            lin = PackedLinear(w, b, "cuda")
+            ap = pad_k(a, lin.k_pad)
+            r = randn(m, n, seed=34) if epi == 2 else None
+
+            def run():
+                c = torch.full((m, lin.n), float("nan"), dtype=BF16, device="cuda")
+                st = lin.struct()
+                need = lib.md_gemm_workspace_bytes(C.byref(st), m, 0)
+                ws = torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")
+                args = _lib.MdGemmArgs(ap.data_ptr(), ap.stride(0), st, c.data_ptr(), c.stride(0), r.data_ptr() if r is not None else None,
+                                       r.stride(0) if r is not None else 0, 0, m, epi, 0, gelu_from, ws.data_ptr(), need)
+                _lib.check(lib.md_gemm_bf16(C.byref(args), stream()), "gemm")
+                torch.cuda.synchronize()
+                return c
+            set_cfg(16)
+            want = run()
+            ref = ref_linear(a, w, b).float()
+            if epi == 1:
+                ref[:, gelu_from:] = torch.nn.functional.gelu(ref[:, gelu_from:], approximate="tanh")
+            if epi == 2:
+                ref = ref + r.float()
+            compare(f"decode cfg 16 k={k} n={n} epi={epi}", want, ref.to(BF16), 4e-3, 6e-2)
+            for cfg in (17, 18, 19, 10):
+                set_cfg(cfg)
+                for rep in range(3):
+                    assert torch.equal(run(), want), f"cfg {cfg} k={k} n={n} epi={epi} rep {rep}"
+        # launch-boundary partial slices: single and paired entry points
+        D, FF = 2048, 8192
+        a1, a2 = randn(m, D, seed=41), randn(m, FF, seed=42)
+        W1, B1 = randn(D, D, scale=1 / math.sqrt(D), seed=43), randn(D, scale=0.1, seed=44)
+        l1_bias = lambda _l: B1.float()
+        l1 = PackedLinear(W1, B1, "cuda")
+        l2 = PackedLinear(randn(D, FF, scale=1 / math.sqrt(FF), seed=45), randn(D, scale=0.1, seed=46), "cuda")
+        s1, s2 = l1.struct(), l2.struct()
+        n1, n2 = lib.md_gemm_partial_slices(C.byref(s1)), lib.md_gemm_partial_slices(C.byref(s2))
+
+        def partials(pair):
+            p1 = torch.full((n1, m, D), float("nan"), dtype=torch.float32, device="cuda")
+            p2 = torch.full((n2, m, D), float("nan"), dtype=torch.float32, device="cuda")
+            if pair:
+                _lib.check(lib.md_gemm_partial_f32_pair(a1.data_ptr(), a1.stride(0), C.byref(s1), p1.data_ptr(), a2.data_ptr(), a2.stride(0),
+                                                        C.byref(s2), p2.data_ptr(), m, D, m * D, stream()))
+            else:
+                _lib.check(lib.md_gemm_partial_f32(a1.data_ptr(), a1.stride(0), C.byref(s1), m, p1.data_ptr(), D, m * D, stream()))
+                _lib.check(lib.md_gemm_partial_f32(a2.data_ptr(), a2.stride(0), C.byref(s2), m, p2.data_ptr(), D, m * D, stream()))
+            torch.cuda.synchronize()
+            return p1, p2
+        set_cfg(16)
+        w1, w2 = partials(True)
+        compare("partial slices sum (proj)", (w1.sum(0) + l1_bias(l1)).to(BF16), ref_linear(a1, W1, B1), 4e-3, 6e-2)
+        for cfg in (16, 17, 18, 19, 10):
+            set_cfg(cfg)
+            for pair in (True, False):
+                g1, g2 = partials(pair)
+                assert torch.equal(g1, w1) and torch.equal(g2, w2), f"partials cfg {cfg} pair {pair}"
+    finally:
+        lib.md_gemm_set_tuning(b"decode_cfg", 16)
+
+
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("m,k,n", [(46720 // 8, 2048, 2048), (2 * 729 * 4 + 77, 1152, 4304), (3000, 4352, 1152), (257, 64, 8), (5000, 640, 1152)])
 def test_gemm_w4_persistent_stream(lib, force_tile, m, k, n, epi):

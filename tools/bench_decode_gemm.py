@@ -25,7 +25,7 @@ def run_b(st):
         s1, s2 = p1.struct(), p2.struct()
         _lib.check(lib.md_gemm_partial_f32_pair(act.data_ptr(), act.stride(0), C.byref(s1), pa.data_ptr(), act.data_ptr() + 3 * D * 2, act.stride(0),
                                                 C.byref(s2), pb.data_ptr(), m, D, m * D, C.c_void_p(st)))
-for name, fn in (("fused qkv|fc1 (58.7 MB)", run_a), ("proj + fc2 partial pair (41.9 MB)", run_b)):
+def timed(fn):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s): fn(s.cuda_stream)
     torch.cuda.synchronize()
@@ -39,4 +39,10 @@ for name, fn in (("fused qkv|fc1 (58.7 MB)", run_a), ("proj + fc2 partial pair (
         for _ in range(4): g.replay()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / (4 * L) * 1e3)
-    print(f"{os.path.basename(os.environ.get('MD_HIP_LIB', 'in-tree'))}: {name:36s} {best:6.1f} us per launch", flush=True)
+    return best
+cfgs = [int(c) for c in sys.argv[1:]] or [None]   # decode_cfg values to compare in ONE process (md_gemm_set_tuning), interleaved twice
+for rep in range(2 if len(cfgs) > 1 else 1):
+    for c in cfgs:
+        if c is not None: _lib.check(lib.md_gemm_set_tuning(b"decode_cfg", c))
+        for name, fn in (("fused qkv|fc1 (58.7 MB)", run_a), ("proj + fc2 partial pair (41.9 MB)", run_b)):
+            print(f"{os.path.basename(os.environ.get('MD_HIP_LIB', 'in-tree'))} decode_cfg={c}: {name:36s} {timed(fn):6.1f} us per launch", flush=True)

@@ -737,16 +737,16 @@ def main():
     # on itself: the algorithmic bytes beside it are live (this run's launches), the counter figure is the
     # committed pass of the same command.
     traffic = {"algorithmic_read_bytes_per_step": alg_rd.value, "algorithmic_written_bytes_per_step": alg_wr.value,
-               "measured": None, "note": "no profiles/r04_pmc_traffic.json"}
+               "measured": None, "note": "no profiles/r05_pmc_traffic.json"}
     try:
-        with open(os.path.join(REPO, "profiles", "r04_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r05_pmc_traffic.json")) as f:
             tg = json.load(f)["tile_gemm"]
         rd, wr = 2.0 * tg["FETCH_SIZE_kb_sum"] * 1024.0, tg["WRITE_SIZE_kb_sum"] * 1024.0
         traffic.update({
             "measured": {"read_bytes_per_step": rd, "written_bytes_per_step": wr, "launches": tg["launches"]},
             "read_ratio": rd / alg_rd.value if alg_rd.value else None,
             "write_ratio": wr / alg_wr.value if alg_wr.value else None,
-            "note": "profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager B=64 step "
+            "note": "profiles/r05_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager B=64 step "
                     "(2 x FETCH_SIZE per the gfx950 note; L2-miss side, Infinity-Cache hits included)",
         })
     except (OSError, KeyError, ValueError, ZeroDivisionError):

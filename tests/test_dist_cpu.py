@@ -162,6 +162,11 @@ def _engine_worker(rank, world, port, out_dir, weights_path):
     steps = list(eng.batch_generate_ids_pipelined((([images[i] for i in mine], [prompts[i] for i in mine]) for _ in range(2)), n_total=n,
                                                   max_tokens=3))
     assert eng.ranks_seen() == world and eng.max_over_ranks(float(rank)) == float(world - 1)
+    # fewer items than ranks: the last rank's shard is empty and still takes part in every collective
+    one = eng.batch_generate_ids(images[:1], prompts[:1], max_tokens=4)
+    one_det = eng.batch_detect(images[:1], ["cat"])
+    none_at_all = eng.batch_caption([])
+    assert (one, one_det, none_at_all) == (([want_ids[0]], [{"objects": []}], []) if rank == 0 else (None, None, None))
     with pytest.raises(ValueError):
         eng.batch_generate_ids(images, prompts[:-1])
     eng.barrier()

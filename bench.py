@@ -555,15 +555,18 @@ def detect_job(engine, cfg, args, fp8):
         calib = model.enable_fp8(imgs[:2])
     n_crops = int(model._crop(imgs[0])[0].shape[0])
 
-    def steps(k):
-        batches = (([im.copy() for im in imgs], [obj] * len(imgs)) for _ in range(k))   # distinct objects per step
-        return list(engine.batch_detect_pipelined(batches, settings=st))
+    def make_batches(k):  # distinct image objects per step (a prefetched batch is keyed by identity), made OUTSIDE the timed region
+        return [([im.copy() for im in imgs], [obj] * len(imgs)) for _ in range(k)]
 
-    steps(max(2, args.warmup))
+    def steps(batches):
+        return list(engine.batch_detect_pipelined(iter(batches), settings=st))
+
+    steps(make_batches(max(2, args.warmup)))
+    timed_batches = make_batches(args.steps)
     engine.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = steps(args.steps)
+    outs = steps(timed_batches)
     torch.cuda.synchronize()
     engine.barrier()
     elapsed = time.perf_counter() - t0

@@ -641,7 +641,6 @@ def main():
     lib = model.lib
     if args.leg != "caption":
         detect_job(engine, cfg, args, fp8=args.leg == "detect13_fp8")
-        engine.close()
         return
     if not args.no_graphs:
         model.compile()  # hipGraph replay of the device-resident decode steps

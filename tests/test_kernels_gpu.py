@@ -48,7 +48,7 @@ def randn(*shape, scale=1.0, seed=0):
 _SPLITK_WS = {}  # zeroed once; every launch leaves the ticket area zero again
 
 
-def gemm(lib, a, lin, epi=0, r=None, res_row_mod=0, store_pad=0, out=None, use_ws=True):
+def gemm(lib, a, lin, epi=0, r=None, res_row_mod=0, store_pad=0, out=None, use_ws=True, tile_policy=0):
     m = a.shape[0]
     width = lin.n_pad if store_pad else lin.n
     c = out if out is not None else torch.full((m, width), float("nan"), dtype=BF16, device="cuda")
@@ -58,7 +58,7 @@ def gemm(lib, a, lin, epi=0, r=None, res_row_mod=0, store_pad=0, out=None, use_w
     args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, c.data_ptr(), c.stride(0),
                            r.data_ptr() if r is not None else None, r.stride(0) if r is not None else 0,
                            res_row_mod, m, epi, store_pad, 0, ws.data_ptr() if ws is not None else None,
-                           need if ws is not None else 0)
+                           need if ws is not None else 0, tile_policy)
     _lib.check(lib.md_gemm_bf16(C.byref(args), stream()), "gemm")
     torch.cuda.synchronize()
     return c
@@ -117,6 +117,42 @@ def test_gemm_tile_configs_agree_bitwise(lib, force_tile):
     assert (first != want).float().mean().item() < 0.02  # a last-bit difference is rare
     for rep in range(6):
         assert torch.equal(gemm(lib, a, lin), first), f"tile 20 rep {rep}"
+
+
+def test_tile_policy_is_a_per_call_field(lib, force_tile):
+    """ABI 5: md_gemm_args.tile_policy.  MD_TILE_PINNED makes the tile config of a > 64-row launch a function of the layer alone --
+    the 256 x 256 kernel whatever the row count -- so a row gets the same bits in a 100-row and in a 5000-row launch; MD_TILE_BY_SHAPE
+    lets small launches take the small-shape configs (another MFMA shape: equal to fp32 rounding, not bitwise).  The policy travels
+    with the call: two interleaved callers with different policies do not affect each other, the "w4" A/B knob is honoured under the
+    pin (advisor, round 4), launches of <= 64 rows ignore it, and an unknown value is refused."""
+    k, n = 2048, 2048
+    w, b = randn(n, k, scale=1 / math.sqrt(k), seed=52), randn(n, scale=0.1, seed=53)
+    lin = PackedLinear(w, b, "cuda")
+    big = randn(5000, k, seed=51)
+    small = big[:100].contiguous()
+    pinned_big = gemm(lib, big, lin, tile_policy=_lib.MD_TILE_PINNED)
+    force_tile(20)
+    assert torch.equal(gemm(lib, big, lin), pinned_big)           # the pin IS the four-wave kernel
+    force_tile(-1)
+    for rep in range(3):  # interleaved callers
+        p_small = gemm(lib, small, lin, tile_policy=_lib.MD_TILE_PINNED)
+        s_small = gemm(lib, small, lin, tile_policy=_lib.MD_TILE_BY_SHAPE)
+        assert torch.equal(p_small, pinned_big[:100])             # same bits alone and in the big launch
+        compare("by-shape vs pinned", s_small, p_small, 3e-4, 2e-2)
+    _lib.check(lib.md_gemm_set_tuning(b"w4", 0))
+    try:
+        eight = gemm(lib, small, lin, tile_policy=_lib.MD_TILE_PINNED)
+        force_tile(11)
+        assert torch.equal(gemm(lib, small, lin), eight)          # pinned + w4 = 0 -> the eight-wave 256 x 256 baseline
+    finally:
+        force_tile(-1)
+        _lib.check(lib.md_gemm_set_tuning(b"w4", 1))
+    rows = randn(48, k, seed=54)
+    assert torch.equal(gemm(lib, rows, lin, tile_policy=_lib.MD_TILE_PINNED), gemm(lib, rows, lin, tile_policy=_lib.MD_TILE_BY_SHAPE))
+    st = lin.struct()
+    c = torch.empty(100, n, dtype=BF16, device="cuda")
+    bad = _lib.MdGemmArgs(small.data_ptr(), small.stride(0), st, c.data_ptr(), c.stride(0), None, 0, 0, 100, 0, 0, 0, None, 0, 7)
+    assert lib.md_gemm_bf16(C.byref(bad), stream()) == 1  # MD_ERR_INVALID_ARG
 
 
 @pytest.mark.parametrize("m", [64, 33, 1])

@@ -17,6 +17,12 @@ runs = []
 for i in idx:
     if runs and i - runs[-1][-1] <= 3: runs[-1].append(i)
     else: runs.append([i])
+# (a 32-token caption decodes in chunks of 16 launches: merge runs that are separated by fewer than 20 other kernels)
+caps = []
+for r in runs:
+    if caps and r[0] - caps[-1][-1] < 20: caps[-1].extend(r)
+    else: caps.append(list(r))
+runs = caps
 a, b = runs[-2][-1] + 1, runs[-1][0]
 enc = rows[a:b]
 dur = collections.defaultdict(list)

@@ -90,7 +90,7 @@ def selftest_dist(args):
     eng = DataParallelEngine(tiny, state_dict_fn=lambda d: synth.synthetic_state_dict(tiny, seed=3, device=d), verify_broadcast=True,
                              device=dev, model_factory=lambda cfg, sd, d, **kw: sd)
     wrep = eng.weights_report
-    assert (wrep is None) == (world == 1) and (wrep is None or (wrep["equal_to_local_copy_on_every_rank"] and wrep["bytes"] > 0))
+    assert (wrep is None) == (not mdist.collectives_on()) and (wrep is None or (wrep["equal_to_local_copy_on_every_rank"] and wrep["bytes"] > 0))
     assert "text.wte" in eng.model
     mine = mdist.shard_range(3 * world + 1, rank, world)
     ids = torch.tensor([[i, i + 1] for i in mine], dtype=torch.int32, device=dev).reshape(len(mine), 2)
@@ -107,7 +107,7 @@ def selftest_dist(args):
         assert per_rank == [r + 0.5 for r in range(world)], per_rank
         print(json.dumps({"selftest": "dist", "n_gpus": world, "max_rank": t, "items": len(got), "ranks_seen": seen,
                           "per_rank_ms_per_step": per_rank, "weights_broadcast": wrep}), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

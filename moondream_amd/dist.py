@@ -23,15 +23,32 @@ import torch
 import torch.distributed as dist
 
 
+SINGLE_RANK_GROUP_ENV = "MOONDREAM_DIST_SINGLE_RANK_GROUP"
+
+
+def single_rank_group() -> bool:
+    """``MOONDREAM_DIST_SINGLE_RANK_GROUP=1``: a job of ONE rank still creates its process group and runs every
+    collective of the N-rank path (weight broadcast, id gather, the all-reduces) over it.  Nothing to gain at run time --
+    it exists so that the exact collective calls of the N-rank path can be executed over RCCL on a one-GPU box
+    (tests/test_model_gpu.py, ``bench.py --gpus 1`` under torchrun); without it one rank means no process group at all."""
+    return os.environ.get(SINGLE_RANK_GROUP_ENV, "0") not in ("", "0")
+
+
+def collectives_on() -> bool:
+    """True when the N-rank code path applies: a process group exists and has more than one rank (or one rank and
+    ``single_rank_group()``)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_group())
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the
-    default process group when WORLD_SIZE > 1."""
+    default process group when WORLD_SIZE > 1 (or at WORLD_SIZE == 1 under ``single_rank_group()``)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("MASTER_PORT", "29500" if world > 1 else str(free_port()))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -91,7 +108,7 @@ def broadcast_state_dict(
     ``template`` (name -> (shape, dtype)) is known everywhere from the config, so
     only payload bytes travel: all tensors are packed into ONE flat uint8 buffer
     and sent with a single broadcast."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         assert sd is not None
         return {k: v.to(device) for k, v in sd.items()}
     names = sorted(template)
@@ -125,7 +142,7 @@ def gather_token_ids(local: torch.Tensor, dst: int = 0, n_total: Optional[int] =
     with ``n_total`` (the number of items ``shard_range`` split) every rank knows every block size and no
     size exchange is needed, otherwise one tiny all-reduce (MAX) sizes the padded blocks and the true row
     counts travel in the same gather as one extra row."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return [local]
     world, rank = dist.get_world_size(), dist.get_rank()
     if n_total is not None:
@@ -156,7 +173,7 @@ def gather_token_ids(local: torch.Tensor, dst: int = 0, n_total: Optional[int] =
 
 def ranks_seen(device) -> int:
     """An all-reduce (SUM) of ones: how many ranks actually took part in the collectives of this run."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return 1
     t = torch.ones(1, dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -165,7 +182,7 @@ def ranks_seen(device) -> int:
 
 def gather_floats(value: float, device, dst: int = 0) -> Optional[List[float]]:
     """One float per rank, on rank ``dst`` (per-rank timings for the bench line); None elsewhere."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return [float(value)]
     t = torch.tensor([value], dtype=torch.float64, device=device)
     bufs = [torch.zeros_like(t) for _ in range(dist.get_world_size())] if dist.get_rank() == dst else None
@@ -174,7 +191,7 @@ def gather_floats(value: float, device, dst: int = 0) -> Optional[List[float]]:
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -182,5 +199,8 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if collectives_on():
+        if dist.get_backend() == "nccl":  # name the device: RCCL otherwise guesses it from the rank (and warns)
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

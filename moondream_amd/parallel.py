@@ -54,6 +54,9 @@ class DataParallelEngine:
                  backend: Optional[str] = None, device: Optional[torch.device] = None,
                  model_factory: Callable[..., Any] = _default_model_factory, **model_kwargs):
         self.rank, self.world, self.local_rank = mdist.init_from_env(backend)
+        # the N-rank path (collectives) applies: more than one rank -- or ONE rank with MOONDREAM_DIST_SINGLE_RANK_GROUP=1, which runs
+        # the same collective calls over a one-rank group (how the RCCL calls of this file are exercised on a one-GPU box)
+        self._collective = mdist.collectives_on()
         if device is None:
             device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
         self.device = torch.device(device)
@@ -63,7 +66,7 @@ class DataParallelEngine:
         self.weights_report: Optional[dict] = None
         sd = self._distribute_weights(weights_file, state_dict, state_dict_fn, verify_broadcast)
         self.model = model_factory(config, sd, self.device, **model_kwargs)
-        self._gather_stream = torch.cuda.Stream(device=self.device) if (self.world > 1 and self.device.type == "cuda") else None
+        self._gather_stream = torch.cuda.Stream(device=self.device) if (self._collective and self.device.type == "cuda") else None
 
     # ------------------------------------------------------------------ launch
     @staticmethod
@@ -89,7 +92,7 @@ class DataParallelEngine:
                 local = load_state_dict_file(weights_file)
             else:
                 raise ValueError("DataParallelEngine needs weights_file, state_dict or state_dict_fn (on rank 0 at least)")
-        if self.world == 1:
+        if not self._collective:
             assert local is not None
             return {k: v.to(self.device) for k, v in local.items()}
         # (name -> shape, dtype): known to every rank that built a copy, sent from rank 0 otherwise (a few KB, once)
@@ -124,7 +127,7 @@ class DataParallelEngine:
         """(this rank's items, global item count)."""
         if local:
             n_local = len(items)
-            if self.world == 1:
+            if not self._collective:
                 return list(items), n_local
             t = torch.tensor([n_local], dtype=torch.int64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -139,7 +142,7 @@ class DataParallelEngine:
     def gather_ids(self, ids: Sequence[Sequence[int]], n_total: int) -> Optional[List[List[int]]]:
         """This rank's ragged id lists -> the global list (image order) on rank 0, None elsewhere.  One fixed-shape int32
         gather: rows are padded with -1 to the longest sequence of the job (one tiny all-reduce) and cut again on rank 0."""
-        if self.world == 1:
+        if not self._collective:
             return [list(map(int, s)) for s in ids]
         longest = torch.tensor([max((len(s) for s in ids), default=0)], dtype=torch.int64, device=self.device)
         dist.all_reduce(longest, op=dist.ReduceOp.MAX)
@@ -157,7 +160,7 @@ class DataParallelEngine:
         """int32 [B_local, T] (host) -> every rank's block on rank 0.  On a GPU the copy and the RCCL gather run on their
         own stream: nothing of a step touches the default stream (a synchronous copy there waits for everything queued on
         the device, the next step's encode and decode included)."""
-        if self.world == 1:
+        if not self._collective:
             return [host_ids]
         if self._gather_stream is None:
             return mdist.gather_token_ids(host_ids.to(self.device), n_total=n_total)
@@ -169,7 +172,7 @@ class DataParallelEngine:
 
     def gather_objects(self, items: List[Any]) -> Optional[List[Any]]:
         """Ragged Python results (detect / point objects, strings) of this rank's block -> the global list on rank 0."""
-        if self.world == 1:
+        if not self._collective:
             return list(items)
         bufs = [None] * self.world if self.rank == 0 else None
         dist.gather_object(list(items), bufs, dst=0)
@@ -190,7 +193,7 @@ class DataParallelEngine:
         return mdist.gather_floats(value, self.device)
 
     def close(self) -> None:
-        if self.world > 1 and dist.is_initialized():
+        if self._collective and dist.is_initialized():
             dist.destroy_process_group()
 
     # ------------------------------------------------------------------ the batched API, sharded

@@ -137,15 +137,18 @@ class _StubModel:
         return [{"points": [{"x": float(im)}]} for im in images]
 
 
-def _engine_worker(rank, world, port, out_dir, weights_path):
+def _engine_worker(rank, world, port, out_dir, weights_path, backend="gloo", device="cpu", single_rank_group=False):
     from moondream_amd.config import get_config
     from moondream_amd.parallel import DataParallelEngine
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if single_rank_group:  # ONE rank that still builds its process group and runs every collective of the N-rank path
+        os.environ[mdist.SINGLE_RANK_GROUP_ENV] = "1"
     cfg = get_config("tiny")
     # rank 0 alone reads the checkpoint FILE; the others learn names / shapes / dtypes and the bytes from the broadcast
-    eng = DataParallelEngine(cfg, weights_file=weights_path if rank == 0 else None, backend="gloo", device=torch.device("cpu"),
+    eng = DataParallelEngine(cfg, weights_file=weights_path if rank == 0 else None, backend=backend, device=torch.device(device),
                              model_factory=_StubModel, max_batch=4)
+    assert dist.is_initialized() and dist.get_backend() == backend and eng._collective
     assert (eng.rank, eng.world) == (rank, world) and eng.model.k == 1000 and eng.model.kw == {"max_batch": 4}
     assert eng.weights_report["bytes"] > 0
     n = 7
@@ -187,18 +190,49 @@ def _engine_worker(rank, world, port, out_dir, weights_path):
 def test_data_parallel_engine_world_2_gloo(tmp_path):
     """The product-level DP runner: rank 0 loads the checkpoint file, flat broadcast, per-rank lockstep engine over
     shard_range blocks, id gather / object gather on rank 0 -- with a stub model, over gloo, world_size 2."""
+    port = _free_port()
+    mp.spawn(_engine_worker, args=(2, port, str(tmp_path), _write_stub_checkpoint(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "engine_ok").exists()
+
+
+def _write_stub_checkpoint(tmp_path):
     weights_path = str(tmp_path / "stub.pt")
     torch.save({"k": torch.tensor([1000], dtype=torch.int32), "w": torch.arange(6, dtype=torch.float32).to(torch.bfloat16)}, weights_path)
+    return weights_path
+
+
+def test_data_parallel_engine_single_rank_group_runs_every_collective(tmp_path):
+    """MOONDREAM_DIST_SINGLE_RANK_GROUP=1: ONE rank builds its process group and goes through the N-rank code path -- the
+    object broadcast of the template, the flat weight broadcast, the all-reduces, the id gather (own stream on a GPU), the
+    object gather, the barrier.  Here over gloo; tests/test_model_gpu.py runs the same worker over RCCL on the GPU box,
+    which is how the RCCL calls of dist.py / parallel.py get executed where only one GPU exists."""
     port = _free_port()
-    mp.spawn(_engine_worker, args=(2, port, str(tmp_path), weights_path), nprocs=2, join=True)
+    mp.spawn(_engine_worker, args=(1, port, str(tmp_path), _write_stub_checkpoint(tmp_path), "gloo", "cpu", True), nprocs=1, join=True)
     assert (tmp_path / "engine_ok").exists()
+
+
+def test_bench_selftest_single_rank_group():
+    """`bench.py --gpus 1 --selftest-dist` under MOONDREAM_DIST_SINGLE_RANK_GROUP=1: the bench's own plumbing
+    (engine weight path with verification, id gather, per-rank floats) over a one-rank process group."""
+    import json
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env[mdist.SINGLE_RANK_GROUP_ENV] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--selftest-dist"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["items"] == 4
+    assert line["weights_broadcast"]["equal_to_local_copy_on_every_rank"] is True
 
 
 def test_data_parallel_engine_single_process_needs_no_process_group(monkeypatch):
     from moondream_amd.config import get_config
     from moondream_amd.parallel import DataParallelEngine
 
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", mdist.SINGLE_RANK_GROUP_ENV):
         monkeypatch.delenv(k, raising=False)
     eng = DataParallelEngine(get_config("tiny"), state_dict={"k": torch.tensor([5], dtype=torch.int32)}, device=torch.device("cpu"),
                              model_factory=_StubModel)

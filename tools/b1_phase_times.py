@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Phase times inside the persistent single-sequence decode kernel (md_decode_step_b1): workgroup 0's real-time stamps
-at every phase boundary (measurement hook: word 768 of the sync state), averaged over the layers of one token."""
-import os, sys
+"""Single-image caption (B = 1), 2B: wall time of one call against the GPU-side phase times of the same call
+(host tiling, vision, image / prompt prefill, decode) -- what p50_caption_latency_ms is made of."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -13,19 +13,22 @@ cfg = get_config("2b")
 dev = torch.device("cuda", 0)
 sd = synth.synthetic_state_dict(cfg, seed=1, device=dev)
 model = MoondreamModel(cfg, sd, device=dev, tokenizer=IdTokenizer(), max_batch=1)
+model.compile()
 img = [synth.synthetic_image(0, 1)]
 prompt = [cfg.tokenizer.templates["caption"]["normal"]]
-model.batch_generate_ids(img, prompt, max_tokens=8, ignore_eos=True)
-with torch.inference_mode():
-    model._b1_sync[64 * 12] = 1
-model.batch_generate_ids(img, prompt, max_tokens=8, ignore_eos=True)
-torch.cuda.synchronize()
-w = model._b1_sync.cpu().numpy().astype(np.uint32)
-L = cfg.text.n_layers
-n = 1 + 6 * L
-t = np.array([int(w[2048 + 2 * i]) | (int(w[2049 + 2 * i]) << 32) for i in range(n)], dtype=np.int64) * 10  # ns (100 MHz)
-d = np.diff(t)
-names = ["phase A (ln + qkv|fc1 rows)", "barrier 1 (+ K/V rows requested)", "phase B (attention partials)", "barrier 2 (+ fc2 rows)", "phase C (combine + proj rows)", "barrier 3 (+ next rows requested)"]
-print(f"one token, {L} layers: total {(t[-1] - t[0]) / 1e3:.1f} us (the lm_head phase is not stamped)")
-for k in range(6):
-    print(f"  {names[k]:36s} mean {d[k::6].mean() / 1e3:6.2f} us   (layer 1: {d[6 + k] / 1e3:6.2f})")
+for timing in (False, True):
+    model.collect_timing = timing
+    lat, ph = [], []
+    for i in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.batch_generate_ids(img, prompt, max_tokens=32, ignore_eos=True)
+        torch.cuda.synchronize()
+        if i >= 2:
+            lat.append((time.perf_counter() - t0) * 1e3)
+            if timing: ph.append(dict(model.last_phase_ms))
+    print(f"collect_timing={timing}: wall p50 {np.median(lat):.2f} ms  min {min(lat):.2f}  max {max(lat):.2f}")
+    if ph:
+        keys = list(ph[0].keys())
+        med = {k: float(np.median([p[k] for p in ph])) for k in keys}
+        print("  GPU phases (median, ms):", {k: round(v, 3) for k, v in med.items()}, " sum", round(sum(med.values()), 2))

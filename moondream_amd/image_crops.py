@@ -3,19 +3,51 @@
 Same contract as the reference's ``image_crops`` module (reference:
 moondream/torch/image_crops.py:17-231): ``select_tiling``,
 ``overlap_crop_image`` (global 378x378 crop + overlapping local crops cut from
-the image resized to the tiling) and ``reconstruct_from_crops``.  The resize
-uses PIL LANCZOS, the reference's fallback branch (image_crops.py:137-150);
-pyvips is not available in this environment, and the two branches give
-different pixels ("image resize parity").
+the image resized to the tiling) and ``reconstruct_from_crops``.
+
+The resize has the reference's TWO branches, chosen as the reference chooses
+(image_crops.py:7-14): pyvips when it imports (image_crops.py:124-136:
+``Image.new_from_array(img).resize(scale_x, vscale=scale_y)`` with the scales
+taken from the image's own size), PIL LANCZOS otherwise (image_crops.py:137-150).
+The two give different pixels ("image resize parity"), so a
+deployment that has pyvips must use it here as well to match the reference
+there.  pyvips is not in this build's image: the PIL branch is the one pinned
+by crop CRCs recorded from the reference; the pyvips branch is pinned on its
+LOGIC (scales, call order, which image feeds the global crop) by running the
+reference's function and this one against the same stand-in module
+(tests/test_image_crops.py), not on libvips' pixels.  ``MOONDREAM_RESIZE=pil``
+forces the PIL branch where pyvips exists.
 """
 from __future__ import annotations
 
 import math
 from typing import List, Sequence, Tuple, TypedDict, Union
 
+import os
+
 import numpy as np
 import torch
 from PIL import Image
+
+
+def _import_pyvips():
+    """The reference's probe (image_crops.py:7-14): pyvips if it imports, anything going wrong = the PIL branch."""
+    if os.environ.get("MOONDREAM_RESIZE", "").lower() == "pil":
+        return None
+    try:
+        import pyvips
+
+        return pyvips
+    except Exception:
+        return None
+
+
+_pyvips = _import_pyvips()
+
+
+def resize_backend() -> str:
+    """"pyvips" | "pil": the branch ``overlap_crop_image`` takes (decided at import, like the reference's HAS_VIPS)."""
+    return "pyvips" if _pyvips is not None else "pil"
 
 
 class OverlapCropOutput(TypedDict):
@@ -79,8 +111,15 @@ def overlap_crop_image(
         assert out.shape == shape and out.dtype == np.uint8, (out.shape, shape)
         crops = out
 
-    resized = _resize(image, th * window + 2 * margin_px, tw * window + 2 * margin_px)
-    crops[0] = _resize(image, base_size[0], base_size[1])
+    if _pyvips is not None:
+        # reference: image_crops.py:124-136 -- scale factors from the array's own size, horizontal scale first, the GLOBAL crop
+        # resized from the original vips image (not from the tiled resize); whatever size libvips rounds to is taken as it comes
+        vimg = _pyvips.Image.new_from_array(image)
+        resized = vimg.resize((tw * window + 2 * margin_px) / image.shape[1], vscale=(th * window + 2 * margin_px) / image.shape[0]).numpy()
+        crops[0] = vimg.resize(base_size[1] / vimg.width, vscale=base_size[0] / vimg.height).numpy()
+    else:
+        resized = _resize(image, th * window + 2 * margin_px, tw * window + 2 * margin_px)
+        crops[0] = _resize(image, base_size[0], base_size[1])
     for ty in range(th):
         for tx in range(tw):
             y0, x0 = ty * window, tx * window

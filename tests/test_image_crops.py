@@ -92,6 +92,78 @@ def test_random_sizes_against_the_reference_itself():
         assert torch.equal(ra, rb), (h, w)
 
 
+def test_pyvips_branch_follows_the_reference_with_a_stand_in_module(monkeypatch):
+    """Build container only.  pyvips is not installed here, so libvips' pixels cannot be pinned; what CAN be pinned is the
+    branch's logic (reference image_crops.py:124-136): which scales are computed from which sizes, horizontal first, and that
+    the global crop comes from the ORIGINAL image.  A stand-in ``pyvips`` (new_from_array / resize(scale, vscale=) / numpy /
+    width / height, resampling through PIL with the rounding libvips documents) is put in sys.modules; the reference's module
+    and this package's are both (re)imported under it and must produce the same tilings and the same crop bytes -- and, the
+    stand-in being a different resampler from the PIL branch's direct call, different bytes from the PIL branch on a
+    non-identity size (so the test cannot pass by both sides ignoring the module)."""
+    import importlib
+    import importlib.util
+    import sys
+    import types
+    import pytest
+    from PIL import Image as PILImage
+
+    ref_root = os.environ.get("MOONDREAM_REFERENCE", "/root/reference")
+    path = os.path.join(ref_root, "moondream", "torch", "image_crops.py")
+    if not os.path.isfile(path):
+        pytest.skip("needs the reference checkout (build container)")
+
+    calls = []
+
+    class FakeVipsImage:
+        def __init__(self, arr):
+            self.arr = np.ascontiguousarray(arr)
+            self.height, self.width = arr.shape[:2]
+
+        @staticmethod
+        def new_from_array(arr):
+            return FakeVipsImage(np.asarray(arr))
+
+        def resize(self, scale, vscale=None):
+            vs = scale if vscale is None else vscale
+            w, h = max(1, int(round(self.width * scale))), max(1, int(round(self.height * vs)))
+            calls.append((self.width, self.height, round(scale, 9), round(vs, 9)))
+            # BILINEAR on purpose: a different resampler from the PIL branch's LANCZOS
+            return FakeVipsImage(np.asarray(PILImage.fromarray(self.arr).resize((w, h), resample=PILImage.Resampling.BILINEAR)))
+
+        def numpy(self):
+            return self.arr
+
+    fake = types.ModuleType("pyvips")
+    fake.Image = FakeVipsImage
+    monkeypatch.setitem(sys.modules, "pyvips", fake)
+    monkeypatch.delenv("MOONDREAM_RESIZE", raising=False)
+    spec = importlib.util.spec_from_file_location("ref_image_crops_vips", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    assert ref.HAS_VIPS
+    import moondream_amd.image_crops as ours_mod
+    ours = importlib.reload(ours_mod)
+    try:
+        assert ours.resize_backend() == "pyvips"
+        rng = np.random.default_rng(5)
+        for h, w in [(378, 378), (768, 1024), (500, 1300), (1200, 640), (97, 2000), (379, 378)]:
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            calls.clear()
+            b = ref.overlap_crop_image(img, overlap_margin=4, max_crops=12)
+            ref_calls = list(calls)
+            calls.clear()
+            a = ours.overlap_crop_image(img, overlap_margin=4, max_crops=12)
+            assert calls == ref_calls and len(calls) == 2, (h, w, calls, ref_calls)  # same two resize calls, same order, same scales
+            assert tuple(a["tiling"]) == tuple(b["tiling"]) and np.array_equal(a["crops"], b["crops"]), (h, w)
+        monkeypatch.setenv("MOONDREAM_RESIZE", "pil")
+        pil_mod = importlib.reload(ours_mod)
+        assert pil_mod.resize_backend() == "pil"
+        assert not np.array_equal(pil_mod.overlap_crop_image(img, overlap_margin=4, max_crops=12)["crops"], a["crops"])
+    finally:
+        monkeypatch.undo()
+        importlib.reload(ours_mod)  # back to this environment's real branch for every other test
+
+
 def test_crop_count_and_out_buffer_match_the_allocating_form():
     """crop_count predicts what overlap_crop_image produces; cutting into a caller-owned buffer (the pinned staging
     path of the engine) gives the same bytes as the allocating form."""

@@ -56,6 +56,7 @@ struct Knobs {
   int decode_cfg = 16; // MD_DECODE_CFG: d / 6 = alternatives to the 64x64 + helper-waves config
   int decode_slices = 0;  // MD_DECODE_SLICES
   int rope_fuse = 1;      // MD_ROPE_FUSE=0: prefill RoPE + KV write as their own kernel again (A/B, tests)
+  int small_m_rule = 1;   // MD_SMALL_M_RULE=0: round 2's single-image tile rule (cost model for everything above 128 tiles of 128 x 128)
   Knobs() {
     auto geti = [](const char* n, int d) { const char* e = getenv(n); return (e && *e) ? atoi(e) : d; };
     tile = geti("MD_GEMM_TILE", -1);
@@ -65,6 +66,7 @@ struct Knobs {
     nt = geti("MD_DECODE_NT", 0);
     decode_slices = geti("MD_DECODE_SLICES", 0);
     rope_fuse = geti("MD_ROPE_FUSE", 1);
+    small_m_rule = geti("MD_SMALL_M_RULE", 1);
     if (const char* dc = getenv("MD_DECODE_CFG")) {
       if (dc[0] == 'd') decode_cfg = 3;
       else if (dc[0] == '6') decode_cfg = 10;
@@ -689,9 +691,6 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
                             : launch_cfg<64, 64, 2, 1, EPI, false, 4, 128, 0, 2>(k, stream);
       return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4, 64, 0, 2>(k, stream)
                           : launch_cfg<64, 64, 2, 1, EPI, false, 4, 64, 0, 2>(k, stream);
-    // 128 x 128, FOUR-stage ring (128 KiB: one workgroup per CU, three slices in flight): the single-image regime's few-tile
-    // long-K layers (round 5: text fc2 at 735 rows 63.7 -> 52.0 us, profiles/r05_b1_tile_config_sweep.txt)
-    case 4: return launch_cfg<128, 128, 2, 2, EPI, false, 4>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }
@@ -734,21 +733,24 @@ int pick_tile(int M, int n_store, int K, int policy) {
   // the 256x256 kernel (16x16x32 MFMAs; the small-shape configs below multiply with 32x32x16: equal to fp32 rounding, not
   // bitwise), so that a sequence gets the same bits alone and in a batch
   if (policy == MD_TILE_PINNED && M > 64) return knobs().w4 ? 20 : 11;
-  // Single-image regime (round 5 re-sweep on 1458 ViT rows / 735 decoder rows, profiles/r05_b1_tile_config_sweep.txt; every
-  // config named here multiplies with 32x32x16 in the same K order: the choice never changes a bit).
-  //  * at most 128 tiles of 128 x 128 and a long K (proj / fc2 of both towers): half the chip is idle whatever the tile and
-  //    the launch runs at the latency of its K loop.  Round 2 took the 64 x 64 decode-regime config there (four times the
-  //    workgroups, 4-deep ring + DMA helper waves: text fc2 81 -> 61 us); the 128 x 128 tile on a FOUR-stage ring (one
-  //    workgroup per CU, three slices in flight, twice the FLOPs per operand byte) is faster still on every such layer:
-  //    text fc2 63.7 -> 52.0 us, text proj 18.4 -> 17.0, ViT fc2 33.1 -> 30.6, ViT proj 13.5 -> 12.6, projector fc2 62.3 -> 51.1.
-  //  * up to 512 tiles of 128 x 128 (ViT qkv / fc1, projector fc1): the two-stage 128 x 128 config keeps TWO workgroups per CU,
-  //    so all of them are resident at once -- the cost model below counts one workgroup per CU and preferred 256 x 128
-  //    (ViT qkv 21.0 -> 18.0 us, fc1 24.7 -> 21.2, projector fc1 37.2 -> 33.6).  Wider layers (the decoder's fused qkv|fc1:
-  //    672 such tiles) stay with the cost model, i.e. the four-wave kernel (46.6 us against 57.6).
+  // Single-image regime (1458 ViT rows / 735 decoder rows; every config named here multiplies with 32x32x16 in the same K
+  // order: the choice never changes a bit).
+  //  * at most 128 tiles of 128 x 128 and a long K (proj / fc2 of both towers): half the chip is idle whatever the tile and the
+  //    launch runs at the latency of its K loop -- the 64 x 64 tiles with the 4-deep ring and DMA helper waves (the decode-regime
+  //    config) quadruple the workgroups (tools/sweep_gemm_b1.py, round 2: text fc2 at 730 rows 81 -> 61 us, ViT fc2 50 -> 30 us).
+  //    Round 5 re-swept it: a 128 x 128 tile on a four-stage ring wins the back-to-back sweep (text fc2 63.7 -> 52.0 us) and LOSES
+  //    inside a caption, where the layer's weights come from HBM and 96 workgroups pull them through 96 CUs (ViT proj / fc2 23.7 ->
+  //    24.9 us, text 42.0 -> 42.5 us per launch: profiles/r05_b1_tile_config_sweep.txt) -- the 64 x 64 config stays.
+  //  * up to 512 tiles of 128 x 128 (ViT qkv / fc1, projector fc1): the two-stage 128 x 128 config keeps TWO workgroups per CU, so
+  //    all of them are resident at once; the cost model below counts one workgroup per CU and preferred 256 x 128.  Inside a
+  //    caption: ViT qkv 25.9 -> 21.5 us, fc1 29.2 -> 24.9 us per launch (round 5).  Wider layers (the decoder's fused qkv|fc1: 672
+  //    such tiles) stay with the cost model, i.e. the four-wave kernel.
   if (M > 64) {
     const long t128 = (long)((M + 127) / 128) * ((n_store + 127) / 128);
-    if (K >= 1024 && t128 <= 128) return 4;
-    if (t128 <= 512) return 2;
+    if (K >= 1024 && t128 <= 128) return 16;
+    // ("small_m_rule": 0 = round 2's rule, 1 = the default below, n > 1 = that many tiles instead of 512 -- A/B)
+    const int rule = knobs().small_m_rule;
+    if (rule != 0 && t128 <= (rule > 1 ? rule : 512)) return 2;
   }
   const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 128};
   const double eff[3] = {1.0, 0.70, 0.55};
@@ -1037,6 +1039,7 @@ extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   else if (s == "decode_slices") k.decode_slices = value;
   else if (s == "w4_variant") md_gemm_w4_set_variant(value);
   else if (s == "rope_fuse") k.rope_fuse = value;
+  else if (s == "small_m_rule") k.small_m_rule = value;
   else if (s == "w4_grid") md_gemm_w4_set_grid(value);
   else if (s == "w4_dbg_lo") md_gemm_w4_set_debug(0, (uint32_t)value);
   else if (s == "w4_dbg_hi") md_gemm_w4_set_debug(1, (uint32_t)value);

@@ -237,8 +237,9 @@ md_status md_amax_bf16(const void* x, int64_t ldx, int32_t rows, int32_t cols, f
  * bits of a product call lives here (that is md_gemm_args.tile_policy, per call).  The complete key list:
  *   "tile"          -1 = automatic; 20 = four-wave 256x256, 11 / 15 = the eight-wave 256x256 baselines, 1 = 256x128,
  *                   2 = 128x128, 16 / 10 / 3 = decode-regime configs (forces the config for every launch)
- *   "small_m_rule"  0: round 2's tile rule for MD_TILE_BY_SHAPE launches (the cost model for everything above 128 tiles
- *                   of 128x128) instead of round 5's (the 128x128 config up to 512 such tiles); same bits either way
+ *   "small_m_rule"  tile rule of MD_TILE_BY_SHAPE launches: 1 (default) = round 5's (the 128x128 config for up to 512 tiles
+ *                   of 128x128), 0 = round 2's (the cost model above 128 such tiles), n > 1 = n tiles instead of 512; same
+ *                   bits either way
  *   "w4"            0: the eight-wave 256x256 kernels wherever the four-wave one would be picked (also under
  *                   MD_TILE_PINNED)
  *   "persist"       0: eight-wave kernels without their persistent tile loop

@@ -27,6 +27,10 @@
 #include "md_common.hpp"
 #include <cstdlib>
 
+// md_gemm_set_tuning("attn_skip_dead_half", 0 | 1) / MD_ATTN_SKIP_DEAD_HALF: A/B and test hook (the two settings give the same bits)
+static int g_attn_skip_dead_half = [] { const char* e = getenv("MD_ATTN_SKIP_DEAD_HALF"); return (e && *e) ? atoi(e) : 1; }();
+void md_attention_set_skip_dead_half(int v) { g_attn_skip_dead_half = v != 0; }
+
 namespace {
 
 struct AttnK {
@@ -44,6 +48,7 @@ struct AttnK {
   int64_t o8_bs, o8_ts;
   float o8_inv_scale;
   int head_dim;
+  int skip_dead_half;  // LDS-DMA prefill kernel: skip the second 32-key sub-block of a last tile that has no live key in it (exact)
 };
 
 template <int HD>
@@ -446,9 +451,17 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   const int k_lane = l31 * C::KROW + hi * 16;
   const int v_lane = (4 * hi + (i16 >> 2)) * C::VROW + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
 
-  auto compute_s = [&](f32x16 (&sa)[2], const char* Ks) {
+  // both_subs == false (the LAST key tile when at most 32 of its keys exist): the second 32-key sub-block holds keys >= kv_len
+  // only -- masked to -inf, P exactly 0, a contribution of exact zeros to every sum -- so its S block is simply -inf and its
+  // exponentials, packs and P V products are skipped; the result is bit for bit the one of the full computation.
+  auto compute_s = [&](f32x16 (&sa)[2], const char* Ks, bool both_subs) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      if (sub == 1 && !both_subs) {  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[1][r] = -INFINITY;
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sa[sub][r] = 0.f;
 #pragma unroll
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     if (PIPE) {
       if (64 < kv_end) issue_k(64, 1);
       tile_barrier();
-      compute_s(sacc, smem);
+      compute_s(sacc, smem, true);
     }
   }
   int buf = 0;
@@ -490,7 +503,9 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     const char* Vs = Ks + C::K_BYTES;
     const char* Kn = smem + (buf ^ 1) * C::BUF;  // PIPE: K(t+1) (stale but finite data after the last tile; result unused)
 
-    if (!PIPE) compute_s(sacc, Ks);
+    // (PIPE keeps the full computation: its S runs one tile ahead)
+    const bool both = PIPE || !p.skip_dead_half || kv0 + 32 < kv_len;
+    if (!PIPE) compute_s(sacc, Ks, both);
 
     const bool full_vis = (kv0 + 63 <= w_qpos_lo) || (w_qpos_hi < p.prefix && kv0 + 64 <= p.prefix);
     const bool need_mask = !(full_vis && kv0 + 64 <= kv_len);
@@ -525,9 +540,10 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     float psum = 0.f;
     bf16x8 pf[2][2];
     f32x16 snext[2];
-    if (PIPE) compute_s(snext, Kn);  // independent of everything below: the scheduler interleaves it
+    if (PIPE) compute_s(snext, Kn, true);  // independent of everything below: the scheduler interleaves it
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < 2; ++sub) {
+      if (sub == 1 && !both) break;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         u32x4 w;
@@ -540,12 +556,14 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
         }
         pf[sub][u] = __builtin_bit_cast(bf16x8, w);
       }
+    }
     l_run += psum;
 
     // O^T += V^T P^T: MFMA K-slot (hi, j) <-> key 16u + 4hi + (j & 3) + 8 (j >> 2), so the two
     // transpose reads of a fragment start at keys 16u + 4hi and 16u + 8 + 4hi
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < 2; ++sub) {
+      if (sub == 1 && !both) break;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -557,6 +575,7 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pf[sub][u], oacc[d], 0, 0, 0);
         }
       }
+    }
     if (PIPE) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) sacc[sub] = snext[sub];
@@ -842,6 +861,7 @@ extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
   k.q_pos0 = a->q_pos0;
   k.kv_len = a->kv_len;
   k.scale_log2 = a->scale * 1.4426950408889634f;
+  k.skip_dead_half = g_attn_skip_dead_half;
   k.o8 = (uint8_t*)a->o8;
   k.o8_bs = a->o8_bs;
   k.o8_ts = a->o8_ts;

@@ -749,6 +749,23 @@ def test_attention_prefill_e4m3_output_equals_quantise_pass(lib, hd, t):
             assert torch.equal(o_b, o)
 
 
+@pytest.mark.parametrize("hd,t,tq,pos", [(72, 729, 729, 0), (64, 735, 735, 0), (64, 730, 5, 725), (64, 97, 97, 0), (72, 96, 96, 0), (64, 65, 65, 0), (64, 33, 33, 0)])
+def test_attention_dead_half_tile_skip_is_exact(lib, hd, t, tq, pos):
+    """Round 5: when at most 32 keys of the LAST 64-key tile exist, the kernel skips the tile's second half (its scores are -inf,
+    its probabilities exactly 0, its contributions exact zeros).  Same bits as the full computation -- for lengths that end in the
+    first half of a tile (729, 735, 97, 65: the skip fires), exactly at the half (96), in the second half (33 + ...: no skip), with
+    the prefix-LM rule and a causal tail."""
+    b, h = 2, 3
+    q, k, v = randn(b, tq, h, hd, seed=30), randn(b, h, t, hd, seed=31), randn(b, h, t, hd, seed=32)
+    outs = []
+    pos0 = torch.full((b,), pos, dtype=torch.int32, device="cuda") if pos else None
+    for skip in (1, 0, 1):
+        _lib.check(lib.md_gemm_set_tuning(b"attn_skip_dead_half", skip))
+        outs.append(run_prefill(lib, q, k, v, tq, t, prefix=min(t, 64) if hd == 64 else t, pos0=pos0).clone())
+    _lib.check(lib.md_gemm_set_tuning(b"attn_skip_dead_half", 1))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_attention_spiky_scores_force_rescale(lib):
     """One key dominates late in the sequence: the online-softmax rescale path."""
     b, h, t, hd = 1, 2, 300, 72

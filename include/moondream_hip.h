@@ -248,8 +248,9 @@ md_status md_amax_bf16(const void* x, int64_t ldx, int32_t rows, int32_t cols, f
  *   "decode_cfg"    16 (default) / 10 / 3: decode-regime tile config
  *   "decode_slices" K slices per decode-regime tile (0 = by shape)
  *   "rope_fuse"     0: prefill RoPE + KV write as their own kernel instead of the qkv GEMM's epilogue
- *   "attn_skip_dead_half"  (not a GEMM key; the library's one tuning entry point) 0: md_attention_prefill computes the second
- *                   32-key half of a last key tile even when no live key is in it (round 4's kernel; same bits, ~3 % slower)
+ *   "attn_skip_dead"  (not a GEMM key; the library's one tuning entry point) exact work skipping of md_attention_prefill:
+ *                   bit 0 = the second 32-key half of a last key tile with no live key in it, bit 1 = waves with no live
+ *                   query row; default 3, 0 = round 4's kernel; same bits whatever the value
  *   "w4_grid"       workgroups of the four-wave kernel's persistent grid (0 = one per CU)
  *   "w4_variant"    main-loop schedule variant of the four-wave kernel (0 = shipped; others: tools/sweep_w4_variants.py)
  *   "w4_dbg_*"      in-kernel cycle stamps of the four-wave kernel (tools/w4_probe.py)

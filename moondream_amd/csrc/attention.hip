@@ -27,9 +27,9 @@
 #include "md_common.hpp"
 #include <cstdlib>
 
-// md_gemm_set_tuning("attn_skip_dead_half", 0 | 1) / MD_ATTN_SKIP_DEAD_HALF: A/B and test hook (the two settings give the same bits)
-static int g_attn_skip_dead_half = [] { const char* e = getenv("MD_ATTN_SKIP_DEAD_HALF"); return (e && *e) ? atoi(e) : 1; }();
-void md_attention_set_skip_dead_half(int v) { g_attn_skip_dead_half = v != 0; }
+// md_gemm_set_tuning("attn_skip_dead", 0..3) / MD_ATTN_SKIP_DEAD: A/B and test hook (every setting gives the same bits)
+static int g_attn_skip_dead = [] { const char* e = getenv("MD_ATTN_SKIP_DEAD"); return (e && *e) ? atoi(e) & 3 : 3; }();
+void md_attention_set_skip_dead(int v) { g_attn_skip_dead = v & 3; }
 
 namespace {
 
@@ -48,7 +48,7 @@ struct AttnK {
   int64_t o8_bs, o8_ts;
   float o8_inv_scale;
   int head_dim;
-  int skip_dead_half;  // LDS-DMA prefill kernel: skip the second 32-key sub-block of a last tile that has no live key in it (exact)
+  int skip_dead;  // LDS-DMA prefill kernel, exact work skipping: bit 0 = the second 32-key half of a last tile with no live key in it, bit 1 = waves with no live query row
 };
 
 template <int HD>
@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
       compute_s(sacc, smem, true);
     }
   }
+  const bool wave_live = !(p.skip_dead & 2) || q_row0 < p.q_len;  // wave-uniform
   int buf = 0;
   for (int kv0 = 0; kv0 < kv_end; kv0 += 64, buf ^= 1) {
     // own DMA of the previous iteration landed (vmcnt 0), everybody's is visible, and the
@@ -504,7 +505,11 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     const char* Kn = smem + (buf ^ 1) * C::BUF;  // PIPE: K(t+1) (stale but finite data after the last tile; result unused)
 
     // (PIPE keeps the full computation: its S runs one tile ahead)
-    const bool both = PIPE || !p.skip_dead_half || kv0 + 32 < kv_len;
+    const bool both = PIPE || !(p.skip_dead & 1) || kv0 + 32 < kv_len;
+    // A wave whose 32 query rows all lie past q_len (the fourth wave of the last query block: 729 / 735 rows = 5 blocks of 128 +
+    // 89 / 95 rows) stores nothing: it keeps its share of the LDS-DMA stream and the barriers and skips the arithmetic, which
+    // leaves its SIMD to the other workgroups' waves.
+    if (!PIPE && !wave_live) continue;
     if (!PIPE) compute_s(sacc, Ks, both);
 
     const bool full_vis = (kv0 + 63 <= w_qpos_lo) || (w_qpos_hi < p.prefix && kv0 + 64 <= p.prefix);
@@ -861,7 +866,7 @@ extern "C" md_status md_attention_prefill(const md_attn_args* a, void* stream) {
   k.q_pos0 = a->q_pos0;
   k.kv_len = a->kv_len;
   k.scale_log2 = a->scale * 1.4426950408889634f;
-  k.skip_dead_half = g_attn_skip_dead_half;
+  k.skip_dead = g_attn_skip_dead;
   k.o8 = (uint8_t*)a->o8;
   k.o8_bs = a->o8_bs;
   k.o8_ts = a->o8_ts;

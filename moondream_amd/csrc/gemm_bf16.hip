@@ -1040,7 +1040,7 @@ extern "C" md_status md_gemm_set_tuning(const char* key, int32_t value) {
   else if (s == "w4_variant") md_gemm_w4_set_variant(value);
   else if (s == "rope_fuse") k.rope_fuse = value;
   else if (s == "small_m_rule") k.small_m_rule = value;
-  else if (s == "attn_skip_dead_half") md_attention_set_skip_dead_half(value);
+  else if (s == "attn_skip_dead") md_attention_set_skip_dead(value);
   else if (s == "w4_grid") md_gemm_w4_set_grid(value);
   else if (s == "w4_dbg_lo") md_gemm_w4_set_debug(0, (uint32_t)value);
   else if (s == "w4_dbg_hi") md_gemm_w4_set_debug(1, (uint32_t)value);

@@ -65,4 +65,4 @@ bool md_gemm_w4_takes(const GemmK& k, int epi);  // shape limits of the four-wav
 void md_gemm_w4_set_grid(int v);     // persistent workgroups per launch of the four-wave kernel (0 = one per CU)
 void md_gemm_w4_set_debug(int half, uint32_t v);  // measurement builds: device buffer for in-kernel stamps
 void md_gemm_w4_set_variant(int v);  // measurement hook: schedule / ablation variant of the bias-epilogue kernel
-void md_attention_set_skip_dead_half(int v);  // attention.hip: prefill kernel skips a last key tile's second half when no live key is in it (exact; 0 = A/B)
+void md_attention_set_skip_dead(int v);  // attention.hip: exact work skipping of the prefill kernel (bit 0: dead half of the last key tile, bit 1: waves without a live query row)

@@ -754,16 +754,17 @@ def test_attention_dead_half_tile_skip_is_exact(lib, hd, t, tq, pos):
     """Round 5: when at most 32 keys of the LAST 64-key tile exist, the kernel skips the tile's second half (its scores are -inf,
     its probabilities exactly 0, its contributions exact zeros).  Same bits as the full computation -- for lengths that end in the
     first half of a tile (729, 735, 97, 65: the skip fires), exactly at the half (96), in the second half (33 + ...: no skip), with
-    the prefix-LM rule and a causal tail."""
+    the prefix-LM rule and a causal tail.  Second switch of the same kind: a wave whose 32 query rows all lie past q_len skips its
+    arithmetic.  Every combination of the two (3 = default, 0 = round 4's kernel, 1, 2) gives the same bits."""
     b, h = 2, 3
     q, k, v = randn(b, tq, h, hd, seed=30), randn(b, h, t, hd, seed=31), randn(b, h, t, hd, seed=32)
     outs = []
     pos0 = torch.full((b,), pos, dtype=torch.int32, device="cuda") if pos else None
-    for skip in (1, 0, 1):
-        _lib.check(lib.md_gemm_set_tuning(b"attn_skip_dead_half", skip))
+    for skip in (3, 0, 1, 2):
+        _lib.check(lib.md_gemm_set_tuning(b"attn_skip_dead", skip))
         outs.append(run_prefill(lib, q, k, v, tq, t, prefix=min(t, 64) if hd == 64 else t, pos0=pos0).clone())
-    _lib.check(lib.md_gemm_set_tuning(b"attn_skip_dead_half", 1))
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    _lib.check(lib.md_gemm_set_tuning(b"attn_skip_dead", 3))
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_attention_spiky_scores_force_rescale(lib):

@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
   const int k_lane = l31 * C::KROW + hi * 16;
   const int v_lane = (4 * hi + (i16 >> 2)) * C::VROW + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
 
-  // both_subs == false (the LAST key tile when at most 32 of its keys exist): the second 32-key sub-block holds keys >= kv_len
-  // only -- masked to -inf, P exactly 0, a contribution of exact zeros to every sum -- so its S block is simply -inf and its
+  // both_subs == false (the LAST key tile of the block when at most 32 of its keys are live): the second 32-key sub-block holds only keys
+  // >= kv_end (past kv_len, or past what the block's last row may see) -- masked to -inf, P exactly 0, a contribution of exact zeros to every sum -- so its S block is simply -inf and its
   // exponentials, packs and P V products are skipped; the result is bit for bit the one of the full computation.
   auto compute_s = [&](f32x16 (&sa)[2], const char* Ks, bool both_subs) {
 #pragma unroll
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void attn_prefill_dma_kernel(const AttnK p) {
     const char* Kn = smem + (buf ^ 1) * C::BUF;  // PIPE: K(t+1) (stale but finite data after the last tile; result unused)
 
     // (PIPE keeps the full computation: its S runs one tile ahead)
-    const bool both = PIPE || !(p.skip_dead & 1) || kv0 + 32 < kv_len;
+    const bool both = PIPE || !(p.skip_dead & 1) || kv0 + 32 < kv_end;  // (kv_end <= kv_len: keys past it are visible to no row of this block)
     // A wave whose 32 query rows all lie past q_len (the fourth wave of the last query block: 729 / 735 rows = 5 blocks of 128 +
     // 89 / 95 rows) stores nothing: it keeps its share of the LDS-DMA stream and the barriers and skips the arithmetic, which
     // leaves its SIMD to the other workgroups' waves.

@@ -749,12 +749,13 @@ def test_attention_prefill_e4m3_output_equals_quantise_pass(lib, hd, t):
             assert torch.equal(o_b, o)
 
 
-@pytest.mark.parametrize("hd,t,tq,pos", [(72, 729, 729, 0), (64, 735, 735, 0), (64, 730, 5, 725), (64, 97, 97, 0), (72, 96, 96, 0), (64, 65, 65, 0), (64, 33, 33, 0)])
+@pytest.mark.parametrize("hd,t,tq,pos", [(72, 729, 729, 0), (64, 735, 735, 0), (64, 730, 5, 725), (64, 730, 10, 700), (64, 97, 97, 0), (72, 96, 96, 0), (64, 65, 65, 0), (64, 33, 33, 0)])
 def test_attention_dead_half_tile_skip_is_exact(lib, hd, t, tq, pos):
     """Round 5: when at most 32 keys of the LAST 64-key tile exist, the kernel skips the tile's second half (its scores are -inf,
     its probabilities exactly 0, its contributions exact zeros).  Same bits as the full computation -- for lengths that end in the
     first half of a tile (729, 735, 97, 65: the skip fires), exactly at the half (96), in the second half (33 + ...: no skip), with
-    the prefix-LM rule and a causal tail.  Second switch of the same kind: a wave whose 32 query rows all lie past q_len skips its
+    the prefix-LM rule and a causal tail (730 keys, 10 causal queries at positions 700..709: the bound is what the block's last row
+    may see, not kv_len).  Second switch of the same kind: a wave whose 32 query rows all lie past q_len skips its
     arithmetic.  Every combination of the two (3 = default, 0 = round 4's kernel, 1, 2) gives the same bits."""
     b, h = 2, 3
     q, k, v = randn(b, tq, h, hd, seed=30), randn(b, h, t, hd, seed=31), randn(b, h, t, hd, seed=32)

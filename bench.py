@@ -111,6 +111,30 @@ def selftest_dist(args):
         torch.distributed.destroy_process_group()
 
 
+def decode_gemm_trace_figure(args):
+    """The decode-regime GEMMs of one token from the committed rocprofv3 kernel trace of an eager B = 64 step
+    (profiles/r05_eager_step_timeline.txt, tools/gpu_r5_eager_step_timeline.sh): a HIP-event bracket around a ~20-us launch contains
+    the events' own cost, a kernel trace does not -- the live `achieved` above understates these launches by ~15 %.  None when the
+    file is absent or the run is not the configuration it was taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_eager_step_timeline.txt")
+    if args.model != "2b" or args.batch != 64 or not os.path.isfile(path):
+        return None
+    import re
+
+    us = {}
+    for line in open(path):
+        m = re.search(r"(gemm_bf16_kernel<64, 64, 2, 1, (\d)|gemm_pair_kernel<64, 64).*n=\s*(\d+)\s+avg=\s*([0-9.]+) us", line)
+        if m:
+            us["pair" if m.group(1).startswith("gemm_pair") else ("qkv_fc1" if m.group(2) == "1" else "lm_head")] = float(m.group(4))
+    if set(us) != {"pair", "qkv_fc1", "lm_head"}:
+        return None
+    n_layers, token_bytes = 24, 2.627e9
+    t = (n_layers * (us["qkv_fc1"] + us["pair"]) + us["lm_head"]) * 1e-6
+    return {"source": "profiles/r05_eager_step_timeline.txt (rocprofv3 --kernel-trace of one eager step, committed)",
+            "us_per_launch": us, "ms_per_token": t * 1e3, "achieved": token_bytes / t / 1e9, "unit": "GB/s", "frac": token_bytes / t / 8e12,
+            "note": "a HIP-event bracket around a ~20-us launch contains the events' own cost; the kernel trace does not"}
+
+
 def _one_numa_node_physical_cores():
     """The logical CPUs this process may use, narrowed to ONE NUMA node and one hardware thread per core (Linux sysfs; anything
     unreadable -> the process's own affinity mask unchanged).  Returns (cpus, description)."""
@@ -806,6 +830,7 @@ def main():
             "achieved": stream_gbs if n1.value else None, "peak": 8000.0, "unit": "GB/s",
             "frac": stream_gbs / 8000.0 if n1.value else None, "launches": int(n1.value),
             "share_of_step": (ms1.value * 1e-3) / step_gpu_s if step_gpu_s > 0 and n1.value else None,
+            "kernel_trace": decode_gemm_trace_figure(args),
         },
         "phase_ms": phase_ms,
     }

@@ -112,7 +112,11 @@ typedef struct {
  *                     (16x16x32 MFMAs).  The two families sum K in different associations: equal to fp32 rounding of the
  *                     accumulator, not bitwise -- so a row's bits can depend on how many rows travel with it.
  *   MD_TILE_PINNED    the tile config is a function of the layer (n, k) alone, never of m: every launch of more than 64
- *                     rows takes the 256x256 kernel, so a sequence gets the same bits alone and in any batch.
+ *                     rows takes the 256x256 kernel, so a sequence gets the same bits alone and in any batch.  That
+ *                     kernel addresses a launch with 32-bit byte offsets (m * lda * 2 < 4 GiB, (m + 256) * ldc * 2 <
+ *                     0xfffff000: ~150 000 rows of the 2B fused qkv|fc1 layer); a larger launch is cut into row blocks
+ *                     of the same kernel (same bits), and one that cannot be cut -- a broadcast residual
+ *                     (res_row_mod != 0), the RoPE epilogue -- returns MD_ERR_UNSUPPORTED instead of changing family.
  * md_vit_model.tile_policy / md_text_model.tile_policy apply it to every GEMM of md_vit_encode / md_vision_project* /
  * md_text_forward* / md_lm_head / md_decode_step made with that struct.  Launches of <= 64 rows (the decode regime) are
  * not affected: they always take the split-K weight-streaming configs. */

@@ -819,7 +819,36 @@ md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse*
   k.slabs = nullptr;
   k.tickets = nullptr;
   const bool forced = knobs().tile >= 0;
-  if (tile == 20 && !md_gemm_w4_takes(k, a->epilogue)) tile = 11;
+  if (tile == 20 && !md_gemm_w4_takes(k, a->epilogue)) {
+    if (a->tile_policy != MD_TILE_PINNED) {
+      tile = 11;
+    } else {
+      // MD_TILE_PINNED promises that the tile config is a function of the layer alone; the four-wave kernel's 32-bit offsets
+      // bound the ROWS of a launch (M * lda * 2 < 4 GiB, (M + 256) * ldc * 2 < 0xfffff000: ~150 k rows of the 2B fused qkv|fc1
+      // layer).  Falling back to the 32x32x16 family here would give a very large batch other bits than the same sequence
+      // alone (advisor, round 5): the launch is cut into row blocks the kernel accepts -- rows are independent, so the bits
+      // are those of one launch -- and what cannot be cut (a broadcast residual, the RoPE epilogue) is refused loudly.
+      if (rf != nullptr || (a->epilogue == MD_EPI_RESIDUAL && a->res_row_mod != 0) || k.K % 64 != 0 ||
+          (uint64_t)k.n_pad * (uint64_t)k.ldw * 2 >= (1ull << 32))
+        return MD_ERR_UNSUPPORTED;
+      uint64_t rows = (1ull << 32) / ((uint64_t)k.lda * 2) - 1;
+      rows = std::min<uint64_t>(rows, 0xfffff000ull / ((uint64_t)k.ldc * 2) - 257);
+      if (a->epilogue == MD_EPI_RESIDUAL) rows = std::min<uint64_t>(rows, 0xfffff000ull / ((uint64_t)k.ldr * 2) - 257);
+      rows = rows / 256 * 256;
+      if (rows < 256 || rows >= (uint64_t)a->m) return MD_ERR_UNSUPPORTED;
+      for (int64_t r0 = 0; r0 < a->m; r0 += (int64_t)rows) {
+        md_gemm_args blk = *a;
+        blk.m = (int32_t)std::min<int64_t>((int64_t)rows, a->m - r0);
+        blk.a = (const char*)a->a + r0 * a->lda * 2;
+        blk.c = (char*)a->c + r0 * a->ldc * 2;
+        if (a->r) blk.r = (const char*)a->r + r0 * a->ldr * 2;
+        if (blk.m <= 64) blk.splitk_ws = nullptr;  // a short last block: no in-launch split-K (another K association)
+        const md_status st = gemm_dispatch(&blk, stream, nullptr);
+        if (st != MD_OK) return st;
+      }
+      return MD_OK;
+    }
+  }
   if (rf != nullptr) {
     // RoPE + KV write in the epilogue: four-wave kernel only, [q | k | v] sections of n_heads x 64 columns ending where the
     // GELU columns start, slab offsets in 32 bits

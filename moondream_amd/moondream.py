@@ -514,6 +514,8 @@ class MoondreamModel:
         tc = self.config.text
         kind = classify_attn_mask(attn_mask, pos_ids, tc.prefix_attn, tc.max_context)
         pos0 = int(pos_ids.reshape(-1)[0])
+        if attn_mask is None and pos0 < tc.prefix_attn:
+            kind = MASK_PREFIX_LM  # None = the prefix-LM buffer's slice (moondream.py:303-304): same check as an explicit one
         if kind == MASK_PREFIX_LM and pos0 + t < tc.prefix_attn:
             # such a slice lets its rows see keys [pos0 + t, prefix) that this pass does not write; the library reads keys
             # [0, pos0 + t) only.  The reference always prefills the whole prefix in one pass (moondream.py:254-258).
@@ -604,11 +606,20 @@ class MoondreamModel:
                     else:
                         expand += list(range(len(uniq), len(uniq) + c.shape[0]))
                         uniq.extend(c[k : k + 1] for k in range(c.shape[0]))
-                host2, token2 = self._pinned_crops(len(uniq), (v.crop_size, v.crop_size, 3))
-                np.concatenate(uniq, axis=0, out=host2)
-                dev_crops = self._upload_pinned(host2, token2)
-                self._release_pinned(token)
+                # ownership (advisor, round 5): from here this block owns the chunk's buffer (``token``: popped from ``staged``,
+                # so the drain no longer releases it) and the second buffer (``token2``) until the upload has taken it over;
+                # whatever raises in between, both go back exactly once
                 staged.pop(0)
+                try:
+                    host2, token2 = self._pinned_crops(len(uniq), (v.crop_size, v.crop_size, 3))
+                    try:
+                        np.concatenate(uniq, axis=0, out=host2)
+                        dev_crops = self._upload_pinned(host2, token2)
+                    except BaseException:
+                        self._release_pinned(token2)
+                        raise
+                finally:
+                    self._release_pinned(token)
                 f = self._vit_run(dev_crops, _lib.MD_CROPS_U8_HWC)
                 if len(expand) != dev_crops.shape[0]:
                     f = f[torch.tensor(expand, dtype=torch.int64, device=self._device)]

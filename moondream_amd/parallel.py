@@ -40,6 +40,25 @@ def _default_model_factory(config, state_dict, device, **kw):
     return MoondreamModel(config, state_dict, device=device, **kw)
 
 
+def pad_id_rows(ids: Sequence[Sequence[int]], width: int) -> torch.Tensor:
+    """Ragged id lists -> int32 [len(ids), width], rows padded with -1 (host tensor)."""
+    out = torch.full((len(ids), int(width)), -1, dtype=torch.int32)
+    for r, row in enumerate(ids):
+        n = len(row)
+        if n > width:
+            raise ValueError(f"sequence {r} has {n} ids, more than the block width {width}")
+        if n:
+            out[r, :n] = torch.as_tensor(list(row), dtype=torch.int32)
+    return out
+
+
+def strip_id_padding(blocks: Optional[Sequence[torch.Tensor]]) -> Optional[List[List[int]]]:
+    """The blocks ``batch_generate_ids_pipelined`` yields on rank 0 -> the global ragged id lists (image order)."""
+    if blocks is None:
+        return None
+    return [[int(t) for t in row if t >= 0] for b in blocks for row in b.tolist()]
+
+
 class DataParallelEngine:
     """One instance per rank.  ``weights_file`` / ``state_dict`` are read on rank 0 only (other ranks may pass None);
     ``state_dict_fn(device)`` instead builds the checkpoint on EVERY rank at once (a synthetic or locally cached checkpoint:
@@ -213,9 +232,13 @@ class DataParallelEngine:
         """Generator: the two-stream pipelined engine of the model (encode of batch k+1 under the decode of batch k) over
         THIS rank's batches (``local_batches``: (images, prompt ids) per step, already this rank's block of an
         ``n_total``-image global batch); yields per step the list of every rank's int32 id block on rank 0 (rank order =
-        image order), None elsewhere.  Every step's gather completes inside the step."""
+        image order), None elsewhere.  Every step's gather completes inside the step.
+
+        A block is int32 [B_rank, max_tokens] ALWAYS: sequences that stopped at an EOS (``ignore_eos=False``) are ragged on a
+        rank and differently long across ranks, and a gather needs the same shape everywhere without a size exchange per
+        step -- rows are padded with -1 (never a token id) to ``max_tokens``; ``strip_id_padding`` cuts them again."""
         for ids in self.model.batch_generate_ids_pipelined(local_batches, max_tokens=max_tokens, ignore_eos=ignore_eos):
-            yield self.gather_id_blocks(torch.tensor(ids, dtype=torch.int32), n_total)
+            yield self.gather_id_blocks(pad_id_rows(ids, max_tokens), n_total)
 
     def _strings(self, fn_name: str, images: Sequence, texts: Optional[Sequence], local: bool, **kw) -> Optional[List[Any]]:
         mine_img, _ = self._mine(images, local)

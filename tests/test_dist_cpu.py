@@ -121,8 +121,9 @@ class _StubModel:
         return [[self.k + im + p[0] + t for t in range(1 + im % 3)][:max_tokens] for im, p in zip(images, prompts)]  # ragged
 
     def batch_generate_ids_pipelined(self, batches, max_tokens=4, ignore_eos=False):
+        # EOS-truncated like MoondreamModel._collect with ignore_eos=False: ragged on a rank, and the longest row differs by rank
         for images, prompts in batches:
-            yield [[self.k + im + t for t in range(max_tokens)] for im in images]
+            yield [[self.k + im + t for t in range(max_tokens if ignore_eos else 1 + im % max_tokens)] for im in images]
 
     def batch_caption(self, images, length="normal", settings=None):
         return [f"{length}:{self.k + im}" for im in images]
@@ -163,7 +164,11 @@ def _engine_worker(rank, world, port, out_dir, weights_path, backend="gloo", dev
     det = eng.batch_detect(images, ["cat"] * n)
     pts = eng.batch_point(images, ["cat"] * n)
     steps = list(eng.batch_generate_ids_pipelined((([images[i] for i in mine], [prompts[i] for i in mine]) for _ in range(2)), n_total=n,
-                                                  max_tokens=3))
+                                                  max_tokens=3, ignore_eos=True))
+    # the default (stop at EOS): ragged rows on a rank, unequal longest row across ranks (rank 1's block of 3 images at
+    # max_tokens 5 never reaches 5 ids) -- every block is [B_rank, max_tokens] padded with -1 (advisor, round 5)
+    ragged = list(eng.batch_generate_ids_pipelined((([images[i] for i in mine], [prompts[i] for i in mine]) for _ in range(2)), n_total=n,
+                                                   max_tokens=5))
     assert eng.ranks_seen() == world and eng.max_over_ranks(float(rank)) == float(world - 1)
     # fewer items than ranks: the last rank's shard is empty and still takes part in every collective
     one = eng.batch_generate_ids(images[:1], prompts[:1], max_tokens=4)
@@ -181,9 +186,13 @@ def _engine_worker(rank, world, port, out_dir, weights_path, backend="gloo", dev
         assert pts == [{"points": [{"x": float(i)}]} for i in range(n)]
         for blocks in steps:
             assert torch.cat(blocks, 0).tolist() == [[1000 + i + t for t in range(3)] for i in range(n)]
+        from moondream_amd.parallel import strip_id_padding
+        for blocks in ragged:
+            assert all(b.shape[1] == 5 and b.dtype == torch.int32 for b in blocks)
+            assert strip_id_padding(blocks) == [[1000 + i + t for t in range(1 + i % 5)] for i in range(n)]
         open(os.path.join(out_dir, "engine_ok"), "w").write("1")
     else:
-        assert got is None and got_local is None and caps is None and det is None and steps == [None, None]
+        assert got is None and got_local is None and caps is None and det is None and steps == [None, None] and ragged == [None, None]
     eng.close()
 
 

@@ -155,6 +155,34 @@ def test_tile_policy_is_a_per_call_field(lib, force_tile):
     assert lib.md_gemm_bf16(C.byref(bad), stream()) == 1  # MD_ERR_INVALID_ARG
 
 
+def test_pinned_policy_cuts_an_oversized_launch_into_row_blocks_instead_of_changing_kernel(lib):
+    """The four-wave kernel addresses C with 32-bit byte offsets ((m + 256) * ldc * 2 < 0xfffff000).  Under MD_TILE_PINNED a
+    launch beyond that used to fall back SILENTLY to the 32x32x16 family -- other bits than the same row in a small launch
+    (advisor, round 5).  Now it is cut into row blocks of the same kernel (bit-identical to a compact launch of the same rows);
+    what cannot be cut -- a broadcast residual -- is refused with MD_ERR_UNSUPPORTED; MD_TILE_BY_SHAPE keeps its fallback."""
+    k, n, m = 512, 256, 20000
+    ldc = 131072                                   # (m + 256) * ldc * 2 = 5.3 GB of C address span -> two row blocks
+    w, b = randn(n, k, scale=1 / math.sqrt(k), seed=61), randn(n, scale=0.1, seed=62)
+    lin = PackedLinear(w, b, "cuda")
+    a = randn(m, k, seed=63)
+    compact = gemm(lib, a, lin, tile_policy=_lib.MD_TILE_PINNED)
+    wide = torch.empty(m, ldc, dtype=BF16, device="cuda")
+    got = gemm(lib, a, lin, out=wide[:, :n], tile_policy=_lib.MD_TILE_PINNED)
+    assert got.stride(0) == ldc and torch.equal(got, compact)
+    res = randn(m, n, seed=64)
+    got_r = gemm(lib, a, lin, epi=_lib.MD_EPI_RESIDUAL, r=res, out=wide[:, :n], tile_policy=_lib.MD_TILE_PINNED)
+    assert torch.equal(got_r, gemm(lib, a, lin, epi=_lib.MD_EPI_RESIDUAL, r=res, tile_policy=_lib.MD_TILE_PINNED))
+    st = lin.struct()
+    pos = randn(729, n, seed=65)
+    args = _lib.MdGemmArgs(a.data_ptr(), a.stride(0), st, wide.data_ptr(), ldc, pos.data_ptr(), pos.stride(0), 729, m,
+                           _lib.MD_EPI_RESIDUAL, 0, 0, None, 0, _lib.MD_TILE_PINNED)
+    assert lib.md_gemm_bf16(C.byref(args), stream()) == 4  # MD_ERR_UNSUPPORTED
+    by_shape = gemm(lib, a, lin, out=wide[:, :n], tile_policy=_lib.MD_TILE_BY_SHAPE)   # still served (another MFMA family)
+    compare("by-shape fallback vs pinned blocks", by_shape, compact, 3e-4, 2e-2)
+    del wide
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("m", [64, 33, 1])
 def test_decode_regime_configs_agree_bitwise(lib, m):
     """Decode regime (m <= 64): every 64 x 64 config -- 16 (two compute waves + two DMA-only helpers), 17 (round 5: FOUR compute

@@ -98,7 +98,7 @@ def run_reference_caption(model, ref_md, image, prompt_ids, max_tokens):
         enc = model.encode_image(Image.fromarray(image, "RGB"))
         t_enc = time.perf_counter() - t0
         model.load_encoded_image(enc)
-        toks = torch.tensor([prompt_ids])
+        toks = torch.tensor([prompt_ids], device=model.device)
         t0 = time.perf_counter()
         text = "".join(
             model._generate_answer(toks, enc.pos, {"temperature": 0, "max_tokens": max_tokens})

@@ -76,10 +76,13 @@ class HfMoondream:
         return answer
 
     def batch_answer(self, images: Sequence, prompts: Sequence[str], tokenizer=None, **kwargs) -> List[str]:
-        """reference: hf_moondream.py:99-103 (a sequential loop there).  Greedy, lockstep; questions of
-        different token counts share one decode batch."""
+        """reference: hf_moondream.py:99-103 -- a sequential loop of ``query`` calls at the model's DEFAULT sampling settings
+        (temperature 0.5, top_p 0.3: moondream.py:50-53).  Here: one lockstep decode over all pairs (questions of different
+        token counts share it), every sequence sampling with the same rule and its own uniforms (round 6; rounds 1-5 forced
+        greedy).  ``settings={"temperature": 0}`` is the greedy form; ``max_new_tokens`` bounds the answers."""
         self._setup_caches()
-        settings = {"max_tokens": kwargs.get("max_new_tokens", kwargs.get("max_tokens", 256))}
+        settings = dict(kwargs.get("settings") or {})
+        settings.setdefault("max_tokens", kwargs.get("max_new_tokens", kwargs.get("max_tokens", 256)))
         return [a.strip() for a in self.model.batch_query(list(images), list(prompts), settings)]
 
     def _unsupported_exception(self):

@@ -882,13 +882,15 @@ class MoondreamModel:
 
     def _decode_greedy(self, first: torch.Tensor, pos: Union[int, Sequence[int]], max_tokens: int, suppress_id: int,
                        slot0: int = 0, eos_id: Optional[int] = None, check_every: int = 16,
-                       lora: Optional[PackedLora] = None, allow_b1: bool = True) -> torch.Tensor:
+                       lora: Optional[PackedLora] = None, allow_b1: bool = True, temperature: float = 0.0, top_p: float = 0.0,
+                       generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """``_decode_greedy_impl`` plus the safety net of the persistent single-sequence kernel: its software grid barriers
         need every workgroup resident; if one times out (the GPU was shared with another persistent kernel) the kernel
         raises an error word and finishes with garbage.  That state is fully re-initialised by decoding the same tokens
         again (K / V rows at positions >= ``pos``, the id history, the position buffer), so the call is repeated on the
         batched kernels and the persistent kernel is switched off for this model."""
-        hist = self._decode_greedy_impl(first, pos, max_tokens, suppress_id, slot0, eos_id, check_every, lora, allow_b1)
+        hist = self._decode_greedy_impl(first, pos, max_tokens, suppress_id, slot0, eos_id, check_every, lora, allow_b1,
+                                        temperature, top_p, generator)
         if self._b1_used:
             torch.cuda.current_stream(self._device).synchronize()
             if int(self._b1_sync[64 * 11]) != 0:
@@ -905,8 +907,12 @@ class MoondreamModel:
 
     def _decode_greedy_impl(self, first: torch.Tensor, pos: Union[int, Sequence[int]], max_tokens: int, suppress_id: int,
                             slot0: int = 0, eos_id: Optional[int] = None, check_every: int = 16,
-                            lora: Optional[PackedLora] = None, allow_b1: bool = True) -> torch.Tensor:
-        """Device-resident greedy loop: returns int32 [steps+1, B] (row 0 = ``first``).
+                            lora: Optional[PackedLora] = None, allow_b1: bool = True, temperature: float = 0.0,
+                            top_p: float = 0.0, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Device-resident decode loop: returns int32 [steps+1, B] (row 0 = ``first``).  ``temperature`` 0: greedy.  Otherwise every
+        step draws each sequence's token with the reference's rule (moondream.py:521-528: softmax(logits / T), _apply_top_p,
+        multinomial) from the step's own logits on the device (md_sample_top_p), with one uniform per (step, sequence) taken
+        UP FRONT from torch's generator -- no host round trip per token, replayable from a hipGraph.
         reference: the generator of moondream.py:471-530 without its per-token host sync.
         ``pos`` is the position of the next token, one int or one per sequence (sequences whose
         prompts differ in length decode in the same lockstep batch).
@@ -927,12 +933,14 @@ class MoondreamModel:
         ws = self._workspace(need, 2)
         kv = self._kv_struct(slot0)
         pos_base = self._h2d(torch.tensor(pos_list, dtype=torch.int32))
+        sample = temperature != 0
+        uniforms = (torch.rand(max_tokens, b, device=self._device, dtype=torch.float32, generator=generator) if sample else None)
 
         # one sequence, greedy, no side path: the whole step as ONE persistent launch (csrc/decode_b1.hip) when the library
         # says this model / cache / device fits its static limits and its grid can be co-resident; anything else decodes on
         # the batched kernels.  Never from the pipelined engine (allow_b1 = False): a second stream's persistent GEMMs
         # could keep workgroups of the grid off the chip and its software barriers would time out.
-        b1 = (b == 1 and allow_b1 and self.single_sequence_kernel and lora is None and not bool(self.w.text.fp8)
+        b1 = (b == 1 and allow_b1 and not sample and self.single_sequence_kernel and lora is None and not bool(self.w.text.fp8)
               and bool(self.lib.md_decode_step_b1_supported(C.byref(self.w.text), C.byref(kv))))
         self._b1_used = b1
         if b1:
@@ -941,7 +949,7 @@ class MoondreamModel:
             need = max(need, self.lib.md_decode_step_b1_workspace_bytes(C.byref(self.w.text)))
             ws = self._workspace(need, 2)
 
-        def one_step(tok_in, tok_out, pos_buf):
+        def one_step(tok_in, tok_out, pos_buf, u_row=None):
             if b1:
                 _lib.check(
                     self.lib.md_decode_step_b1(
@@ -959,6 +967,14 @@ class MoondreamModel:
                 ),
                 "md_decode_step",
             )
+            if sample:  # the step left its logits [B, V] in ``logits``: draw from them instead of the argmax it wrote
+                _lib.check(
+                    self.lib.md_sample_top_p(
+                        logits.data_ptr(), logits.stride(0), b, t.vocab_size, suppress_id, float(temperature), float(top_p),
+                        u_row.data_ptr(), tok_out.data_ptr(), None, 0, self._stream(),
+                    ),
+                    "md_sample_top_p",
+                )
 
         def all_done(upto):
             return eos_id is not None and bool((hist[: upto + 1] == eos_id).any(dim=0).all())
@@ -971,7 +987,10 @@ class MoondreamModel:
             while steps < max_tokens:
                 emb = self._embed(hist[steps].reshape(b, 1))
                 h = self._text_forward(emb, pos_h, slot0, pos_dev=pos_t, lora=lora)
-                hist[steps + 1] = self._pick(self._lm_head(h), 0.0, 0.0, suppress_id)
+                if sample:
+                    hist[steps + 1] = self._pick(self._lm_head(h), temperature, top_p, suppress_id, generator)
+                else:
+                    hist[steps + 1] = self._pick(self._lm_head(h), 0.0, 0.0, suppress_id)
                 pos_t.add_(1)
                 pos_h = [p + 1 for p in pos_h]
                 steps += 1
@@ -981,7 +1000,7 @@ class MoondreamModel:
         if not self.use_graphs:
             pos_t = pos_base.clone()
             while steps < max_tokens:
-                one_step(hist[steps], hist[steps + 1], pos_t)
+                one_step(hist[steps], hist[steps + 1], pos_t, uniforms[steps] if sample else None)
                 steps += 1
                 if check_every and steps % check_every == 0 and all_done(steps):
                     break
@@ -994,29 +1013,34 @@ class MoondreamModel:
             # a graph is replayed only on the stream (context) it was captured for: the pipelined engine's
             # decode stream and the default stream each keep their own captures
             key = ("decode", b, slot0, n, suppress_id, ws.data_ptr(), self._kv_k.data_ptr(), logits.data_ptr(),
-                   torch.cuda.current_stream(self._device).cuda_stream, b1)
+                   torch.cuda.current_stream(self._device).cuda_stream, b1, float(temperature), float(top_p))
             entry = self._graphs.get(key)
             if entry is None:
                 buf = torch.zeros(n + 1, b, dtype=torch.int32, device=self._device)
                 pos_buf = torch.zeros(b, dtype=torch.int32, device=self._device)
+                u_buf = torch.zeros(n, b, dtype=torch.float32, device=self._device)
                 # eager warm-up on scratch state is not possible (KV side effects), so the
                 # first chunk of a new shape runs eagerly and the graph is captured afterwards
                 buf[0] = hist[steps]
                 pos_buf.copy_(pos_base + steps)
+                if sample:
+                    u_buf.copy_(uniforms[steps : steps + n])
                 for i in range(n):
-                    one_step(buf[i], buf[i + 1], pos_buf)
+                    one_step(buf[i], buf[i + 1], pos_buf, u_buf[i])
                 hist[steps + 1 : steps + n + 1] = buf[1:]
                 torch.cuda.synchronize(self._device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     for i in range(n):
-                        one_step(buf[i], buf[i + 1], pos_buf)
+                        one_step(buf[i], buf[i + 1], pos_buf, u_buf[i])
                 # the capture did not execute; nothing to undo
-                self._graphs[key] = (g, buf, pos_buf)
+                self._graphs[key] = (g, buf, pos_buf, u_buf)
             else:
-                g, buf, pos_buf = entry
+                g, buf, pos_buf, u_buf = entry
                 buf[0] = hist[steps]
                 pos_buf.copy_(pos_base + steps)
+                if sample:
+                    u_buf.copy_(uniforms[steps : steps + n])
                 g.replay()
                 hist[steps + 1 : steps + n + 1] = buf[1:]
             steps += n
@@ -1053,13 +1077,15 @@ class MoondreamModel:
         return out
 
     def _prepare_sequences(self, images, prompts: Sequence[Sequence[int]], mark=None, lora: Optional[PackedLora] = None,
-                           fuse: bool = False, logits_capture: Optional[torch.Tensor] = None):
+                           fuse: bool = False, logits_capture: Optional[torch.Tensor] = None, sampler=None):
         """Everything before the first generated token, for B (image, prompt-ids) pairs: sequences are
         placed in KV slots in order of prompt length (stable), so that every group of equal-length
         prompts occupies a contiguous slot range; raw images are encoded together and prefilled
         straight into their slots, EncodedImages are copied into theirs; one prompt prefill per
         distinct length.  Returns (order, first int32 [B], hidden_last [B, D], next_pos list) in slot
-        order; ``order[slot]`` is the caller's index.  Must run under torch.inference_mode()."""
+        order; ``order[slot]`` is the caller's index.  ``sampler`` = (temperature, top_p, suppress_id, generator) draws the first token
+        as the reference's _prefill_prompt does (moondream.py:313-318; suppress_id -1 there); None = argmax.  Must run under
+        torch.inference_mode()."""
         mark = mark or (lambda name: None)
         b = len(images)
         self._select_kernels(b)
@@ -1098,7 +1124,7 @@ class MoondreamModel:
                 lg = self._lm_head(hidden)
                 if logits_capture is not None:
                     logits_capture[g0:g1] = lg
-                first[g0:g1] = self._pick(lg, 0.0, 0.0)
+                first[g0:g1] = self._pick(lg, 0.0, 0.0) if sampler is None else self._pick(lg, *sampler)
                 hidden_last[g0:g1] = hidden[:, -1, :]
                 next_pos[g0:g1] = [x.shape[1]] * (g1 - g0)
                 g0 = g1
@@ -1134,7 +1160,7 @@ class MoondreamModel:
             logits, hidden, p1 = self._prefill_prompts(prompts[g0:g1], pos, g0, lora=lora)
             if logits_capture is not None:
                 logits_capture[g0:g1] = logits
-            first[g0:g1] = self._pick(logits, 0.0, 0.0)
+            first[g0:g1] = self._pick(logits, 0.0, 0.0) if sampler is None else self._pick(logits, *sampler)
             hidden_last[g0:g1] = hidden[:, -1, :]
             next_pos[g0:g1] = [p1] * (g1 - g0)
             g0 = g1
@@ -1149,8 +1175,18 @@ class MoondreamModel:
         eos_id: Optional[int] = None,
         ignore_eos: bool = False,
         variant: Optional[str] = None,
+        temperature: float = 0.0,
+        top_p: float = DEFAULT_TOP_P,
+        generator: Optional[torch.Generator] = None,
     ) -> List[List[int]]:
-        """Greedy token ids for B (image, prompt-ids) pairs, decoded in lockstep.
+        """Token ids for B (image, prompt-ids) pairs, decoded in lockstep; greedy by default.
+
+        ``temperature`` > 0 (round 6): every sequence SAMPLES each of its tokens -- the first from the prompt pass's logits,
+        the rest inside the lockstep loop -- with the reference's rule (softmax(logits / T), ``_apply_top_p``, multinomial:
+        moondream.py:313-318, 521-528) on the device, one uniform per (step, sequence) from ``generator``; this is what the
+        reference's loop of ``query`` / ``caption`` calls does at its DEFAULT settings (temperature 0.5, top_p 0.3:
+        moondream.py:50-53; hf_moondream.py:99-103).  Sequences are statistically independent (own uniforms), not
+        reproducible against torch.multinomial's stream.  The greedy contract below is the ``temperature = 0`` case.
 
         Defined as: element i is what the sequential path (encode_image ->
         load_encoded_image -> _generate_answer with temperature 0) returns for
@@ -1184,11 +1220,13 @@ class MoondreamModel:
 
         lora = self._lora({"variant": variant})
         with torch.inference_mode():
-            order, first, _, next_pos = self._prepare_sequences(list(images), prompts, mark, lora, fuse=True)
+            sampler = None if temperature == 0 else (float(temperature), float(top_p), -1, generator)
+            order, first, _, next_pos = self._prepare_sequences(list(images), prompts, mark, lora, fuse=True, sampler=sampler)
             b = len(order)
             stop = None if ignore_eos else eos
             hist = self._decode_greedy(first, next_pos if len(set(next_pos)) > 1 else next_pos[0], max_tokens,
-                                       tk.answer_id, 0, stop, lora=lora)
+                                       tk.answer_id, 0, stop, lora=lora, temperature=float(temperature), top_p=float(top_p),
+                                       generator=generator)
             mark("decode")
             cols = hist.t().tolist()
             if b == 1:
@@ -1344,32 +1382,41 @@ class MoondreamModel:
             self._check_b1_barriers()
         return [self._truncate(cols[i], eos, max_tokens) for i in range(b)]
 
+    @staticmethod
+    def _sampling_kwargs(settings: Optional[dict]) -> dict:
+        """``settings`` of the string API -> keyword arguments of ``batch_generate_ids``, with the REFERENCE'S defaults
+        (moondream.py:50-53, read at :447-457): max_tokens 768, temperature 0.5, top_p 0.3.  ``settings["generator"]`` (an
+        extension) seeds the draws; ``{"temperature": 0}`` is greedy."""
+        st = settings or {}
+        return dict(max_tokens=st.get("max_tokens", DEFAULT_MAX_TOKENS), variant=st.get("variant"),
+                    temperature=st.get("temperature", DEFAULT_TEMPERATURE), top_p=st.get("top_p", DEFAULT_TOP_P),
+                    generator=st.get("generator"))
+
     def batch_caption(self, images, length: str = "normal", settings: Optional[dict] = None) -> List[str]:
         tpl = self.config.tokenizer.templates["caption"]
         if tpl is None:
             raise NotImplementedError("Model does not support captioning.")
         if length not in tpl:
             raise ValueError(f"Model does not support caption length '{length}'.")
-        mt = (settings or {}).get("max_tokens", DEFAULT_MAX_TOKENS)
-        ids = self.batch_generate_ids(images, [tpl[length]] * len(images), mt, variant=(settings or {}).get("variant"))
+        ids = self.batch_generate_ids(images, [tpl[length]] * len(images), **self._sampling_kwargs(settings))
         return [self.tokenizer.decode(s) for s in ids]
 
     def batch_query(self, images, questions: Sequence[str], settings: Optional[dict] = None) -> List[str]:
         tpl = self.config.tokenizer.templates["query"]
         if tpl is None:
             raise NotImplementedError("Model does not support querying.")
-        mt = (settings or {}).get("max_tokens", DEFAULT_MAX_TOKENS)
         prompts = [
             list(tpl["prefix"]) + list(self.tokenizer.encode(q).ids) + list(tpl["suffix"]) + list(tpl["suffix"])
             for q in questions
         ]
-        ids = self.batch_generate_ids(images, prompts, mt, variant=(settings or {}).get("variant"))
+        ids = self.batch_generate_ids(images, prompts, **self._sampling_kwargs(settings))
         return [self.tokenizer.decode(s) for s in ids]
 
     def batch_generate(self, images, prompts: Optional[Sequence[str]] = None, settings: Optional[dict] = None) -> List[str]:
-        """BASELINE.json's ``batch_generate``: captions when ``prompts`` is None, else answers
-        (greedy; element i == caption(images[i]) / query(images[i], prompts[i]) at temperature 0: bit for bit under
-        ``set_strict_batch_invariance``, within bf16 accumulation-order noise otherwise -- see ``batch_generate_ids``)."""
+        """BASELINE.json's ``batch_generate``: captions when ``prompts`` is None, else answers, with the reference's sampling
+        settings (``settings``: max_tokens / temperature / top_p / variant; defaults 768 / 0.5 / 0.3 as moondream.py:50-53).
+        At ``{"temperature": 0}`` element i == caption(images[i]) / query(images[i], prompts[i]): bit for bit under
+        ``set_strict_batch_invariance``, within bf16 accumulation-order noise otherwise -- see ``batch_generate_ids``."""
         if prompts is None:
             return self.batch_caption(images, "normal", settings)
         return self.batch_query(images, prompts, settings)

@@ -28,8 +28,22 @@ TEXT_PROJ_GAIN = 1.0
 TEXT_FC2_GAIN = 0.5
 # beta is given for dim 256 and scaled by 16/sqrt(dim) (the planted logit grows like
 # beta*sqrt(dim)); see _plant_lm_head
-PLANT = dict(beta=1.6, c=8.0, s0=0.1)
+PLANT = dict(beta=1.6, c_code=12.0, c_deep=0.8, s0=0.1)
 WTE_STD = 2.5
+
+# ---- round 6: the planted "image code" path (see _plant_code_path) -------------------------------------------------
+# Every synthetic image carries a colour cast: per channel one of four levels of the normalised pixel mean
+# (synthetic_image_array).  2 bits x 3 channels = 64 image classes = a 6-bit code that a few planted weights carry -- through
+# the kernels under test, not around them -- to the last hidden state, where the lm_head pair rows and the region decoders read it.
+CODE_BITS = 6
+CAST_LEVELS = (-0.6, -0.2, 0.2, 0.6)      # normalised ((x / 255 - 0.5) / 0.5) channel means of the four levels
+CAST_NOISE = 0.35                         # amplitude of the uniform pixel noise around the level (no clipping: 0.6 + 0.35 < 1)
+CODE_GAMMA = 8.0                          # ViT protected coordinates: GAMMA x channel mean, and the constant reference GAMMA
+CODE_STEEP = 24.0                         # projector threshold units: K.  u = K x GAMMA x (level - theta) / sigma, sigma ~ 7.3: 5.3 at the nearest threshold (saturated: S = 1.0000 / 0.0000), 26 at the farthest (a bf16 GELU output resolves 1/8 there: +-0.03 of random rounding per token in the code coordinates, averaged away over the 729 keys)
+CODE_RHO = 1.0                            # decoder: V copy gain of the code coordinates
+DEFAULT_CODE = (1, -1, -1, 1, -1, 1)      # the code of "no image": carried by every token embedding
+IMAGE_CODE_AMPLITUDE = 0.5                # an image embedding carries its code as +-0.5 ...
+TEXT_CODE_AMPLITUDE = 0.25                 # ... a token embedding the default code as +-0.25
 
 
 def hash_uniform(n: int, key: int, device="cpu") -> torch.Tensor:
@@ -127,6 +141,7 @@ def synthetic_state_dict(
     ln("text.post_ln", t.dim)
     sd["text.wte"] = _tensor("text.wte", (t.vocab_size, t.dim), WTE_STD, seed, device, dtype)
     if planted:
+        _plant_code_path(sd, config, dtype)
         _plant_lm_head(sd, config, seed, device, dtype, **PLANT)
     else:
         lin("text.lm_head", t.vocab_size, t.dim, gain=1.0)
@@ -145,11 +160,264 @@ def synthetic_state_dict(
         sd["region.size_features"] = _tensor(
             "region.size_features", (2, r.size_feat_dim // 2), 2.0, seed, device, dtype
         )
+        if planted:
+            _plant_region_heads(sd, config, dtype)
     return sd
 
 
-def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c=4.0, s0=0.1):
-    """lm_head with a planted "bigram + context bit" structure.
+def protected_coords(config: MoondreamConfig) -> dict:
+    """Feature indices the planted code path owns.  ViT stream (enc_dim): r, g, b channel means, a constant reference, an
+    always-zero coordinate.  Decoder stream (dim): ``zero`` (always 0: LayerNorm's mean shift is read off it), ``p1`` (the
+    6-bit code as +-1, present at image-token positions only, written by the vision projection and never by a decoder layer),
+    ``p2`` (what the attention of every decoder layer copies of p1 from the image keys, accumulated; read by lm_head and the
+    region decoders), ``flag`` (1.0 where the input embedding of a position came from encode_coordinate / encode_size)."""
+    e, d = config.vision.enc_dim, config.text.dim
+    return {
+        "vit_rgb": [e - 5, e - 4, e - 3], "vit_ref": e - 2, "vit_zero": e - 1,
+        "flag": [d - 16, d - 15], "zero": d - 14, "p1": list(range(d - 12, d - 6)), "p2": list(range(d - 6, d)),
+        "all_text": list(range(d - 16, d)), "all_vit": list(range(e - 5, e)),
+    }
+
+
+def image_code_bits(index: int) -> list:
+    """The 6 code bits (+1 / -1) of synthetic image ``index``: class = index mod 64, two bits per colour channel (level = 2 hi + lo
+    in thermometer-friendly order: level 0 -> (-1, -1), 1 -> (-1, +1), 2 -> (+1, -1), 3 -> (+1, +1))."""
+    levels = image_cast_levels(index)
+    bits = []
+    for lv in levels:
+        bits += [1 if lv >= 2 else -1, 1 if lv in (1, 3) else -1]
+    return bits
+
+
+def image_cast_levels(index: int) -> tuple:
+    """Level (0..3) of the R, G, B colour cast of synthetic image ``index``: the base-4 digits of a fixed permutation of index mod 64."""
+    cls = (int(index) * 37 + 11) % 64
+    return (cls & 3, (cls >> 2) & 3, (cls >> 4) & 3)
+
+
+def _plant_code_path(sd, config, dtype):
+    """Make greedy token ids a WELL-POSED integer output for every synthetic image (round 6).
+
+    Why: a decision taken by the sign of a deep feature <LN(h), r> is ill-posed whenever |feature| is inside the bf16
+    implementation noise of h (relative ~1e-2 after 24 layers: two correct implementations are independent rounding-noise
+    realisations), i.e. for 2-3 % of all decisions whatever the gain -- amplification scales signal and noise alike.  Rounds 1-5
+    therefore compared ids under a measured licence.  Here the member of a token pair is chosen by a DISCRETE property of the
+    image that the network carries with a wide gap, while the deep feature keeps contributing to the logits (c_deep) where the
+    teacher-forced logit comparison sees it:
+
+      * patch embedding (vision.py:67): three rows average the normalised pixels of one colour channel (GAMMA x mean), one row is
+        the constant GAMMA (bias), one is 0.  No ViT block writes to these five coordinates (zero rows in proj / fc2), every block
+        reads them like any other feature; post_ln passes them with weight 1 / bias 0.
+      * vision projection (vision.py:77-89): per channel three threshold units pairs gelu(K u + 1) - gelu(K u - 1) (= 0 or 2 once
+        saturated) with u = (v_c - v_0) - theta (v_ref - v_0): LayerNorm's mean shift cancels against the zero coordinate, its scale
+        against the reference coordinate.  fc2 turns the thermometer code into 6 coordinates of +-0.5 (p1) in every image embedding.
+      * every decoder block: one attention head (l mod n_kv_heads; its query rows are zero, i.e. it attends uniformly) copies
+        RHO (LN(x)[p1] - LN(x)[zero]) into six of its value dims; proj writes them to p2.  What accumulates in p2 at a text
+        position is RHO x sum over layers of the key-average of p1 / row sigma: 729 image keys at amplitude 0.5 against a few text
+        keys at 0.25 (the default code) -> sign = the image's code bit, through the softmax normalisation, the V rows of the KV
+        cache, proj and the residual adds of every layer.  p1 / zero / flag are never written by a block; fc2 does not write p2.
+      * text.post_ln passes p2 and zero with weight 1 / bias 0; _plant_lm_head reads p2[j] - zero.
+    """
+    v, t = config.vision, config.text
+    pc = protected_coords(config)
+    f32 = torch.float32
+
+    def edit(name, fn):
+        w = sd[name].to(f32)
+        fn(w)
+        sd[name] = w.to(dtype)
+
+    # ---- vision tower
+    pd = v.enc_patch_size * v.enc_patch_size  # create_patches: "b c (h p1) (w p2) -> b (h w) (c p1 p2)" -- channel-major
+    def patch_w(w):
+        w[pc["all_vit"]] = 0.0
+        for c, row in enumerate(pc["vit_rgb"]):
+            w[row, c * pd : (c + 1) * pd] = CODE_GAMMA / pd
+    def patch_b(b):
+        b[pc["all_vit"]] = 0.0
+        b[pc["vit_ref"]] = CODE_GAMMA
+    edit("vision.patch_emb.weight", patch_w)
+    edit("vision.patch_emb.bias", patch_b)
+    edit("vision.pos_emb", lambda w: w.__setitem__((Ellipsis, pc["all_vit"]), 0.0))
+    zero_rows = lambda rows: (lambda w: w.__setitem__(rows, 0.0))   # (w[list].zero_() would zero a COPY)
+    for i in range(v.enc_n_layers):
+        for name in ("attn.proj", "mlp.fc2"):
+            edit(f"vision.blocks.{i}.{name}.weight", zero_rows(pc["all_vit"]))
+            edit(f"vision.blocks.{i}.{name}.bias", zero_rows(pc["all_vit"]))
+    edit("vision.post_ln.weight", lambda w: w.__setitem__(pc["all_vit"], 1.0))
+    edit("vision.post_ln.bias", zero_rows(pc["all_vit"]))
+    # projector: the LAST 18 hidden units are the threshold pairs; they read the GLOBAL crop's features (columns [0, enc_dim))
+    thetas = (-0.4, 0.0, 0.4)
+    n_units = 3 * len(thetas) * 2
+    u0 = v.proj_inner_dim - n_units
+    def fc1_w(w):
+        w[u0:] = 0.0
+        for c, col in enumerate(pc["vit_rgb"]):
+            for k, th in enumerate(thetas):
+                for s in range(2):
+                    row = u0 + (c * len(thetas) + k) * 2 + s
+                    w[row, col] = CODE_STEEP
+                    w[row, pc["vit_ref"]] = -CODE_STEEP * th
+                    w[row, pc["vit_zero"]] = -CODE_STEEP * (1.0 - th)
+    def fc1_b(b):
+        for i in range(n_units // 2):
+            b[u0 + 2 * i], b[u0 + 2 * i + 1] = 1.0, -1.0
+    edit("vision.proj_mlp.fc1.weight", fc1_w)
+    edit("vision.proj_mlp.fc1.bias", fc1_b)
+    def fc2_w(w):
+        w[:, u0:] = 0.0          # the threshold units feed the code coordinates only
+        w[pc["all_text"]] = 0.0  # and nothing else writes the protected coordinates of an image embedding
+        for c in range(3):
+            S = lambda k: (u0 + (c * len(thetas) + k) * 2, u0 + (c * len(thetas) + k) * 2 + 1)  # (plus, minus) unit of threshold k
+            hi, lo = pc["p1"][2 * c], pc["p1"][2 * c + 1]
+            # S_k = 0.5 (u+ - u-) in {0, 1};  hi = 2 S_1 - 1 (level >= 2);  lo = 2 (S_0 - S_1 + S_2) - 1 (level 1 or 3)
+            A = IMAGE_CODE_AMPLITUDE
+            w[hi, S(1)[0]], w[hi, S(1)[1]] = A, -A
+            for k, sg in ((0, A), (1, -A), (2, A)):
+                w[lo, S(k)[0]], w[lo, S(k)[1]] = sg, -sg
+    def fc2_b(b):
+        b[pc["all_text"]] = 0.0
+        b[pc["p1"]] = -IMAGE_CODE_AMPLITUDE
+    edit("vision.proj_mlp.fc2.weight", fc2_w)
+    edit("vision.proj_mlp.fc2.bias", fc2_b)
+
+    # ---- decoder
+    def wte(w):
+        w[:, pc["all_text"]] = 0.0
+        # EVERY token embedding carries a DEFAULT code at half the amplitude of an image embedding's: without an image (the
+        # text-only query, moondream.py:564-575) every key holds it, so p2 accumulates it whatever the attention pattern and
+        # the pair decisions stay well-posed there too (they follow the default bits); with an image the 729 image keys
+        # outweigh the few text keys (a text key counts half, and there are 5-64 of them)
+        for j, bit in enumerate(DEFAULT_CODE):
+            w[:, pc["p1"][j]] = TEXT_CODE_AMPLITUDE * bit
+    edit("text.wte", wte)
+    hd = t.dim // t.n_heads
+    group = t.n_heads // t.n_kv_heads
+    q_dim, kv_dim = t.n_heads * hd, t.n_kv_heads * hd
+    for l in range(t.n_layers):
+        p = f"text.blocks.{l}"
+        kvh = l % t.n_kv_heads
+        v_rows = [q_dim + kv_dim + kvh * hd + j for j in range(CODE_BITS)]
+        # the query head that reads those value dims attends UNIFORMLY (q = 0): the text keys of this checkpoint carry larger
+        # k vectors than the image keys and take most of a random head's softmax mass, which would let the default code of
+        # the text tokens (below) outvote the image's; with equal scores the image's 729 keys always outweigh <= 64 text keys
+        q_rows = list(range(kvh * group * hd, (kvh * group + 1) * hd))
+        def qkv_w(w):
+            w[v_rows] = 0.0
+            w[q_rows] = 0.0
+            for j, row in enumerate(v_rows):
+                w[row, pc["p1"][j]] = CODE_RHO
+                w[row, pc["zero"]] = -CODE_RHO
+        edit(p + ".attn.qkv.weight", qkv_w)
+        edit(p + ".attn.qkv.bias", zero_rows(v_rows + q_rows))
+        def proj_w(w):
+            w[pc["all_text"]] = 0.0
+            for j in range(CODE_BITS):
+                w[pc["p2"][j], kvh * group * hd + j] = 1.0   # the first query head that shares kv head kvh
+        edit(p + ".attn.proj.weight", proj_w)
+        edit(p + ".attn.proj.bias", zero_rows(pc["all_text"]))
+        edit(p + ".mlp.fc2.weight", zero_rows(pc["all_text"]))
+        edit(p + ".mlp.fc2.bias", zero_rows(pc["all_text"]))
+        edit(p + ".ln.weight", lambda w: w.__setitem__(pc["all_text"], 1.0))
+        edit(p + ".ln.bias", zero_rows(pc["all_text"]))
+    edit("text.post_ln.weight", lambda w: w.__setitem__(pc["all_text"], 1.0))
+    edit("text.post_ln.bias", zero_rows(pc["all_text"]))
+
+
+REGION_FLAG = 4.0        # value of the flag coordinate in an encode_coordinate / encode_size embedding
+REGION_GATE = 16.0       # gate gain: GATE x FLAG = 64 >> |h[p2]| switches a unit group off
+REGION_MISS = -3.0       # contribution of a unit to the anchors whose bit does NOT match (a match contributes +1)
+REGION_FC2_GAIN = 0.1    # the random part of the decoders' output layer (the planted anchor must stand clear of 1024 such logits)
+COORD_ANCHORS = [32 + 64 * k for k in range(16)]    # coordinate bins the code can select: x = bin / 1024 in (0.03, 0.97)
+SIZE_ANCHORS = [520 + 30 * k for k in range(16)]    # size bins: 2^((bin / 1023) 10 - 10) in (0.034, 0.70)
+
+
+def region_anchor(bits, which: str) -> int:
+    """The bin the planted region heads select for an image with code ``bits`` (+-1 x 6): ``which`` in x_first (object 0: bits
+    0-3), y (bits 2-5), x_later (objects >= 1: bits 1-4), w (bits 0-3), h (bits 2-5); anchor index = sum (bit > 0) << n."""
+    lo = {"x_first": 0, "y": 2, "x_later": 1, "w": 0, "h": 2}[which]
+    k = sum((1 << n) for n in range(4) if bits[lo + n] > 0)
+    return (SIZE_ANCHORS if which in ("w", "h") else COORD_ANCHORS)[k]
+
+
+def _plant_region_heads(sd, config, dtype):
+    """Region decoders whose 1024-bin argmax is a WELL-POSED output (round 6; reference region.py:32-93, loop moondream.py:653-733).
+    With i.i.d. weights the best two of 1024 bins are 0-85 bf16 ulps apart and nothing could be compared at the object level
+    (rounds 2-5: "objects up to the first narrow decision").  Planted:
+
+      * encode_coordinate / encode_size write a FLAG (bias only) into a protected coordinate of the embedding they produce; no
+        decoder layer writes it, so the last hidden state of that position still carries it: the heads know which step they are at
+        (x of the first object: no flag; y: coordinate flag; x of a later object: size flag);
+      * fc1: a pair of units gelu(+h[p2[j]] + gate), gelu(-h[p2[j]] + gate) per code bit and step -- the one whose sign matches the
+        image's code bit is active with value |h[p2[j]]| (the accumulated code amplitude, several units), the other ~0;
+      * fc2: an active unit adds +1 x its value to the 8 of 16 ANCHOR bins whose index has that bit, REGION_MISS x to the other 8:
+        the anchor spelled by four code bits gets 4 |h|, every other anchor <= 0, every non-anchor bin only the (scaled down)
+        random part.  The winner stands ~100 bf16 ulps clear.
+    Objects of an image are therefore a function of its 6 code bits (``region_anchor``), reached through every decoder layer's
+    attention exactly like the token decisions."""
+    t, r = config.text, config.region
+    pc = protected_coords(config)
+    f32 = torch.float32
+    flag_c, flag_s = pc["flag"]
+
+    def edit(name, fn):
+        w = sd[name].to(f32)
+        fn(w)
+        sd[name] = w.to(dtype)
+
+    for enc, flag in (("region.coord_encoder", flag_c), ("region.size_encoder", flag_s)):
+        edit(enc + ".weight", lambda w: w.__setitem__(pc["all_text"], 0.0))
+        def bias(b, flag=flag):
+            b[pc["all_text"]] = 0.0
+            b[flag] = REGION_FLAG
+        edit(enc + ".bias", bias)
+
+    GF = REGION_GATE * REGION_FLAG
+
+    def plant(prefix, groups, n_out_blocks):
+        """groups: (first code bit, output block, anchors, gate) with gate = {flag coordinate: weight} and a bias."""
+        n_units = 8 * len(groups)
+        inner = sd[prefix + ".fc1.weight"].shape[0]
+        u0 = inner - n_units
+        def fc1_w(w):
+            w[u0:] = 0.0
+            for g, (lo, _blk, _anch, gate, _gb) in enumerate(groups):
+                for n in range(4):
+                    for s, sg in enumerate((1.0, -1.0)):
+                        row = u0 + g * 8 + n * 2 + s
+                        w[row, pc["p2"][lo + n]] = sg
+                        for col, gw in gate.items():
+                            w[row, col] = gw
+        def fc1_b(b):
+            for g, (_lo, _blk, _anch, _gate, gb) in enumerate(groups):
+                b[u0 + g * 8 : u0 + g * 8 + 8] = gb
+        def fc2_w(w):
+            w *= REGION_FC2_GAIN
+            w[:, u0:] = 0.0
+            for g, (_lo, blk, anchors, _gate, _gb) in enumerate(groups):
+                for n in range(4):
+                    for s in range(2):
+                        col = u0 + g * 8 + n * 2 + s
+                        for k, bin_ in enumerate(anchors):
+                            has = (k >> n) & 1
+                            w[blk * 1024 + bin_, col] = 1.0 if has == (1 - s) else REGION_MISS
+        edit(prefix + ".fc1.weight", fc1_w)
+        edit(prefix + ".fc1.bias", fc1_b)
+        edit(prefix + ".fc2.weight", fc2_w)
+
+    plant("region.coord_decoder", [
+        (0, 0, COORD_ANCHORS, {flag_c: -REGION_GATE, flag_s: -REGION_GATE}, 0.0),   # x of the first object: neither flag
+        (2, 0, COORD_ANCHORS, {flag_c: REGION_GATE}, -GF),                            # y: the input was a coordinate embedding
+        (1, 0, COORD_ANCHORS, {flag_s: REGION_GATE}, -GF),                            # x of a later object: the input was a size embedding
+    ], 1)
+    plant("region.size_decoder", [
+        (0, 0, SIZE_ANCHORS, {}, 0.0),    # w
+        (2, 1, SIZE_ANCHORS, {}, 0.0),    # h
+    ], 2)
+
+
+def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c_code=12.0, c_deep=0.8, s0=0.1):
+    """lm_head with a planted "bigram + image-code bit + deep context" structure.
 
     With i.i.d. random weights the top-1/top-2 logit gap is 0-3 bf16 ulps
     ("token-ID bit-exactness"), so greedy ids are decided
@@ -158,15 +426,23 @@ def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c=4.0, s0=0.1):
     m = perm(t) >> 1: both rows carry beta * unit(wte[t]) (so the pair wins
     against the other V-2 rows by a wide margin once LN(h) has a component
     along wte[t], which the residual stream guarantees), and the two rows
-    differ by +-c * r for one fixed random direction r, so WHICH of the two
-    wins is the sign of <LN(h), r> -- a feature of the whole context (image
-    prefix and all previous tokens through attention).  The result is a
-    diverse token stream whose every id depends on the full computation while
-    the typical margin is tens of bf16 ulps.  Row 0 (eos) gets a large
-    negative bias so generation length is fixed by max_tokens.
+    differ by +- (c_code * (e[p2[j]] - e[zero]) + c_deep * r):
+
+      * c_code reads coordinate j = j(m) of the image code that the planted path of _plant_code_path accumulated in the last
+        hidden state: LN(h)[p2[j]] - LN(h)[zero] = h[p2[j]] / sigma = bit_j x (something positive, O(1)) -- the WINNER of the
+        pair is a discrete property of the image (64 classes), decided with a margin of several logit units through the
+        attention of every decoder layer;
+      * c_deep * <LN(h), r> for one fixed random direction r (pair's own token directions projected out) is the deep,
+        continuous context feature rounds 1-5 used ALONE to pick the winner (c = 8).  Its sign is within bf16 implementation noise
+        for 2-3 % of all decisions, so it can no longer decide (c_deep x 4.5 sigma stays below the code term) but still moves
+        both logits by ~+-1: a wrong kernel shows in the teacher-forced logit comparison, not in a coin flip.
+
+    Row 0 (eos) gets a large negative bias so generation length is fixed by max_tokens.  Without an image (text-only query)
+    the code term is exactly 0 and the deep term decides, as before.
     """
     t = config.text
     V, D = t.vocab_size, t.dim
+    pc = protected_coords(config)
     beta = beta * 16.0 / math.sqrt(D)
     a = int(V * 0.6180339887) | 1  # odd multiplier near V/phi, made coprime with V
     while math.gcd(a, V) != 1:
@@ -181,18 +457,27 @@ def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c=4.0, s0=0.1):
     # that CPU and GPU generation give the same bits despite different summation
     # orders; everything else is elementwise IEEE arithmetic.
     wte = sd["text.wte"].float()
+    wte[:, pc["all_text"]] = 0.0   # the token directions of the pair rows stay clear of the protected coordinates
     unit = wte / wte.double().norm(dim=-1, keepdim=True).float()
     r = hash_uniform(D, _key("text.lm_head.context_dir", seed), device) * math.sqrt(3.0)
+    r[pc["all_text"]] = 0.0
     r = r / r.double().norm().float()  # <LN(h), r> ~ N(0,1) for |LN(h)| ~ sqrt(D)
     sign = torch.where((rows & 1) == 0, 1.0, -1.0).to(torch.float32).unsqueeze(1)
     noise = hash_uniform(V * D, _key("text.lm_head.weight", seed), device).reshape(V, D)
+    noise[:, pc["all_text"]] = 0.0
     ue, uo = unit[t_even], unit[t_odd]
     # context direction with the pair's own token directions projected out, so the
     # winning bit is not a function of the current token's embedding alone
     dot_e = (ue.double() @ r.double()).float().unsqueeze(1)
     dot_o = (uo.double() @ r.double()).float().unsqueeze(1)
     r_pair = r.unsqueeze(0) - dot_e * ue - dot_o * uo
-    w = beta * (ue + uo) + c * sign * r_pair + noise * (s0 * math.sqrt(3.0 / D))
+    w = beta * (ue + uo) + c_deep * sign * r_pair + noise * (s0 * math.sqrt(3.0 / D))
+    # the code coordinate of pair m: a fixed hash of the pair index
+    pair = rows >> 1
+    j = ((pair * 2654435761) >> 7) % CODE_BITS
+    p2 = torch.tensor(pc["p2"], device=device, dtype=torch.int64)[j]
+    w[rows, p2] = c_code * sign[:, 0]
+    w[:, pc["zero"]] = -c_code * sign[:, 0]
     sd["text.lm_head.weight"] = w.to(dtype)
     bias = _tensor("text.lm_head.bias", (V,), 0.05, seed, device, torch.float32)
     bias[config.tokenizer.eos_id] = -60.0
@@ -203,9 +488,14 @@ def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c=4.0, s0=0.1):
 # Synthetic inputs (BASELINE.md section 3 / SURVEY.md section 8d)
 # --------------------------------------------------------------------------
 def synthetic_image_array(index: int, seed: int = 0, size=(378, 378)) -> np.ndarray:
-    """HWC uint8 image ``np.random.default_rng(seed+index)`` (PCG64: stable)."""
+    """HWC uint8 image: uniform pixel noise (``np.random.default_rng(seed+index)``, PCG64: stable) around a per-channel colour
+    cast -- one of four levels per channel (``image_cast_levels``), i.e. one of 64 classes by ``index`` -- so that the image has
+    a DISCRETE property (its 6 code bits) besides its noise: normalised value = level + CAST_NOISE * u, u uniform in [-1, 1)."""
     rng = np.random.default_rng(seed + index)
-    return rng.integers(0, 256, (size[0], size[1], 3), dtype=np.uint8)
+    noise = rng.integers(0, 256, (size[0], size[1], 3), dtype=np.uint8)
+    level = np.array([CAST_LEVELS[lv] for lv in image_cast_levels(index)], dtype=np.float64)
+    val = 127.5 + 127.5 * (level[None, None, :] + CAST_NOISE * (noise.astype(np.float64) - 127.5) / 127.5)
+    return np.clip(np.rint(val), 0, 255).astype(np.uint8)
 
 
 def synthetic_image(index: int, seed: int = 0, size=(378, 378)):

@@ -453,6 +453,18 @@ def gen_detect(name="tiny_detect", cfg_name="tiny", seed=1, n_cases=2, max_objec
         ulp = 2.0 ** (np.floor(np.log2(max(abs(float(top[0])), 2.0 ** -120))) - 7)
         return float(top[0] - top[1]) / ulp
 
+    def eos_margin(lg):
+        """The loop only asks whether the next token is EOS (moondream.py:668-671): the margin of THAT decision is the gap
+        between the best non-EOS logit and the EOS logit (in bf16 ulps of the larger), not the gap between the best two
+        tokens -- which token it is has no effect on the objects."""
+        lg = lg.float().reshape(-1)
+        eos = float(lg[cfg.tokenizer.eos_id])
+        rest = lg.clone()
+        rest[cfg.tokenizer.eos_id] = float("-inf")
+        best = float(rest.max())
+        ulp = 2.0 ** (np.floor(np.log2(max(abs(best), abs(eos), 2.0 ** -120))) - 7)
+        return abs(best - eos) / ulp
+
     for kind in ("detect", "point"):
         kept, src = 0, -1
         while kept < n_cases:
@@ -470,7 +482,7 @@ def gen_detect(name="tiny_detect", cfg_name="tiny", seed=1, n_cases=2, max_objec
                 if kind == "detect":
                     sz = rec["decode_size"][k][1]
                     margins += [margin(sz[0]), margin(sz[1])]
-                margins.append(margin(nxt[k]))
+                margins.append(eos_margin(nxt[k]))
             per_dec = len(margins) // max(1, len(objs))
             # with i.i.d. synthetic weights the 1024-bin heads have top-1/top-2 gaps of a few bf16 ulps on
             # most decisions; keep images whose FIRST object (all its decisions) is wide-margin and record
@@ -561,6 +573,15 @@ def gen_detect13(name="md2b_detect13", cfg_name="2b", seed=1, n_images=8, max_ob
         top = torch.topk(lg.float().reshape(-1), 2).values
         return float(top[0] - top[1]) / 2.0 ** (np.floor(np.log2(max(abs(float(top[0])), 2.0 ** -120))) - 7)
 
+    def eos_ulps(lg):
+        """margin of the loop's EOS test (moondream.py:668-671): best non-EOS logit vs the EOS logit, in bf16 ulps of the larger"""
+        lg = lg.float().reshape(-1)
+        eos = float(lg[cfg.tokenizer.eos_id])
+        rest = lg.clone()
+        rest[cfg.tokenizer.eos_id] = float("-inf")
+        best = float(rest.max())
+        return abs(best - eos) / 2.0 ** (np.floor(np.log2(max(abs(best), abs(eos), 2.0 ** -120))) - 7)
+
     for i in range(n_images):
         image = synth.synthetic_image_array(i, seed, size)
         rec = {"decode_coordinate": [], "decode_size": [], "next": [], "proj": []}
@@ -598,7 +619,7 @@ def gen_detect13(name="md2b_detect13", cfg_name="2b", seed=1, n_images=8, max_ob
         margins = []
         for k in range(len(objs)):
             sz = rec["decode_size"][k]
-            margins.append([ulps(rec["decode_coordinate"][2 * k]), ulps(rec["decode_coordinate"][2 * k + 1]), ulps(sz[0]), ulps(sz[1]), ulps(nxt[k])])
+            margins.append([ulps(rec["decode_coordinate"][2 * k]), ulps(rec["decode_coordinate"][2 * k + 1]), ulps(sz[0]), ulps(sz[1]), eos_ulps(nxt[k])])
         pfx = f"img{i}."
         out[pfx + "objects"] = np.array([[o[k] for k in ("x_min", "y_min", "x_max", "y_max")] for o in objs], dtype=np.float64).reshape(len(objs), 4)
         out[pfx + "margins"] = np.array(margins, dtype=np.float32).reshape(len(objs), 5)

@@ -617,16 +617,103 @@ def test_batch_generate_strings_ragged_equals_sequential(tiny):
     orig = model._text_forward
     model._text_forward = lambda x, *a, **k: (calls.append(tuple(x.shape)), orig(x, *a, **k))[1]
     try:
-        got = model.batch_generate(images, questions, {"max_tokens": 10})
+        got = model.batch_generate(images, questions, st)
     finally:
         model._text_forward = orig
     assert got == seq
-    assert got == model.batch_query(images, questions, {"max_tokens": 10})
+    assert got == model.batch_query(images, questions, st)
     prompt_prefills = [c for c in calls if c[1] not in (1, 730)]
     assert len(prompt_prefills) == 3, calls  # one per distinct question length, not one per image
-    caps = model.batch_generate(images[:3], None, {"max_tokens": 8})
+    caps = model.batch_generate(images[:3], None, {"temperature": 0, "max_tokens": 8})
     assert caps == [model.caption(im, settings={"temperature": 0, "max_tokens": 8})["caption"] for im in images[:3]]
-    assert caps == model.batch_caption(images[:3], "normal", {"max_tokens": 8})
+    assert caps == model.batch_caption(images[:3], "normal", {"temperature": 0, "max_tokens": 8})
+
+
+def test_batched_sampled_decode_follows_the_reference_rule(tiny):
+    """Round 6: the lockstep engine SAMPLES when temperature > 0 -- what the reference's loop of query() calls does at its
+    default settings (temperature 0.5, top_p 0.3: moondream.py:50-53, 313-318, 521-528; hf_moondream.py:99-103).
+    (a) temperature -> 0+ with any top_p keeps only the argmax: ids equal the greedy ids;  (b) the draws are seeded
+    (same generator state -> same ids), different seeds differ at a hot setting;  (c) DISTRIBUTION: 64 copies of one
+    (image, prompt) decoded in lockstep at T = 1.5, top_p = 0.95 draw their FIRST TWO tokens from exactly the distribution
+    the reference's rule assigns -- the empirical frequencies of the first token (drawn from the prompt pass's logits) and
+    of the second token given the most frequent first one (drawn inside the loop from the decode step's logits) match
+    softmax / top-p / renormalise of the logits the greedy path reports, by a chi-square bound;  (d) hipGraph replay and
+    eager launches draw the same ids from the same uniforms;  (e) batch_query / batch_caption use the reference's default
+    settings when none are given and stay greedy at {"temperature": 0}."""
+    g, cfg, sd, model = tiny
+    img = golden_image(g, 0)
+    prompt = g["img0.cap.prompt"].tolist()
+    n = 8
+    greedy = model.batch_generate_ids([img] * 2, [prompt] * 2, max_tokens=n)
+    cold = model.batch_generate_ids([img] * 2, [prompt] * 2, max_tokens=n, temperature=1e-3, top_p=0.3,
+                                    generator=torch.Generator(device="cuda").manual_seed(5))
+    assert cold == greedy
+    def hot(seed, b=6, **kw):
+        return model.batch_generate_ids([img] * b, [prompt] * b, max_tokens=n, temperature=4.0, top_p=0.999,
+                                        generator=torch.Generator(device="cuda").manual_seed(seed), **kw)
+    a, a2, c = hot(1), hot(1), hot(2)
+    assert a == a2 and a != c
+    assert len({tuple(s) for s in a}) > 1            # sequences of one batch draw independently
+    use_graphs = model.use_graphs
+    try:
+        model.use_graphs = not use_graphs
+        model._graphs.clear()
+        assert hot(1) == a                           # (d)
+        assert hot(1) == a                           # ... and again from the captured graph
+    finally:
+        model.use_graphs = use_graphs
+        model._graphs.clear()
+    # (c) distribution of the first two tokens
+    T, P = 1.5, 0.95
+    def reference_rule(logits_bf16, suppress=None):
+        lg = logits_bf16.clone()
+        if suppress is not None:
+            lg[suppress] = float("-inf")
+        probs = torch.softmax(lg / T, dim=-1)        # bf16 like the reference's logits (moondream.py:316,526)
+        srt, idx = torch.sort(probs, descending=True)
+        cum = torch.cumsum(srt, dim=-1)
+        srt[(cum - srt) > P] = 0.0
+        srt.div_(srt.sum())
+        return torch.zeros_like(probs).scatter_(0, idx, srt).float().cpu()
+    enc = model.encode_image(img)
+    model.load_encoded_image(enc)
+    with torch.inference_mode():
+        logits0, _, nxt, pos = model._prefill_prompt(torch.tensor([prompt]), enc.pos, 0.0, 0.0)
+    p0 = reference_rule(logits0[0])
+    draws = []
+    for seed in range(12):
+        draws += model.batch_generate_ids([img] * 64, [prompt] * 64, max_tokens=2, temperature=T, top_p=P,
+                                          generator=torch.Generator(device="cuda").manual_seed(100 + seed))
+    first = torch.tensor([d[0] for d in draws])
+    assert float(p0[first].min()) > 0                 # nothing outside the top-p support is ever drawn
+    def chi2_ok(counts, probs, nd):
+        """Pearson chi-square of the observed counts against nd x probs: bins with an expectation >= 5 one by one, the rest
+        lumped into one bin; accepted up to the mean + 5 standard deviations of the chi-square law (+ slack for the lump)."""
+        keep = probs * nd >= 5
+        exp = torch.cat([probs[keep] * nd, (probs[~keep].sum() * nd).reshape(1)])
+        obs = torch.cat([counts[keep].float(), counts[~keep].sum().float().reshape(1)])
+        nz = exp > 0
+        chi2 = float(((obs[nz] - exp[nz]) ** 2 / exp[nz]).sum()) + (float("inf") if float(obs[~nz].sum()) > 0 else 0.0)
+        dof = max(1, int(nz.sum()) - 1)
+        return chi2 <= dof + 5 * (2 * dof) ** 0.5 + 5, (chi2, dof)
+    ok, info = chi2_ok(torch.bincount(first, minlength=p0.numel()), p0, len(first))
+    assert ok, info
+    top = int(torch.bincount(first).argmax())
+    with torch.inference_mode():
+        emb = model._embed(torch.tensor([[top]]))
+        mask = None
+        logits1, _ = model._decode_one_tok(emb, mask, torch.tensor([pos]), None)
+    p1 = reference_rule(logits1[0], suppress=cfg.tokenizer.answer_id)
+    second = torch.tensor([d[1] for d in draws if d[0] == top and len(d) > 1])
+    assert len(second) >= 30
+    assert float(p1[second].min()) > 0
+    ok, info = chi2_ok(torch.bincount(second, minlength=p1.numel()), p1, len(second))
+    assert ok, info
+    # (e) the string API: reference defaults unless told otherwise
+    qs = ["11 12 13"] * 3
+    assert model.batch_query([img] * 3, qs, {"temperature": 0, "max_tokens": 6}) == [model.query(img, qs[0], settings={"temperature": 0, "max_tokens": 6})["answer"]] * 3
+    sampled = model.batch_query([img] * 3, qs, {"max_tokens": 6, "generator": torch.Generator(device="cuda").manual_seed(3)})
+    assert len(sampled) == 3 and all(isinstance(x, str) for x in sampled)
 
 
 def test_prefetched_crops_are_used_and_identical(tiny):
@@ -698,7 +785,8 @@ def test_hf_wrapper_answer_question_and_batch_answer(tiny):
     rq = queue.Queue()
     assert hf.answer_question(images[0], questions[0], result_queue=rq, settings=st) == want[0]
     assert hf._is_kv_cache_setup and rq.get_nowait() == want[0]
-    assert hf.batch_answer(images, questions, max_new_tokens=9) == want
+    assert hf.batch_answer(images, questions, max_new_tokens=9, settings={"temperature": 0}) == want
+    assert len(hf.batch_answer(images, questions, max_new_tokens=9)) == 2   # the reference's default sampling settings
     enc = hf.encode_image(images[1])
     assert hf.answer_question(enc, questions[1], settings=st) == want[1]
     sampled = hf.answer_question(images[0], questions[0])          # default sampling settings, like the reference

@@ -99,6 +99,7 @@ def selftest_dist(args):
     t = mdist.max_over_ranks(float(rank), dev)
     seen = mdist.ranks_seen(dev)
     per_rank = mdist.gather_floats(float(rank) + 0.5, dev)
+    bindings = eng.gather_objects([eng.cpu_binding])   # every rank's core share (dist.bind_rank_cpus), on rank 0
     if os.environ.get("MD_SELFTEST_FAIL_RANK") == str(rank):  # tests: a failing rank must fail the whole launch
         raise RuntimeError(f"selftest: rank {rank} asked to fail")
     if rank == 0:
@@ -106,7 +107,7 @@ def selftest_dist(args):
         assert got == list(range(3 * world + 1)), got
         assert per_rank == [r + 0.5 for r in range(world)], per_rank
         print(json.dumps({"selftest": "dist", "n_gpus": world, "max_rank": t, "items": len(got), "ranks_seen": seen,
-                          "per_rank_ms_per_step": per_rank, "weights_broadcast": wrep}), flush=True)
+                          "per_rank_ms_per_step": per_rank, "weights_broadcast": wrep, "cpu_binding": bindings}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
@@ -612,7 +613,7 @@ def detect_job(engine, cfg, args, fp8):
     line = {
         "metric": "images_per_sec", "value": n_total * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": max(2, args.warmup), "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "ranks_seen": seen,
-        "weights_broadcast": engine.weights_report, "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms], "scaling": "weak",
+        "weights_broadcast": engine.weights_report, "cpu_binding": engine.cpu_binding, "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms], "scaling": "weak",
         "vs_baseline": None, "dtype": "fp8 (e4m3 operands, fp32 accumulate; bf16 residual stream)" if fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"Moondream-{args.model.upper()} {mode} batch_detect: {B2} images/GPU x {size[0]}x{size[1]} ({n_crops} crops "
                                f"each), detect prompt, max_objects {max_objects} (every sequence runs all rounds), seeded synthetic weights",
@@ -790,6 +791,7 @@ def main():
         "higher_is_better": True,
         "ranks_seen": ranks_seen,
         "weights_broadcast": weights_broadcast,
+        "cpu_binding": engine.cpu_binding,   # rank 0's share of the host's cores (dist.bind_rank_cpus; every rank binds its own)
         "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms] if per_rank_ms else None,
         "scaling": "weak",
         "vs_baseline": None,

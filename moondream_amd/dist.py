@@ -48,13 +48,92 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or single_rank_group()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500" if world > 1 else str(free_port()))
+        os.environ.setdefault("MASTER_PORT", str(default_master_port()) if world > 1 else str(free_port()))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def default_master_port() -> int:
+    """MASTER_PORT when a launcher set WORLD_SIZE > 1 but no port (mpirun / srun style; torchrun always sets one).  Every
+    rank must arrive at the SAME number without talking, and two jobs of one host should not both land on 29500: the port
+    is derived from what the ranks of one job share and other jobs do not -- the launcher's job / run id if there is one,
+    else the parent process id (the launcher's) and the user id."""
+    import zlib
+
+    for key in ("TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID", "OMPI_MCA_ess_base_jobid", "PMIX_NAMESPACE"):
+        if os.environ.get(key):
+            tag = f"{key}={os.environ[key]}"
+            break
+    else:
+        tag = f"ppid={os.getppid()}"
+    return 20000 + zlib.crc32(f"{tag}/uid={os.getuid()}".encode()) % 30000
+
+
+# ------------------------------------------------------------------ one process per GPU on one host: who gets which cores
+def _cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_cpus(device_index: int) -> Tuple[Optional[int], List[int]]:
+    """(NUMA node, its logical CPUs) of the GPU ``device_index`` from sysfs (``/sys/bus/pci/devices/<bdf>/numa_node`` and
+    ``local_cpulist``), or (None, []) when the PCI address or sysfs is not available (no GPU, containers without sysfs)."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        with open(base + "/local_cpulist") as f:
+            cpus = _cpulist(f.read())
+        with open(base + "/numa_node") as f:
+            node = int(f.read().strip())
+        return (node if node >= 0 else None), cpus
+    except Exception:
+        return None, []
+
+
+def plan_rank_cpus(local_rank: int, local_world: int, allowed: Sequence[int], numa_cpus_by_rank: Sequence[Sequence[int]]) -> List[int]:
+    """Pure planning step of ``bind_rank_cpus`` (unit-tested on CPU).  ``numa_cpus_by_rank[r]``: CPUs local to rank r's GPU
+    ([] = unknown).  The ranks whose GPUs sit on the same NUMA node split that node's allowed CPUs evenly, in rank order; a rank
+    whose node is unknown (or whose share would be empty) gets an even slice of ALL allowed CPUs instead.  Never returns an
+    empty list."""
+    allowed = sorted(set(int(c) for c in allowed))
+    mine = sorted(set(numa_cpus_by_rank[local_rank]) & set(allowed)) if local_rank < len(numa_cpus_by_rank) else []
+    if mine:
+        peers = [r for r in range(local_world) if r < len(numa_cpus_by_rank) and sorted(set(numa_cpus_by_rank[r]) & set(allowed)) == mine]
+        share = shard_range(len(mine), peers.index(local_rank), len(peers))
+        if len(share):
+            return [mine[i] for i in share]
+    share = shard_range(len(allowed), local_rank, max(1, local_world))
+    return [allowed[i] for i in share] or allowed
+
+
+def bind_rank_cpus(local_rank: int, local_world: int, use_gpu_topology: bool = True) -> dict:
+    """Give this rank its own cores: 8 ranks x (a PIL tiling pool + launch threads + the pipelined engine's workers) on one
+    host otherwise all float over all cores, migrate across NUMA nodes and fight for the same ones (review, round 5).  The
+    process's affinity mask becomes its share of the CPUs local to its GPU's NUMA node (``plan_rank_cpus``); thread pools
+    created afterwards size themselves from that mask.  ``MOONDREAM_BIND_CPUS=0`` turns it off.  Returns what was done."""
+    if os.environ.get("MOONDREAM_BIND_CPUS", "1") in ("0", "") or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return {"bound": False, "reason": "one rank on this host" if local_world <= 1 else "disabled"}
+    allowed = sorted(os.sched_getaffinity(0))
+    by_rank: List[List[int]] = []
+    nodes: List[Optional[int]] = []
+    for r in range(local_world):
+        node, cpus = gpu_numa_cpus(r) if (use_gpu_topology and torch.cuda.is_available() and r < torch.cuda.device_count()) else (None, [])
+        by_rank.append(cpus)
+        nodes.append(node)
+    cpus = plan_rank_cpus(local_rank, local_world, allowed, by_rank)
+    os.sched_setaffinity(0, cpus)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
+    return {"bound": True, "cpus": len(cpus), "first": cpus[0], "last": cpus[-1], "numa_node": nodes[local_rank],
+            "how": "share of the GPU's NUMA node" if by_rank[local_rank] else "even slice of the allowed CPUs (no GPU topology in sysfs)"}
 
 
 def free_port() -> int:

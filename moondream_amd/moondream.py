@@ -799,7 +799,12 @@ class MoondreamModel:
             # one process per GPU: the ranks of a node share its cores (8 ranks x 32 workers + prefetch workers would
             # oversubscribe a 256-thread host)
             ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
-            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(32, n // ranks_here - 2 if ranks_here > 1 else n)))
+            total = os.cpu_count() or n
+            if ranks_here > 1 and n * ranks_here <= total + ranks_here:
+                share = n          # the affinity mask already IS this rank's share (dist.bind_rank_cpus): do not divide twice
+            else:
+                share = n // ranks_here
+            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(32, share - 2 if ranks_here > 1 else n)))
         return pool
 
     def _run_vision_encoder(self, image: Image.Image) -> torch.Tensor:

@@ -23,6 +23,8 @@ degenerates to the single-GPU model: no process group, no collective.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -83,6 +85,9 @@ class DataParallelEngine:
             torch.cuda.set_device(self.device)
         self.config = config
         self.weights_report: Optional[dict] = None
+        # before any thread pool exists: this rank's share of the cores next to its GPU (dist.bind_rank_cpus)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world) or self.world)
+        self.cpu_binding = mdist.bind_rank_cpus(self.local_rank, local_world, use_gpu_topology=self.device.type == "cuda")
         sd = self._distribute_weights(weights_file, state_dict, state_dict_fn, verify_broadcast)
         self.model = model_factory(config, sd, self.device, **model_kwargs)
         self._gather_stream = torch.cuda.Stream(device=self.device) if (self._collective and self.device.type == "cuda") else None

@@ -15,7 +15,7 @@ and records, for fixed seeded inputs, the per-stage activations, KV rows,
 logits, greedy token ids and top-1/top-2 margins that the oracle
 (``oracle/moondream_oracle.py``) and the HIP path are compared against.
 
-Usage:  python oracle/make_golden.py [tiny] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [lora] [0.5b] [2b] [bench64] [vqa64] [detect13] [reftime]
+Usage:  python oracle/make_golden.py [tiny] [layers] [multicrop] [crops] [textonly] [detect] [sampling] [reasoning] [lora] [0.5b] [2b] [bench64] [vqa64] [detect13] [reftime]
 """
 from __future__ import annotations
 
@@ -636,6 +636,71 @@ def gen_detect13(name="md2b_detect13", cfg_name="2b", seed=1, n_images=8, max_ob
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
 
 
+def gen_layers(name="tiny_layers", cfg_name="tiny", seed=1):
+    """PER-LAYER drift profile (round 6): the reference's activation after EVERY ViT block (as post_ln(x_k): what
+    vision_encoder, vision.py:64-74, returns with its block list cut after block k) and after EVERY decoder block of the image
+    prefill (text_decoder, text.py:128-160, cut after block k), for image 0 of tiny_seed1 -- plus, per layer, the relative RMS
+    distance of the ORACLE from the reference there.  tests/test_model_gpu.py holds the HIP path to 1.3 x that distance layer by
+    layer: a single bad layer is caught where it happens instead of being forgiven by an end-of-stack tolerance."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from moondream.torch.vision import prepare_crops, create_patches
+    from moondream.torch.layers import attn, layer_norm, mlp
+    from moondream.torch.text import text_decoder, text_encoder
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import moondream_oracle as O
+
+    cfg = get_config(cfg_name)
+    sd = synth.synthetic_state_dict(cfg, seed=seed)
+    model, ref_md = load_reference(cfg, sd)
+    g0 = np.load(os.path.join(GOLD, "tiny_seed1.npz"))
+    index = int(g0["image_index"][0])
+    image = synth.synthetic_image_array(index, seed, (378, 378))
+    vc, w = model.config.vision, model.vision
+    ts = 9
+    out = {"seed": np.int64(seed), "cfg": np.array(cfg_name), "image_index": np.int64(index), "vit_token_stride": np.int64(ts)}
+
+    def rel(a, b):
+        a, b = a.float(), b.float()
+        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+    orc = O.Oracle(cfg, sd)
+    tap = {"__all_blocks__": True}
+    crops_u8 = np.stack([image, image])
+    orc.encode_image(crops_u8, (1, 1), tap)
+    drift_v, drift_t = [], []
+    with torch.inference_mode():
+        crops, tiling = prepare_crops(Image.fromarray(image, "RGB"), vc, device="cpu")
+        assert tuple(tiling) == (1, 1)
+        x = w.patch_emb(create_patches(crops, vc.enc_patch_size)) + w.pos_emb
+        for i, block in enumerate(w.blocks):
+            x = x + attn(layer_norm(x, block.ln1), block.attn, n_heads=vc.enc_n_heads)
+            x = x + mlp(layer_norm(x, block.ln2), block.mlp)
+            y = layer_norm(x, w.post_ln)
+            yo = O.layer_norm(tap[f"vit.block{i}"], sd["vision.post_ln.weight"], sd["vision.post_ln.bias"])
+            out[f"vit.ln_block{i}"] = bf16_bits(y[:, ::ts])
+            drift_v.append(rel(yo, y))
+        img_emb = model._run_vision_encoder(Image.fromarray(image, "RGB"))
+        bos = text_encoder(torch.tensor([[cfg.tokenizer.bos_id]]), model.text)
+        x0 = torch.cat([bos, img_emb[None]], dim=1)
+        mask = model.attn_mask[:, :, 0 : x0.size(1), :]
+        pos_ids = torch.arange(x0.size(1), dtype=torch.long)
+        tap_t = {"__all_blocks__": True}   # the oracle's decoder from the REFERENCE's embeddings: the decoder's drift alone
+        O.text_decoder(x0[0], sd, cfg, O.OracleKV.empty(cfg), pos_ids, orc.cos, orc.sin, tap_t, orc.fast)
+        for k in range(1, cfg.text.n_layers + 1):
+            cut = SimpleNamespace(blocks=model.text.blocks[:k], freqs_cis=model.text.freqs_cis)
+            h = text_decoder(x0, cut, mask, pos_ids, model.config.text, None)[0]
+            out[f"text.block{k - 1}"] = bf16_bits(h)
+            drift_t.append(rel(tap_t[f"text.block{k - 1}"], h))
+        out["text.input"] = bf16_bits(x0[0])   # the decoder is driven from the REFERENCE's embeddings: its drift alone
+    out["oracle_drift_vit"] = np.array(drift_v, dtype=np.float64)
+    out["oracle_drift_text"] = np.array(drift_t, dtype=np.float64)
+    print(f"[{name}] oracle-vs-reference drift: ViT {['%.2e' % d for d in drift_v]}; decoder {['%.2e' % d for d in drift_t]}", flush=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)", flush=True)
+
+
 def gen_sampling(name="sampling_top_p", seed=7):
     """The reference's sampling filter on fixed logits: softmax(logits / T) -> MoondreamModel._apply_top_p
     (moondream.py:270-278, called at :316-317 and :526-527), bf16 like the decode path's logits.
@@ -861,6 +926,8 @@ def main():
         gen_crops()
     if "tiny" in which:
         gen_model_case("tiny_seed1", "tiny", 1, [(378, 378)], 24, True, n_images=3)
+    if "layers" in which:
+        gen_layers()
     if "multicrop" in which:
         gen_multicrop()
     if "textonly" in which:

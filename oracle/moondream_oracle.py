@@ -207,7 +207,7 @@ def vision_encoder(x_bchw: torch.Tensor, sd, cfg, tap: Optional[dict] = None, fa
         x = add_bf16(x, a)
         m = mlp(layer_norm(x, sd[p + ".ln2.weight"], sd[p + ".ln2.bias"]), sd, p + ".mlp", fast)
         x = add_bf16(x, m)
-        if tap is not None and i in (0, v.enc_n_layers - 1):
+        if tap is not None and (i in (0, v.enc_n_layers - 1) or tap.get("__all_blocks__")):
             tap[f"vit.block{i}"] = x
     x = layer_norm(x, sd["vision.post_ln.weight"], sd["vision.post_ln.bias"])
     if tap is not None:
@@ -390,7 +390,7 @@ def text_decoder(x, sd, cfg, kv: OracleKV, pos: torch.Tensor, cos, sin, tap=None
         a = text_attention(h, sd, p + ".attn", cfg, i, kv, pos, cos, sin, allowed, fast, None if ll is None else ll["attn"])
         m = mlp(h, sd, p + ".mlp", fast, None if ll is None else ll["mlp"])
         x = add_bf16(add_bf16(x, a), m)
-        if tap is not None and i in (0, t.n_layers - 1):
+        if tap is not None and (i in (0, t.n_layers - 1) or tap.get("__all_blocks__")):
             tap[f"text.block{i}"] = x
     return x
 

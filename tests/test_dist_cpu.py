@@ -250,3 +250,52 @@ def test_data_parallel_engine_single_process_needs_no_process_group(monkeypatch)
     assert eng.batch_caption([3]) == ["normal:8"]
     with pytest.raises(ValueError):
         DataParallelEngine(get_config("tiny"), device=torch.device("cpu"), model_factory=_StubModel)
+
+
+def test_bench_selftest_world_8_gloo():
+    """The driver's 8-GPU command line in a dry run (review, round 5): `bench.py --gpus 8 --selftest-dist` launches itself
+    as 8 ranks (gloo here), every rank binds its share of the cores, builds the checkpoint, takes the flat broadcast and
+    verifies it, gathers ids / floats; the line carries ranks_seen, per-rank values, the broadcast's bytes and seconds and
+    every rank's core share -- disjoint across ranks."""
+    import json
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--selftest-dist"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["items"] == 25
+    assert line["per_rank_ms_per_step"] == [r + 0.5 for r in range(8)]
+    wb = line["weights_broadcast"]
+    assert wb["equal_to_local_copy_on_every_rank"] is True and wb["bytes"] > 0 and wb["seconds"] >= 0
+    binds = line["cpu_binding"]
+    assert len(binds) == 8
+    n_cpu = len(os.sched_getaffinity(0))
+    if n_cpu >= 8:
+        assert all(b["bound"] for b in binds)
+        spans = sorted((b["first"], b["last"]) for b in binds)
+        assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), spans   # disjoint shares
+        assert sum(b["cpus"] for b in binds) == n_cpu
+
+
+def test_plan_rank_cpus_splits_numa_nodes_between_their_gpus():
+    """dist.plan_rank_cpus: 8 ranks, GPUs 0-3 on node 0 (CPUs 0-63, 128-191), GPUs 4-7 on node 1 -- every rank gets a quarter
+    of ITS node, shares are disjoint and cover the host; unknown topology -> even slices; a restricted mask is respected;
+    and the derived rendezvous port is a function of the job, equal on every rank."""
+    node0 = list(range(0, 64)) + list(range(128, 192))
+    node1 = list(range(64, 128)) + list(range(192, 256))
+    by_rank = [node0] * 4 + [node1] * 4
+    shares = [mdist.plan_rank_cpus(r, 8, range(256), by_rank) for r in range(8)]
+    assert all(len(s) == 32 for s in shares)
+    assert sorted(c for s in shares for c in s) == list(range(256))
+    assert all(set(shares[r]) <= set(node0) for r in range(4)) and all(set(shares[r]) <= set(node1) for r in range(4, 8))
+    flat = [mdist.plan_rank_cpus(r, 8, range(16), [[]] * 8) for r in range(8)]
+    assert flat == [[2 * r, 2 * r + 1] for r in range(8)]
+    masked = [mdist.plan_rank_cpus(r, 2, [4, 5, 6, 7], [node0, node0]) for r in range(2)]
+    assert masked == [[4, 5], [6, 7]]
+    assert mdist.plan_rank_cpus(1, 4, [3], [[]] * 4) == [3]           # fewer cores than ranks: never an empty mask
+    a = mdist.default_master_port()
+    assert 20000 <= a < 50000 and a == mdist.default_master_port()

@@ -604,6 +604,87 @@ def test_rowwise_add_and_gelu_kernels():
     compare("gelu", out, torch.nn.functional.gelu(a.float(), approximate="tanh").to(BF16), 3e-3, 2e-2)
 
 
+# ------------------------------------------------------------------ per-layer drift profile (round 6)
+def _layer_profile(model, cfg, g):
+    """HIP activation after every ViT block k (as post_ln(x_k): md_vit_encode with the block list cut after block k) and after
+    every decoder block of the image prefill (md_text_forward cut after block k, driven from the REFERENCE's [bos | image]
+    embeddings), as relative RMS distances from the reference's tensors in tiny_layers.npz."""
+    import ctypes as C
+    from moondream_amd import _lib
+    from oracle import moondream_oracle as O
+
+    lib, dev = model.lib, model.device
+    v, t = cfg.vision, cfg.text
+    arr = synth.synthetic_image_array(int(g["image_index"]), int(g["seed"]), (378, 378))
+    crops = O.normalize_crops(np.stack([arr, arr])).to(dev).contiguous()
+    ts = int(g["vit_token_stride"])
+    st = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def rel(a, b):
+        a, b = a.detach().float().cpu(), b.float()
+        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+    vit_d, txt_d = [], []
+    for k in range(1, v.enc_n_layers + 1):
+        cut = type(model.w.vit).from_buffer_copy(model.w.vit)
+        cut.n_layers = k
+        out = torch.empty(2, v.n_patches, v.enc_dim, dtype=BF16, device=dev)
+        ws = model._workspace(lib.md_vit_workspace_bytes(C.byref(cut), 2))
+        _lib.check(lib.md_vit_encode(C.byref(cut), crops.data_ptr(), _lib.MD_CROPS_BF16_CHW, 2, out.data_ptr(), ws.data_ptr(), ws.numel(), st()))
+        vit_d.append(rel(out[:, ::ts], bits_to_bf16(g[f"vit.ln_block{k - 1}"])))
+    x0 = bits_to_bf16(g["text.input"]).to(dev).reshape(1, -1, t.dim).contiguous()
+    pos0 = torch.zeros(1, dtype=torch.int32, device=dev)
+    model._ensure_batch(1)
+    for k in range(1, t.n_layers + 1):
+        cut = type(model.w.text).from_buffer_copy(model.w.text)
+        cut.n_layers = k
+        hidden = torch.empty_like(x0)
+        kv = model._kv_struct(0)
+        ws = model._workspace(lib.md_text_workspace_bytes(C.byref(cut), 1, x0.shape[1]))
+        _lib.check(lib.md_text_forward(C.byref(cut), x0.data_ptr(), hidden.data_ptr(), 1, x0.shape[1], pos0.data_ptr(), C.byref(kv),
+                                       ws.data_ptr(), ws.numel(), st()))
+        txt_d.append(rel(hidden[0], bits_to_bf16(g[f"text.block{k - 1}"])))
+    return np.array(vit_d), np.array(txt_d)
+
+
+LAYER_DRIFT_FACTOR = 1.3   # HIP drift at a layer <= 1.3 x the oracle's drift from the reference at that layer ...
+LAYER_DRIFT_SLACK = 5e-4   # ... + this (the first layers' drift is a handful of flipped roundings: a ratio of two tiny numbers)
+
+
+def test_per_layer_drift_profile_and_mutation_is_caught_where_it_happens(tiny, golden_dir):
+    """Each ViT block and each decoder block separately (review, round 5): an end-of-stack tolerance of 1.5e-2 after 27 blocks
+    forgives one bad layer whose error the following layers dilute.  The reference's activation after EVERY block is in
+    tiny_layers.npz together with the oracle's drift from it; the HIP path must stay within 1.3 x that drift at every layer.
+    Then the lost-head mutation of the 2B test (one attention head of ViT block 13 lost: its proj input columns zeroed) is
+    planted here: the profile must trip AT block 13 -- not before, and visibly (> 2 x the bound) -- and be clean again after."""
+    g0, cfg, sd, model = tiny
+    g = load_golden(golden_dir, "tiny_layers.npz")
+    bound_v = LAYER_DRIFT_FACTOR * g["oracle_drift_vit"] + LAYER_DRIFT_SLACK
+    bound_t = LAYER_DRIFT_FACTOR * g["oracle_drift_text"] + LAYER_DRIFT_SLACK
+    vit_d, txt_d = _layer_profile(model, cfg, g)
+    print("ViT  drift HIP   :", " ".join(f"{d:.2e}" for d in vit_d))
+    print("ViT  drift oracle:", " ".join(f"{d:.2e}" for d in g["oracle_drift_vit"]))
+    print("text drift HIP   :", " ".join(f"{d:.2e}" for d in txt_d), "| oracle:", " ".join(f"{d:.2e}" for d in g["oracle_drift_text"]))
+    assert (vit_d <= bound_v).all(), [(k, vit_d[k], bound_v[k]) for k in range(len(vit_d)) if vit_d[k] > bound_v[k]]
+    assert (txt_d <= bound_t).all(), [(k, txt_d[k], bound_t[k]) for k in range(len(txt_d)) if txt_d[k] > bound_t[k]]
+    hd = cfg.vision.enc_dim // cfg.vision.enc_n_heads
+    w = model.w._vit_packed[13]["proj"].w            # [n_pad][k_pad] bf16: input feature f of the layer = column f
+    keep = w.clone()
+    try:
+        w[:, hd : 2 * hd].zero_()                    # head 1 of block 13 lost
+        torch.cuda.synchronize()
+        bad_v, _ = _layer_profile(model, cfg, g)
+    finally:
+        w.copy_(keep)
+        torch.cuda.synchronize()
+    over = [k for k in range(len(bad_v)) if bad_v[k] > bound_v[k]]
+    print("ViT  drift with head 1 of block 13 lost:", " ".join(f"{d:.2e}" for d in bad_v))
+    assert over and over[0] == 13 and bad_v[13] > 2 * bound_v[13], (over, bad_v[13], bound_v[13])
+    assert np.array_equal(bad_v[:13], vit_d[:13])    # the layers before it are untouched, bit for bit
+    again_v, again_t = _layer_profile(model, cfg, g)
+    assert np.array_equal(again_v, vit_d) and np.array_equal(again_t, txt_d)
+
+
 # ------------------------------------------------------------------ batched string API + HF wrapper
 def test_batch_generate_strings_ragged_equals_sequential(tiny):
     """batch_generate / batch_query / batch_caption (the names BASELINE.json uses) with questions of

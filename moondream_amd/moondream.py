@@ -1346,8 +1346,13 @@ class MoondreamModel:
                     # this batch's crops are cut and queued for upload: the pool is free for the next batch's tiling
                     staged = self._pipe_staged = self._stage_crops(list(nxt[0])) if nxt is not None else None
                     if self.fused_prefill:  # [bos | image | prompt] in one decoder pass, as in _prepare_sequences
-                        bos = self._embed(torch.full((b, 1), tk.bos_id, dtype=torch.int32))
-                        x = torch.cat([bos, img_emb, self._embed(torch.tensor(prompts, dtype=torch.int32))], dim=1)
+                        # assembled in a PREALLOCATED arena (one per batch shape; stream-ordered reuse on run_s: the previous
+                        # step's pass has read it before this step's copies run) instead of a fresh torch.cat per step; the
+                        # BOS column is written once
+                        n_img, n_pr = img_emb.shape[1], len(prompts[0])
+                        x = self._prefill_arena(b, 1 + n_img + n_pr, tk.bos_id)
+                        x[:, 1 : 1 + n_img].copy_(img_emb)
+                        x[:, 1 + n_img :].copy_(self._embed(torch.tensor(prompts, dtype=torch.int32)))
                         logits = self._lm_head(self._text_forward(x, 0, slot0))
                         p1 = x.shape[1]
                     else:
@@ -1367,8 +1372,7 @@ class MoondreamModel:
                     if self.pipeline_streams == 3:  # measurement only: rounds 1-3's collection (synchronous copy on the default stream)
                         hist_host = hist
                     else:
-                        with torch.inference_mode(False):
-                            hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+                        hist_host = self._pinned_ids(tuple(hist.shape))   # recycled by _collect: no cudaHostAlloc per step
                         hist_host.copy_(hist, non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(dec_s)
@@ -1379,10 +1383,33 @@ class MoondreamModel:
         while pending:
             yield self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
 
+    def _prefill_arena(self, b: int, t: int, bos_id: int) -> torch.Tensor:
+        """bf16 [b, t, D] buffer of the pipelined engine's fused prefill input, column 0 = the BOS embedding."""
+        key = (b, t)
+        arenas = self.__dict__.setdefault("_prefill_arenas", {})
+        x = arenas.get(key)
+        if x is None:
+            if len(arenas) >= 4:   # a handful of batch shapes at most: do not hoard
+                arenas.clear()
+            x = arenas[key] = torch.empty(b, t, self.config.text.dim, dtype=BF16, device=self._device)
+            x[:, :1].copy_(self._embed(torch.full((b, 1), bos_id, dtype=torch.int32)))
+        return x
+
+    def _pinned_ids(self, shape) -> torch.Tensor:
+        """A pinned int32 host buffer for one step's ids, from a free list that ``_collect`` refills (a pinned allocation per
+        step is a driver call and a page-locking of its own; review, round 5)."""
+        free = self.__dict__.setdefault("_pinned_id_free", {}).setdefault(shape, [])
+        if free:
+            return free.pop()
+        with torch.inference_mode(False):
+            return torch.empty(shape, dtype=torch.int32, pin_memory=True)
+
     def _collect(self, item, eos, max_tokens):
         hist, done, b = item
         done.synchronize()
         cols = hist.t().tolist()
+        if hist.device.type == "cpu" and hist.is_pinned():
+            self.__dict__.setdefault("_pinned_id_free", {}).setdefault(tuple(hist.shape), []).append(hist)
         if b == 1:
             self._check_b1_barriers()
         return [self._truncate(cols[i], eos, max_tokens) for i in range(b)]

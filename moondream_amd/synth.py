@@ -28,7 +28,7 @@ TEXT_PROJ_GAIN = 1.0
 TEXT_FC2_GAIN = 0.5
 # beta is given for dim 256 and scaled by 16/sqrt(dim) (the planted logit grows like
 # beta*sqrt(dim)); see _plant_lm_head
-PLANT = dict(beta=1.6, c_code=12.0, c_deep=0.8, s0=0.1)
+PLANT = dict(beta=1.6, c_code=12.0, c_deep=0.8, c_tok=1.0, s0=0.1)
 WTE_STD = 2.5
 
 # ---- round 6: the planted "image code" path (see _plant_code_path) -------------------------------------------------
@@ -36,10 +36,15 @@ WTE_STD = 2.5
 # (synthetic_image_array).  2 bits x 3 channels = 64 image classes = a 6-bit code that a few planted weights carry -- through
 # the kernels under test, not around them -- to the last hidden state, where the lm_head pair rows and the region decoders read it.
 CODE_BITS = 6
+SPECIAL_PAIRS = 5                         # candidate pairs {0,1} .. {8,9}: special token ids, never a planted winner
+TOK_BITS = 32                             # protected decoder coordinates that carry the codeword of the current token's pair
 CAST_LEVELS = (-0.6, -0.2, 0.2, 0.6)      # normalised ((x / 255 - 0.5) / 0.5) channel means of the four levels
 CAST_NOISE = 0.35                         # amplitude of the uniform pixel noise around the level (no clipping: 0.6 + 0.35 < 1)
 CODE_GAMMA = 8.0                          # ViT protected coordinates: GAMMA x channel mean, and the constant reference GAMMA
-CODE_STEEP = 24.0                         # projector threshold units: K.  u = K x GAMMA x (level - theta) / sigma, sigma ~ 7.3: 5.3 at the nearest threshold (saturated: S = 1.0000 / 0.0000), 26 at the farthest (a bf16 GELU output resolves 1/8 there: +-0.03 of random rounding per token in the code coordinates, averaged away over the 729 keys)
+# projector threshold units: K.  u = K x GAMMA x (level - theta) / sigma with sigma ~ 7.3: 5.3 at the nearest threshold (saturated:
+# S = 1.0000 / 0.0000), 26 at the farthest, where a bf16 GELU output resolves 1/8: +-0.03 of random rounding per token in the code
+# coordinates, averaged away over the 729 keys (K = 64 made that +-0.12 and cost the tiny model's K rows 0.5e-2 of relative RMS)
+CODE_STEEP = 24.0
 CODE_RHO = 1.0                            # decoder: V copy gain of the code coordinates
 DEFAULT_CODE = (1, -1, -1, 1, -1, 1)      # the code of "no image": carried by every token embedding
 IMAGE_CODE_AMPLITUDE = 0.5                # an image embedding carries its code as +-0.5 ...
@@ -174,9 +179,36 @@ def protected_coords(config: MoondreamConfig) -> dict:
     e, d = config.vision.enc_dim, config.text.dim
     return {
         "vit_rgb": [e - 5, e - 4, e - 3], "vit_ref": e - 2, "vit_zero": e - 1,
+        "tok": list(range(d - 16 - TOK_BITS, d - 16)),
         "flag": [d - 16, d - 15], "zero": d - 14, "p1": list(range(d - 12, d - 6)), "p2": list(range(d - 6, d)),
-        "all_text": list(range(d - 16, d)), "all_vit": list(range(e - 5, e)),
+        "all_text": list(range(d - 16 - TOK_BITS, d)), "all_vit": list(range(e - 5, e)),
     }
+
+
+def pair_codewords(n_pairs: int, device="cpu") -> torch.Tensor:
+    """+-1 codeword [n_pairs, 32] of every token pair: the second-order Reed-Muller code RM(2, 5) -- the pair index as the 16
+    coefficients of a Boolean polynomial of degree <= 2 in 5 variables, evaluated at the 32 points of {0, 1}^5.  2^16 codewords,
+    any two differ in >= 8 of 32 positions (integer arithmetic only: the same bits everywhere)."""
+    assert n_pairs <= 1 << 16
+    m = torch.arange(n_pairs, dtype=torch.int64, device=device).unsqueeze(1)          # [n, 1]
+    x = torch.arange(32, dtype=torch.int64, device=device).unsqueeze(0)               # [1, 32]: the evaluation points
+    xs = [(x >> i) & 1 for i in range(5)]
+    acc = (m >> 0) & 1                                                                  # constant term
+    bit = 1
+    for i in range(5):
+        acc = acc ^ (((m >> bit) & 1) & xs[i])
+        bit += 1
+    for i in range(5):
+        for j in range(i + 1, 5):
+            acc = acc ^ (((m >> bit) & 1) & xs[i] & xs[j])
+            bit += 1
+    return (1 - 2 * acc).to(torch.float32)
+
+
+def token_code_amplitude(config: MoondreamConfig) -> float:
+    """Amplitude of the pair codeword in a token embedding: roughly 0.15 x the standard deviation of the last hidden state,
+    which grows with depth (2.6 after 3 decoder layers, 6.3 after 24 with this checkpoint's gains)."""
+    return 0.4 * (1.0 + 0.25 * math.sqrt(config.text.n_layers))
 
 
 def image_code_bits(index: int) -> list:
@@ -290,6 +322,12 @@ def _plant_code_path(sd, config, dtype):
         # outweigh the few text keys (a text key counts half, and there are 5-64 of them)
         for j, bit in enumerate(DEFAULT_CODE):
             w[:, pc["p1"][j]] = TEXT_CODE_AMPLITUDE * bit
+        # ... and the CODEWORD OF ITS PAIR (the pair of next-token candidates it owns, _plant_lm_head) in the ``tok``
+        # coordinates: no decoder layer writes them, so the last hidden state of a position still holds its input token's
+        # codeword exactly, and lm_head's pair rows read it -- WHICH pair wins is decided with a gap of >= 8 of 32 positions
+        # instead of by the depth-diluted <LN(h), wte[t]> alone (one of 2112 bench decisions had that down to 0.19)
+        pairs = _token_pairs(t.vocab_size, w.device)
+        w[:, pc["tok"]] = token_code_amplitude(config) * pair_codewords(t.vocab_size // 2, w.device)[pairs]
     edit("text.wte", wte)
     hd = t.dim // t.n_heads
     group = t.n_heads // t.n_kv_heads
@@ -416,7 +454,26 @@ def _plant_region_heads(sd, config, dtype):
     ], 2)
 
 
-def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c_code=12.0, c_deep=0.8, s0=0.1):
+def _pair_perm(V: int):
+    a = int(V * 0.6180339887) | 1  # odd multiplier near V/phi, made coprime with V
+    while math.gcd(a, V) != 1:
+        a += 2
+    return a, 17
+
+
+def _token_pairs(V: int, device="cpu") -> torch.Tensor:
+    """pair index m = perm(t) >> 1 of every token t, perm(t) = (a t + b) mod V (the bijection _plant_lm_head uses)."""
+    a, b = _pair_perm(V)
+    t = torch.arange(V, dtype=torch.int64, device=device)
+    m = ((a * t + b) % V) >> 1
+    # the first SPECIAL_PAIRS pairs hold the special ids (eos / bos 0, answer 3 -- SUPPRESSED in every decode step,
+    # moondream.py:517 --, thinking 4, coord 5, size 6, grounding 7 / 9): a token that owned one of them would have its
+    # winner taken away (round 6: the one narrow decision of the first re-conditioned bench fixture was exactly that: the
+    # code picked 3, 3 was -inf, and the next candidates were near-ties).  Their owners share the LAST pairs instead.
+    return torch.where(m < SPECIAL_PAIRS, V // 2 - 1 - m, m)
+
+
+def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c_code=12.0, c_deep=0.8, c_tok=1.0, s0=0.1):
     """lm_head with a planted "bigram + image-code bit + deep context" structure.
 
     With i.i.d. random weights the top-1/top-2 logit gap is 0-3 bf16 ulps
@@ -437,18 +494,18 @@ def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c_code=12.0, c_dee
         for 2-3 % of all decisions, so it can no longer decide (c_deep x 4.5 sigma stays below the code term) but still moves
         both logits by ~+-1: a wrong kernel shows in the teacher-forced logit comparison, not in a coin flip.
 
-    Row 0 (eos) gets a large negative bias so generation length is fixed by max_tokens.  Without an image (text-only query)
-    the code term is exactly 0 and the deep term decides, as before.
+    WHICH pair wins is decided by the tok coordinates (the current token's RM(2,5) pair codeword, carried unchanged from its
+    embedding: + c_tok x 32 a / sigma for its own pair, at most half of that for any other) on top of the beta term.  Pairs of
+    special ids are nobody's pair (``_token_pairs``).  Row 0 (eos) gets a large negative bias so generation length is fixed by
+    max_tokens.  Without an image (text-only query) every key carries the DEFAULT code at half amplitude: the decisions follow
+    it with a margin of a few logit units, which the deep term can still overrule (those goldens stay filtered by margin).
     """
     t = config.text
     V, D = t.vocab_size, t.dim
     pc = protected_coords(config)
     beta = beta * 16.0 / math.sqrt(D)
-    a = int(V * 0.6180339887) | 1  # odd multiplier near V/phi, made coprime with V
-    while math.gcd(a, V) != 1:
-        a += 2
+    a, b = _pair_perm(V)
     a_inv = pow(a, -1, V)
-    b = 17
     rows = torch.arange(V, device=device, dtype=torch.int64)
     # perm(t) = (a*t + b) mod V  ->  perm^-1(v) = a_inv * (v - b) mod V
     t_even = (a_inv * (((rows & ~1) - b) % V)) % V
@@ -466,18 +523,37 @@ def _plant_lm_head(sd, config, seed, device, dtype, beta=1.0, c_code=12.0, c_dee
     noise = hash_uniform(V * D, _key("text.lm_head.weight", seed), device).reshape(V, D)
     noise[:, pc["all_text"]] = 0.0
     ue, uo = unit[t_even], unit[t_odd]
+    # owners of a pair: the two tokens the permutation maps onto it; none for the special pairs (rows 0 .. 2 SPECIAL_PAIRS - 1),
+    # and the owners of special pair k additionally own pair V/2 - 1 - k (``_token_pairs``) -- added in a fixed order below
+    special = (rows >> 1) < SPECIAL_PAIRS
+    ue = torch.where(special.unsqueeze(1), torch.zeros_like(ue), ue)
+    uo = torch.where(special.unsqueeze(1), torch.zeros_like(uo), uo)
     # context direction with the pair's own token directions projected out, so the
     # winning bit is not a function of the current token's embedding alone
     dot_e = (ue.double() @ r.double()).float().unsqueeze(1)
     dot_o = (uo.double() @ r.double()).float().unsqueeze(1)
     r_pair = r.unsqueeze(0) - dot_e * ue - dot_o * uo
-    w = beta * (ue + uo) + c_deep * sign * r_pair + noise * (s0 * math.sqrt(3.0 / D))
+    own = ue + uo
+    for k in range(SPECIAL_PAIRS):
+        for tok in (int((a_inv * ((2 * k - b) % V)) % V), int((a_inv * ((2 * k + 1 - b) % V)) % V)):
+            u = unit[tok]
+            for row in (V - 2 - 2 * k, V - 1 - 2 * k):       # the two rows of pair V/2 - 1 - k
+                own[row] = own[row] + u
+                r_pair[row] = r_pair[row] - (u.double() @ r.double()).float() * u
+    w = beta * own + c_deep * sign * r_pair + noise * (s0 * math.sqrt(3.0 / D))
     # the code coordinate of pair m: a fixed hash of the pair index
     pair = rows >> 1
     j = ((pair * 2654435761) >> 7) % CODE_BITS
     p2 = torch.tensor(pc["p2"], device=device, dtype=torch.int64)[j]
     w[rows, p2] = c_code * sign[:, 0]
     w[:, pc["zero"]] = -c_code * sign[:, 0]
+    # WHICH pair: both rows of pair m read the tok coordinates with m's codeword (minus its sum on the zero coordinate, so
+    # that LayerNorm's mean shift cancels): + c_tok x 32 x amplitude / sigma for the pair of the current token, at most half
+    # of that for any other pair
+    all_cw = pair_codewords(V // 2 + SPECIAL_PAIRS, device)
+    cw = all_cw[torch.where(pair < SPECIAL_PAIRS, V // 2 + pair, pair)]   # the special pairs' rows: codewords no token carries
+    w[:, pc["tok"]] = c_tok * cw
+    w[:, pc["zero"]] += -c_tok * cw.sum(dim=1)
     sd["text.lm_head.weight"] = w.to(dtype)
     bias = _tensor("text.lm_head.bias", (V,), 0.05, seed, device, torch.float32)
     bias[config.tokenizer.eos_id] = -60.0
@@ -517,17 +593,41 @@ def synthetic_vqa_prompt(config: MoondreamConfig, index: int, seed: int = 0, n_q
 def synthetic_lora(config: MoondreamConfig, seed: int = 0, rank: int = 8, device="cpu", dtype=torch.bfloat16) -> dict:
     """A seeded LoRA "variant" in the nested layout the reference's ``variant_state_dict`` returns
     (lora.py:54-79): per decoder block A [rank, in] / B [out, rank] for attn.qkv, attn.proj, mlp.fc1, mlp.fc2.
-    Scales are large enough to move the logits (a wrong or missing side path changes the generated ids)."""
+    Scales are large enough to move the logits.  Round 6: the variant also changes the DISCRETE outcome, on purpose and with
+    a wide margin -- six rank rows of every block's qkv pair read (LN(x)[p1[j]] - LN(x)[zero]) and add -2 RHO x that to the
+    planted value dims (``_plant_code_path``), so the image code arrives NEGATED in p2 and every pair decision flips to the
+    other member: a missing or mis-applied side path gives the base model's ids, not a near-tie.  The random part of the
+    variant leaves the protected coordinates and the planted head's rows alone (its B rows there are zero)."""
     t = config.text
+    pc = protected_coords(config)
+    hd = t.dim // t.n_heads
+    group = t.n_heads // t.n_kv_heads
+    q_dim, kv_dim = t.n_heads * hd, t.n_kv_heads * hd
+    assert rank >= CODE_BITS + 1
     blocks = {}
     for i in range(t.n_layers):
-        def pair(name, out_f, in_f, gain):
-            a = _tensor(f"lora.{i}.{name}.A", (rank, in_f), 1.0 / math.sqrt(in_f), seed, device, dtype)
-            b = _tensor(f"lora.{i}.{name}.B", (out_f, rank), gain / math.sqrt(rank), seed, device, dtype)
-            return {"A": a, "B": b}
+        def pair(name, out_f, in_f, gain, zero_out_rows=()):
+            a = _tensor(f"lora.{i}.{name}.A", (rank, in_f), 1.0 / math.sqrt(in_f), seed, device, torch.float32)
+            b = _tensor(f"lora.{i}.{name}.B", (out_f, rank), gain / math.sqrt(rank), seed, device, torch.float32)
+            if len(zero_out_rows):
+                b[list(zero_out_rows)] = 0.0
+            return a, b
 
+        kvh = i % t.n_kv_heads
+        v_rows = [q_dim + kv_dim + kvh * hd + j for j in range(CODE_BITS)]
+        q_rows = list(range(kvh * group * hd, (kvh * group + 1) * hd))
+        qa, qb = pair("qkv", t.qkv_dim, t.dim, 0.5, v_rows + q_rows)
+        qa[:CODE_BITS] = 0.0
+        qb[:, :CODE_BITS] = 0.0
+        for j in range(CODE_BITS):
+            qa[j, pc["p1"][j]], qa[j, pc["zero"]] = 1.0, -1.0
+            qb[v_rows[j], j] = -2.0 * CODE_RHO
+        pa, pb = pair("proj", t.dim, t.dim, 0.5, pc["all_text"])
+        f1a, f1b = pair("fc1", t.ff_dim, t.dim, 0.5)
+        f2a, f2b = pair("fc2", t.dim, t.ff_dim, 0.25, pc["all_text"])
+        cast = lambda x: x.to(dtype)
         blocks[str(i)] = {
-            "attn": {"qkv": pair("qkv", t.qkv_dim, t.dim, 0.5), "proj": pair("proj", t.dim, t.dim, 0.5)},
-            "mlp": {"fc1": pair("fc1", t.ff_dim, t.dim, 0.5), "fc2": pair("fc2", t.dim, t.ff_dim, 0.25)},
+            "attn": {"qkv": {"A": cast(qa), "B": cast(qb)}, "proj": {"A": cast(pa), "B": cast(pb)}},
+            "mlp": {"fc1": {"A": cast(f1a), "B": cast(f1b)}, "fc2": {"A": cast(f2a), "B": cast(f2b)}},
         }
     return {"text": {"blocks": blocks}}

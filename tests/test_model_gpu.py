@@ -422,7 +422,7 @@ def vqa64_vs_reference(model, cfg, sd, imgs64, golden_dir):
           f"teacher-forced: {rep['parity_tf_decisions_must_match']} must-match decisions, {rep['parity_tf_decisions_violations']} violations")
     assert second["max_logit_err"] <= 0.5
     assert rep["parity_ok"], rep["parity_note"]
-    assert rep["parity_tf_decisions_must_match"] >= 1800 and rep["parity_tf_decisions_violations"] == 0
+    assert rep["parity_exact"] == 64 and rep["parity_tf_decisions_must_match"] == 64 * 33 and rep["parity_tf_decisions_violations"] == 0
     # the sequences whose every margin clears the licence are identical outright
     wide = [i for i in range(64) if float(gv["margins"][i].min()) > rep["parity_threshold"]]
     assert wide and all(got[i] == gv["tokens"][i].tolist() for i in wide), wide
@@ -1087,6 +1087,13 @@ def detect13_vs_reference(model, golden_dir):
     print(f"detect13 at 2B: {rep['objects_compared']} objects with every decision >= {rep['margin_floor_ulps']} ulps compared exactly, "
           f"{rep['objects_mismatched']} mismatched")
     assert rep["ok"], rep
+    # round 6: the region heads decide with >= 120 bf16 ulps on every object of the fixture (planted anchors): ALL objects compare
+    assert rep["objects_compared"] == sum(len(g[f"img{i}.objects"]) for i in range(n)) == 32, rep
+    for i in range(n):   # and they are the anchors the image's code spells (synth.region_anchor): the planted path, end to end
+        bits = synth.image_code_bits(i)
+        x, y = synth.region_anchor(bits, "x_first") / 1024, synth.region_anchor(bits, "y") / 1024
+        o = res[i]["objects"][0]
+        assert abs((o["x_min"] + o["x_max"]) / 2 - x) < 1e-6 and abs((o["y_min"] + o["y_max"]) / 2 - y) < 1e-6, (i, o, x, y)
     one = model.detect(imgs[3], obj, settings=st)
     k = P.leading_wide_objects(g["img3.margins"], 4.0)
     assert one["objects"][:k] == res[3]["objects"][:k]
@@ -1162,6 +1169,13 @@ def batch_equals_sequential_unfiltered(model, imgs64, prompt, got64_default, ref
     assert same_ds >= 32 and same_strict >= 32  # quantified above; the hard claims are the strict-mode equality and the margin bound
 
 
+# End-of-stack activation tolerance at full size (27 ViT blocks / 24 decoder blocks, sampled): relative RMS against the reference.
+# The reference itself is 9.6e-3 from an fp64 evaluation at that depth and so is this path (test_vit_error_against_fp64_truth...);
+# rounds 1-5 allowed 1.5e-2, the round-5 review asked for 1.25e-2 -- the per-layer profile on the tiny model
+# (test_per_layer_drift_profile_...) is what catches a single bad layer.
+ACT_TOL = 1.25e-2
+
+
 def mutation_sensitivity(model, cfg, g, images, imgs64, pr, gb):
     """The parity gates must be able to FAIL.  Each mutation plants ONE local fault of the kind a kernel bug produces into the
     packed weights of the 2B model -- (a) one attention head of one ViT block lost (its 72 input columns of the block's proj
@@ -1189,7 +1203,7 @@ def mutation_sensitivity(model, cfg, g, images, imgs64, pr, gb):
         act = {"vit.out": rel_rms(feats[:, ::ts, ::fs], bits_to_bf16(g["img0.vit.out"]))}
         for li in (0, cfg.text.n_layers - 1):
             act[f"k{li}"] = rel_rms(enc.caches[li][0][0, :, ::rs], bits_to_bf16(g[f"img0.cap.k{li}"]))
-        failed = [k for k, v in act.items() if v > 1.5e-2] + ([] if rep["parity_ok"] else ["ids report"])
+        failed = [k for k, v in act.items() if v > ACT_TOL] + ([] if rep["parity_ok"] else ["ids report"])
         return failed, rep, act
 
     failed, rep, act = gates()
@@ -1291,11 +1305,11 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
     arr = np.array(images[0])
     feats = model._vis_enc(O.normalize_crops(np.stack([arr, arr])).cuda())
     ts, fs = int(g["vit_token_stride"]), int(g["vit_feat_stride"])
-    compare(f"{cfg_name} vit.out", feats[:, ::ts, ::fs], bits_to_bf16(g["img0.vit.out"]), 1.5e-2)
+    compare(f"{cfg_name} vit.out", feats[:, ::ts, ::fs], bits_to_bf16(g["img0.vit.out"]), ACT_TOL)
     enc = model.encode_image(images[0])
     rs = int(g["kv_row_stride"])
     for li in (0, cfg.text.n_layers - 1):
-        compare(f"{cfg_name} k{li}", enc.caches[li][0][0, :, ::rs], bits_to_bf16(g[f"img0.cap.k{li}"]), 1.5e-2)
+        compare(f"{cfg_name} k{li}", enc.caches[li][0][0, :, ::rs], bits_to_bf16(g[f"img0.cap.k{li}"]), ACT_TOL)
     # top-8 logits of the prompt prefill
     model.load_encoded_image(enc)
     logits, _, _ = model._prefill_prompts([prompts[0]], enc.pos, 0)
@@ -1349,7 +1363,10 @@ def test_full_size_models_vs_reference(golden_dir, name, cfg_name):
               f"with a reference margin above the licence, {rep['parity_tf_decisions_violations']} of them differ "
               f"({rep['parity_tf_decisions_agree']} of {rep['parity_decisions']} decisions agree in all)")
         assert rep["parity_ok"], rep["parity_note"]
-        assert rep["parity_tf_decisions_must_match"] >= 1800 and rep["parity_tf_decisions_violations"] == 0
+        # round 6: the fixture is well-conditioned (every reference margin >= 8, tests/test_parity_cpu.py) -- ALL 64 sequences and
+        # ALL 64 x 33 teacher-forced decisions must equal the reference's; the licence machinery above has nothing left to license
+        assert rep["parity_exact"] == 64 and rep["parity_must_match"] == 64, (rep["parity_exact"], rep["parity_must_match"])
+        assert rep["parity_tf_decisions_must_match"] == 64 * 33 and rep["parity_tf_decisions_violations"] == 0
         for i in g["image_index"].tolist():  # the wide-margin images of md2b_seed1 are among the 64: exact
             assert got64[i] == gb["tokens"][i].tolist(), i
     vqa64_vs_reference(model, cfg, sd, imgs64, golden_dir)

@@ -113,15 +113,21 @@ def test_logit_error_in_bf16_ulps():
 
 
 def test_reference_fixture_against_itself():
-    """tests/golden/md2b_bench64.npz: the reference's own ids are 64/64; the fixture's tie / narrow-margin census is the one
-    the bench's exact-count floor is argued from."""
+    """tests/golden/md2b_bench64.npz / md2b_vqa64.npz: the reference's own ids are 64/64 and every decision of both bench
+    fixtures is wide-margin."""
     g = np.load(os.path.join(GOLD, "md2b_bench64.npz"))
     ids = g["tokens"].tolist()
     rep = P.parity_report(ids, ids, g["margins"], g["top8_val"], g["top8_val"], tokens=32, min_exact=64)
     assert rep["parity_ok"] and rep["parity_exact"] == 64 and rep["parity_threshold"] == 0.0
-    m = g["margins"][:, :32]
-    assert int((m.min(axis=1) == 0.0).sum()) == 9          # sequences with an exact tie somewhere
-    assert int((m.min(axis=1) > 0.25).sum()) == 12         # sequences every decision of which is wider than 0.25
+    # round 6: the fixture is WELL-CONDITIONED -- every one of the 64 x 33 decisions of the reference has a top-1 / top-2 margin
+    # far above the measured logit error (0.31), so "ids equal the reference's" is a requirement on every sequence, not a
+    # licensed statistic (rounds 1-5: 9 sequences held an exact tie, 12 had every margin above 0.25)
+    m = g["margins"]
+    assert m.shape == (64, 33) and float(m.min()) >= 2.0, float(m.min())
+    assert rep["parity_must_match"] == 64 and rep["parity_tf_decisions_must_match"] == 64 * 33
+    assert len({tuple(t) for t in ids}) >= 48              # and the streams still differ from image to image
+    v = np.load(os.path.join(GOLD, "md2b_vqa64.npz"))
+    assert v["margins"].shape == (64, 33) and float(v["margins"].min()) >= 2.0, float(v["margins"].min())
 
 
 def test_detect_parity_compares_leading_wide_objects_exactly():
@@ -307,12 +313,14 @@ def test_fp8_contract_and_fp8_detect_parity_helpers():
     gd = np.load(os.path.join(GOLD, "md2b_detect13.npz"))
     objs = [[dict(zip(("x_min", "y_min", "x_max", "y_max"), o)) for o in np.asarray(gd[f"img{i}.objects"]).reshape(-1, 4).tolist()]
             for i in range(int(gd["n_images"]))]
+    # round 6: every object decision of the fixture clears the fp8 licence (>= 120 of 96 bf16 ulps): the fp8 mode's objects ARE
+    # validated at the object level -- ok is True / False, never None
     r = P.detect_parity_fp8(objs, gd)
-    assert r["ok"] is None and "THROUGHPUT ONLY" in r["verdict"] and r["objects_equal"] == r["objects_paired"] == 32
+    assert r["ok"] is True and r["objects_compared"] == r["objects_equal"] == r["objects_paired"] == 32 and "equal the reference" in r["verdict"]
     assert r["centre_error_bins_median_p90_max"] == [0.0, 0.0, 0.0]
     objs[0][0]["y_min"] += 0.01   # 0.01 of the image height: the centre moves by 0.005 x 1024 bins
     r = P.detect_parity_fp8(objs, gd)
-    assert r["objects_equal"] == 31 and abs(r["centre_error_bins_median_p90_max"][2] - 5.12) < 1e-6
-    # with a licence the fixture can clear, equality is enforced
-    r4 = P.detect_parity_fp8(objs, gd, licence_ulps=1.0)
-    assert r4["objects_compared"] > 0 and r4["ok"] is False
+    assert r["ok"] is False and r["objects_equal"] == 31 and abs(r["centre_error_bins_median_p90_max"][2] - 5.12) < 1e-6
+    # a licence no object of the fixture clears: stated as what it is (throughput only), not as a pass
+    r4 = P.detect_parity_fp8(objs, gd, licence_ulps=1e6)
+    assert r4["objects_compared"] == 0 and r4["ok"] is None and "THROUGHPUT ONLY" in r4["verdict"]

@@ -183,26 +183,56 @@ def _set_affinity_all_threads(cpus):
     return prev
 
 
-def reference_cpu_timing(cfg, sd, seed, T, n_images=3):
+def reference_cpu_timing(cfg, sd, seed, T, n_images=3, threads=None):
     """The UNMODIFIED reference (moondream/torch under MOONDREAM_REFERENCE or /root/reference; tokenizer stubbed, the same seeded
     synthetic weights) on this host's cores: B = 1 sequential, encode_image + the answer generator, wall clock, one warm-up image
-    then ``n_images - 1`` timed (method of the reference's sample.py:159-207).  Only where the checkout exists -- never on the GPU
-    box; a checker-side measurement, outside every timed region."""
+    then ``n_images - 1`` timed (method of the reference's sample.py:159-207).  Only where the checkout exists -- never on the
+    driver's GPU box; a checker-side measurement, outside every timed region.
+
+    ``threads`` = (encode, decode) torch thread counts and the process is pinned to the physical cores of one NUMA node -- the
+    SAME treatment ``cpu_baseline`` gives the port (round 6: with torch's default of one thread per logical CPU the reference
+    took 28 s per image on a 256-thread host, 8x slower than the port beside it, which says nothing about either)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import make_golden as mg
     from moondream_amd import synth
 
     model, ref_md = mg.load_reference(cfg, {k: v.cpu() for k, v in sd.items()})
     prompt = cfg.tokenizer.templates["caption"]["normal"]
+    default_threads = torch.get_num_threads()
+    prev_masks = None
+    if threads is not None:
+        enc_t, dec_t = (max(1, int(x)) for x in threads)
+
+        def with_threads(fn, n):
+            def f(*a, **k):
+                torch.set_num_threads(n)
+                return fn(*a, **k)
+            return f
+
+        # instance attributes shadow the class's methods: the reference's own code, run under a thread count per phase
+        model._vis_enc, model._vis_proj = with_threads(model._vis_enc, enc_t), with_threads(model._vis_proj, enc_t)
+        model._prefill, model._decode_one_tok = with_threads(model._prefill, enc_t), with_threads(model._decode_one_tok, dec_t)
+        cpus, _ = _one_numa_node_physical_cores()
+        prev_masks = _set_affinity_all_threads(cpus)
     t_enc, t_gen = [], []
-    for i in range(n_images):
-        r = mg.run_reference_caption(model, ref_md, synth.synthetic_image_array(i, seed, (378, 378)), prompt, T)
-        t_enc.append(r["t_enc"])
-        t_gen.append(r["t_gen"])
+    try:
+        for i in range(n_images):
+            r = mg.run_reference_caption(model, ref_md, synth.synthetic_image_array(i, seed, (378, 378)), prompt, T)
+            t_enc.append(r["t_enc"])
+            t_gen.append(r["t_gen"])
+    finally:
+        torch.set_num_threads(default_threads)
+        if prev_masks:
+            for tid, mask in prev_masks.items():
+                try:
+                    os.sched_setaffinity(tid, mask)
+                except OSError:
+                    pass
     enc, gen = float(np.median(t_enc[1:])), float(np.median(t_gen[1:]))
-    return {"images_per_sec": 1.0 / (enc + gen), "threads": torch.get_num_threads(), "encode_s": enc, "generate_s": gen,
+    how = f"{default_threads} torch threads" if threads is None else f"{enc_t} / {dec_t} torch threads (encode / decode), one NUMA node's physical cores"
+    return {"images_per_sec": 1.0 / (enc + gen), "threads": default_threads if threads is None else max(enc_t, dec_t), "encode_s": enc, "generate_s": gen,
             "sample": f"the unmodified reference, B=1, {n_images - 1} images after one warm-up: encode_image {enc:.2f}s + {T} greedy tokens "
-                      f"{gen:.2f}s, {torch.get_num_threads()} torch threads"}
+                      f"{gen:.2f}s, {how}"}
 
 
 def cpu_baseline(cfg, sd, seed, T, budget_s=30.0):
@@ -766,19 +796,20 @@ def main():
     # on itself: the algorithmic bytes beside it are live (this run's launches), the counter figure is the
     # committed pass of the same command.
     traffic = {"algorithmic_read_bytes_per_step": alg_rd.value, "algorithmic_written_bytes_per_step": alg_wr.value,
-               "measured": None, "note": "no profiles/r05_pmc_traffic.json"}
+               "measured": None, "note": "no profiles/r0N_pmc_traffic.json"}
     try:
-        with open(os.path.join(REPO, "profiles", "r05_pmc_traffic.json")) as f:
+        pmc_file = next(n for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json") if os.path.isfile(os.path.join(REPO, "profiles", n)))
+        with open(os.path.join(REPO, "profiles", pmc_file)) as f:
             tg = json.load(f)["tile_gemm"]
         rd, wr = 2.0 * tg["FETCH_SIZE_kb_sum"] * 1024.0, tg["WRITE_SIZE_kb_sum"] * 1024.0
         traffic.update({
             "measured": {"read_bytes_per_step": rd, "written_bytes_per_step": wr, "launches": tg["launches"]},
             "read_ratio": rd / alg_rd.value if alg_rd.value else None,
             "write_ratio": wr / alg_wr.value if alg_wr.value else None,
-            "note": "profiles/r05_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager B=64 step "
+            "note": f"profiles/{pmc_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager B=64 step "
                     "(2 x FETCH_SIZE per the gfx950 note; L2-miss side, Infinity-Cache hits included)",
         })
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
+    except (OSError, KeyError, ValueError, ZeroDivisionError, StopIteration):
         pass
     result = {
         "metric": "images_per_sec",
@@ -852,7 +883,7 @@ def main():
             "note": "all kernels of the vision phase (H2D of the crops, patchify, 27 blocks incl. attention and layer norms, stitch, "
                     "projector), 2 crops/image (666.45 GFLOP each) + projector (51.98 GFLOP/image); the host-side tiling the eager "
                     "step waits for first is phase_ms.host_tiling (hidden behind the previous step's decode in the timed region)",
-            "activation_tolerance": "ViT outputs vs the reference's: 1.5e-2 rel-RMS in the -m gpu tests (measured floor 1.02e-2); the north "
+            "activation_tolerance": "ViT outputs vs the reference's: 1.25e-2 rel-RMS in the -m gpu tests (measured 1.07e-2; per-layer profile on the tiny model within 1.3x of the oracle's drift at every block); the north "
                                     "star's 1e-3 is below what bf16 allows: against an fp64 evaluation of the same weights the reference "
                                     "itself sits at 9.633e-3 rel-RMS and this path at 9.616e-3 (test_vit_error_against_fp64_truth_no_worse_than_reference)",
         }
@@ -1130,7 +1161,9 @@ def main():
         ref_root = os.environ.get("MOONDREAM_REFERENCE", "/root/reference")
         if os.path.isdir(os.path.join(ref_root, "moondream", "torch")):
             try:
-                rt = reference_cpu_timing(cfg, sd, args.seed, T)
+                det = result["cpu_baseline"].get("details") or {}
+                thr = (det["encode_threads"], det["decode_threads"]) if "encode_threads" in det and "decode_threads" in det else None
+                rt = reference_cpu_timing(cfg, sd, args.seed, T, threads=thr)
                 result["cpu_baseline"].update({"kind": "reference", "value": rt["images_per_sec"], "cores": rt["threads"], "port_value": est,
                                                "sample": rt["sample"]})
             except Exception as e:  # a checkout that does not import (missing dependency): the port's figure stands, loudly

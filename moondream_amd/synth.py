@@ -41,10 +41,9 @@ TOK_BITS = 32                             # protected decoder coordinates that c
 CAST_LEVELS = (-0.6, -0.2, 0.2, 0.6)      # normalised ((x / 255 - 0.5) / 0.5) channel means of the four levels
 CAST_NOISE = 0.35                         # amplitude of the uniform pixel noise around the level (no clipping: 0.6 + 0.35 < 1)
 CODE_GAMMA = 8.0                          # ViT protected coordinates: GAMMA x channel mean, and the constant reference GAMMA
-# projector threshold units: K.  u = K x GAMMA x (level - theta) / sigma with sigma ~ 7.3: 5.3 at the nearest threshold (saturated:
-# S = 1.0000 / 0.0000), 26 at the farthest, where a bf16 GELU output resolves 1/8: +-0.03 of random rounding per token in the code
-# coordinates, averaged away over the 729 keys (K = 64 made that +-0.12 and cost the tiny model's K rows 0.5e-2 of relative RMS)
-CODE_STEEP = 24.0
+CODE_STEEP = 6.0                          # projector units: v = K x GAMMA x level / sigma = +-1.3 (inner levels) / +-4.0 (outer levels)
+CODE_SIGMA = 7.3                          # nominal standard deviation of the ViT's last residual stream (tiny 7.2, 2B 7.3): only the
+                                          # read-out constants of the "lo" bit depend on it (its midpoint tracks sigma through LN[ref])
 CODE_RHO = 1.0                            # decoder: V copy gain of the code coordinates
 DEFAULT_CODE = (1, -1, -1, 1, -1, 1)      # the code of "no image": carried by every token embedding
 IMAGE_CODE_AMPLITUDE = 0.5                # an image embedding carries its code as +-0.5 ...
@@ -213,11 +212,12 @@ def token_code_amplitude(config: MoondreamConfig) -> float:
 
 def image_code_bits(index: int) -> list:
     """The 6 code bits (+1 / -1) of synthetic image ``index``: class = index mod 64, two bits per colour channel (level = 2 hi + lo
-    in thermometer-friendly order: level 0 -> (-1, -1), 1 -> (-1, +1), 2 -> (+1, -1), 3 -> (+1, +1))."""
+    hi = the sign of the level (levels 2, 3 -> +1), lo = inner level (levels 1, 2 -> +1): 0 -> (-1, -1), 1 -> (-1, +1), 2 -> (+1, +1),
+    3 -> (+1, -1))."""
     levels = image_cast_levels(index)
     bits = []
     for lv in levels:
-        bits += [1 if lv >= 2 else -1, 1 if lv in (1, 3) else -1]
+        bits += [1 if lv >= 2 else -1, 1 if lv in (1, 2) else -1]
     return bits
 
 
@@ -240,9 +240,10 @@ def _plant_code_path(sd, config, dtype):
       * patch embedding (vision.py:67): three rows average the normalised pixels of one colour channel (GAMMA x mean), one row is
         the constant GAMMA (bias), one is 0.  No ViT block writes to these five coordinates (zero rows in proj / fc2), every block
         reads them like any other feature; post_ln passes them with weight 1 / bias 0.
-      * vision projection (vision.py:77-89): per channel three threshold units pairs gelu(K u + 1) - gelu(K u - 1) (= 0 or 2 once
-        saturated) with u = (v_c - v_0) - theta (v_ref - v_0): LayerNorm's mean shift cancels against the zero coordinate, its scale
-        against the reference coordinate.  fc2 turns the thermometer code into 6 coordinates of +-0.5 (p1) in every image embedding.
+      * vision projection (vision.py:77-89): per channel four hidden units of v = K (LN[c] - LN[zero]) -- gelu(v + 1) - gelu(v - 1)
+        (~0 / ~2: the sign of the level) and gelu(v) + gelu(-v) (~|v|: inner or outer level, against a midpoint that tracks
+        LayerNorm's scale through the reference coordinate); LayerNorm's mean shift cancels against the zero coordinate.  Every
+        unit output stays below 5 (e4m3-safe).  fc2 turns them into 6 coordinates of +-0.5 (p1) in every image embedding.
       * every decoder block: one attention head (l mod n_kv_heads; its query rows are zero, i.e. it attends uniformly) copies
         RHO (LN(x)[p1] - LN(x)[zero]) into six of its value dims; proj writes them to p2.  What accumulates in p2 at a text
         position is RHO x sum over layers of the key-average of p1 / row sigma: 729 image keys at amplitude 0.5 against a few text
@@ -278,38 +279,50 @@ def _plant_code_path(sd, config, dtype):
             edit(f"vision.blocks.{i}.{name}.bias", zero_rows(pc["all_vit"]))
     edit("vision.post_ln.weight", lambda w: w.__setitem__(pc["all_vit"], 1.0))
     edit("vision.post_ln.bias", zero_rows(pc["all_vit"]))
-    # projector: the LAST 18 hidden units are the threshold pairs; they read the GLOBAL crop's features (columns [0, enc_dim))
-    thetas = (-0.4, 0.0, 0.4)
-    n_units = 3 * len(thetas) * 2
+    # projector: the LAST 14 hidden units decode the levels; they read the GLOBAL crop's features (columns [0, enc_dim)).
+    # With v = K (LN[c] - LN[zero]) = K x GAMMA x level / sigma (nominally +-1.3 for the inner levels, +-4.0 for the outer ones):
+    #   d = gelu(v + 1) - gelu(v - 1)  ~ 0 for a negative level, ~ 2 for a positive one     -> the "hi" bit (sign of the level)
+    #   G = gelu(v) + gelu(-v) ~ |v|                                                         -> the "lo" bit (inner vs outer level),
+    #       against the midpoint m x r, r = LN[ref] - LN[zero] = GAMMA / sigma carried by a pass-through pair gelu(r) - gelu(-r) = r
+    # EVERY unit output stays below 5: the first version (three threshold pairs per channel, outputs up to 27) needed the
+    # difference of two LARGE GELU outputs to be exact, which holds in bf16 and not after the fp8 mode's e4m3 quantisation of
+    # the projector's hidden activations (the code bits of a quarter of the images flipped there).
+    K = CODE_STEEP
+    n_units = 3 * 4 + 2
     u0 = v.proj_inner_dim - n_units
+    U = lambda c, k: u0 + 4 * c + k          # channel c: gelu(v + 1), gelu(v - 1), gelu(v), gelu(-v)
+    R_POS, R_NEG = u0 + 12, u0 + 13          # gelu(r), gelu(-r)
     def fc1_w(w):
         w[u0:] = 0.0
         for c, col in enumerate(pc["vit_rgb"]):
-            for k, th in enumerate(thetas):
-                for s in range(2):
-                    row = u0 + (c * len(thetas) + k) * 2 + s
-                    w[row, col] = CODE_STEEP
-                    w[row, pc["vit_ref"]] = -CODE_STEEP * th
-                    w[row, pc["vit_zero"]] = -CODE_STEEP * (1.0 - th)
+            for k, sg in enumerate((K, K, K, -K)):
+                w[U(c, k), col], w[U(c, k), pc["vit_zero"]] = sg, -sg
+        w[R_POS, pc["vit_ref"]], w[R_POS, pc["vit_zero"]] = 1.0, -1.0
+        w[R_NEG, pc["vit_ref"]], w[R_NEG, pc["vit_zero"]] = -1.0, 1.0
     def fc1_b(b):
-        for i in range(n_units // 2):
-            b[u0 + 2 * i], b[u0 + 2 * i + 1] = 1.0, -1.0
+        b[u0:] = 0.0
+        for c in range(3):
+            b[U(c, 0)], b[U(c, 1)] = 1.0, -1.0
     edit("vision.proj_mlp.fc1.weight", fc1_w)
     edit("vision.proj_mlp.fc1.bias", fc1_b)
+    # the linear read-out of the units, solved on the four nominal levels in float64 (a few scalars: the same bits everywhere)
+    gelu = lambda x: 0.5 * x * (1.0 + math.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+    r_nom = CODE_GAMMA / CODE_SIGMA
+    g_inner, g_outer = (gelu(K * r_nom * lv) + gelu(-K * r_nom * lv) for lv in (CAST_LEVELS[2], CAST_LEVELS[3]))
+    lo_mid, lo_half = 0.5 * (g_inner + g_outer) / r_nom, 0.5 * (g_outer - g_inner)
     def fc2_w(w):
-        w[:, u0:] = 0.0          # the threshold units feed the code coordinates only
+        w[:, u0:] = 0.0          # the planted units feed the code coordinates only
         w[pc["all_text"]] = 0.0  # and nothing else writes the protected coordinates of an image embedding
+        A = IMAGE_CODE_AMPLITUDE
         for c in range(3):
-            S = lambda k: (u0 + (c * len(thetas) + k) * 2, u0 + (c * len(thetas) + k) * 2 + 1)  # (plus, minus) unit of threshold k
             hi, lo = pc["p1"][2 * c], pc["p1"][2 * c + 1]
-            # S_k = 0.5 (u+ - u-) in {0, 1};  hi = 2 S_1 - 1 (level >= 2);  lo = 2 (S_0 - S_1 + S_2) - 1 (level 1 or 3)
-            A = IMAGE_CODE_AMPLITUDE
-            w[hi, S(1)[0]], w[hi, S(1)[1]] = A, -A
-            for k, sg in ((0, A), (1, -A), (2, A)):
-                w[lo, S(k)[0]], w[lo, S(k)[1]] = sg, -sg
+            w[hi, U(c, 0)], w[hi, U(c, 1)] = A, -A                       # hi = A (d - 1)            (bias below)
+            w[lo, U(c, 2)], w[lo, U(c, 3)] = -A / lo_half, -A / lo_half  # lo = A (m r - G) / half: +1 inner level, -1 outer
+            w[lo, R_POS], w[lo, R_NEG] = A * lo_mid / lo_half, -A * lo_mid / lo_half
     def fc2_b(b):
         b[pc["all_text"]] = 0.0
-        b[pc["p1"]] = -IMAGE_CODE_AMPLITUDE
+        for c in range(3):
+            b[pc["p1"][2 * c]] = -IMAGE_CODE_AMPLITUDE
     edit("vision.proj_mlp.fc2.weight", fc2_w)
     edit("vision.proj_mlp.fc2.bias", fc2_b)
 

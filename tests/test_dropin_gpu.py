@@ -124,7 +124,9 @@ def test_reference_detect_and_point_on_the_hip_seam(tiny_bound, golden_dir, case
     assert n_ok >= 1 and len(objs) >= n_ok
     keys = ("x_min", "y_min", "x_max", "y_max") if kind == "detect" else ("x", "y")
     for k in range(n_ok):
-        assert [objs[k][f] for f in keys] == ref[k].tolist(), (case, k, objs[k], ref[k])
+        # the same BINS (the region heads' argmaxes); the floats come out of the reference's own torch.pow / division, which
+        # its GPU build and its CPU build round differently in the last bits (1.5e-8 seen)
+        assert [objs[k][f] for f in keys] == pytest.approx(ref[k].tolist(), abs=1e-6), (case, k, objs[k], ref[k])
 
 
 def test_reference_spatial_query_on_the_hip_seam(tiny_bound, golden_dir):

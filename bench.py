@@ -727,8 +727,9 @@ def main():
     if args.w4_grid and not args.no_pipeline:
         _lib.check(lib.md_gemm_set_tuning(b"w4_grid", args.w4_grid))
     if args.warmup:
-        # pipelined mode alternates two KV slot groups: warm both (graph capture) before timing
-        run_steps(args.warmup if args.no_pipeline else max(2, args.warmup))
+        # pipelined mode alternates two KV slot groups and decodes two consecutive batches as one lockstep of 128 (round 6:
+        # MoondreamModel.pair_decode): warm both groups (graph capture of the paired decode at either slot base) before timing
+        run_steps(args.warmup if args.no_pipeline else max(4, args.warmup))
     engine.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -838,7 +839,10 @@ def main():
             # the rest of what the pipelining buys (no-pipeline: 292.8 ms) is host work hidden: tiling, launches, D2H
             "host_latency_hiding": "none" if args.no_pipeline else "step i+1's host tiling (thread pool) + encode launches run while step i "
                                    "decodes on a second, higher-priority HIP stream; step i's ids are collected (pinned, async D2H) after "
-                                   "step i+1 is queued; kernels of the two streams overlap on the GPU (3 % of a step vs one in-order stream)",
+                                   "step i+1 is queued; kernels of the two streams overlap on the GPU (3 % of a step vs one in-order stream)"
+                                   + ("; the decode of two consecutive steps runs as ONE lockstep of 128 sequences (each step is still "
+                                      "encoded on its own, 64 images per launch; md_decode_step takes 65..128 rows in one pass over the "
+                                      "weights, bit-identical to two passes of 64)" if model.pair_decode and 2 * args.batch <= 128 else ""),
             # every row of [bos | 729 image embeddings | prompt] goes through every decoder block, as in the reference;
             # the reference does it as two passes over the weights (encode_image, then the prompt)
             "prefill": "image prefix + prompt in one decoder pass" if model.fused_prefill else "image prefix, then prompt (two passes)",

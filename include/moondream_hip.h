@@ -117,10 +117,16 @@ typedef struct {
  *                     0xfffff000: ~150 000 rows of the 2B fused qkv|fc1 layer); a larger launch is cut into row blocks
  *                     of the same kernel (same bits), and one that cannot be cut -- a broadcast residual
  *                     (res_row_mod != 0), the RoPE epilogue -- returns MD_ERR_UNSUPPORTED instead of changing family.
+ *   MD_TILE_DECODE_TALL  (round 6; set by md_decode_step / md_text_forward themselves for a decode step of 65 .. 128 sequences, accepted
+ *                     from a caller of md_gemm_bf16 too) a launch of 65 .. 128 rows is a WEIGHT STREAM like the <= 64-row regime: one
+ *                     128 x 64 tile per weight panel (four compute waves + two DMA waves), the same K order per output element as
+ *                     the 64-row configs -- a sequence gets the same bits in a decode step of 128 as in one of 64; layers of
+ *                     >= 16384 output columns (lm_head) take the by-shape config (same MFMA family, same K order).  Other row
+ *                     counts: as MD_TILE_BY_SHAPE.
  * md_vit_model.tile_policy / md_text_model.tile_policy apply it to every GEMM of md_vit_encode / md_vision_project* /
  * md_text_forward* / md_lm_head / md_decode_step made with that struct.  Launches of <= 64 rows (the decode regime) are
  * not affected: they always take the split-K weight-streaming configs. */
-enum { MD_TILE_BY_SHAPE = 0, MD_TILE_PINNED = 1 };
+enum { MD_TILE_BY_SHAPE = 0, MD_TILE_PINNED = 1, MD_TILE_DECODE_TALL = 2 };
 
 md_status md_gemm_bf16(const md_gemm_args* args, void* stream);
 size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols);

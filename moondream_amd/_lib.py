@@ -21,7 +21,7 @@ SOURCES = ["gemm_bf16.hip", "gemm_w4.hip", "gemm_fp8w.hip", "gemm_f8.hip", "quan
 MD_OK = 0
 ABI_VERSION = 5  # include/moondream_hip.h MD_ABI_VERSION
 MD_EPI_BIAS, MD_EPI_GELU, MD_EPI_RESIDUAL = 0, 1, 2
-MD_TILE_BY_SHAPE, MD_TILE_PINNED = 0, 1  # md_gemm_args / md_vit_model / md_text_model .tile_policy (ABI 5)
+MD_TILE_BY_SHAPE, MD_TILE_PINNED, MD_TILE_DECODE_TALL = 0, 1, 2  # md_gemm_args / md_vit_model / md_text_model .tile_policy (ABI 5; 2: round 6)
 MD_CROPS_U8_HWC, MD_CROPS_BF16_CHW = 0, 1
 
 c_void_p, c_int32, c_int64, c_size_t, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float

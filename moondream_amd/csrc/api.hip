@@ -42,7 +42,19 @@ struct TilePolicyScope {
   TilePolicyScope(const TilePolicyScope&) = delete;
   TilePolicyScope& operator=(const TilePolicyScope&) = delete;
 };
-inline bool tile_policy_ok(int p) { return p == MD_TILE_BY_SHAPE || p == MD_TILE_PINNED; }
+inline bool tile_policy_ok(int p) { return p == MD_TILE_BY_SHAPE || p == MD_TILE_PINNED || p == MD_TILE_DECODE_TALL; }
+
+// Round 6: a decode step (q_len 1) of 65 .. 128 sequences as ONE pass over the weights -- the fused qkv|fc1 GEMM on the 128 x 64
+// weight-streaming tile, proj / fc2 as K-slice partials of 128 rows + the fused tail, lm_head on its by-shape config -- instead of
+// two passes of 64 rows.  Same K order per output element as the 64-row regime: a sequence gets the same bits either way.
+// Measured (tools/bench_decode_gemm_m128.py): qkv|fc1 19.8 us vs 2 x 16.4, pair 20.3 vs 2 x 13.7, lm_head 57 vs 2 x 54.
+// MD_DECODE_TALL=0: the round-5 behaviour (blocks of 64).  Not with the fp8 weight stream attached (its kernels are <= 64 rows).
+inline bool decode_tall_model(const md_text_model* m) {
+  static const bool allowed = [] { const char* e = getenv("MD_DECODE_TALL"); return !(e && e[0] == '0'); }();
+  return allowed && m->blocks[0].qkv_fc1.w != nullptr && m->n_kv_heads == m->n_heads && !(m->fp8 && m->fp8->blocks) &&
+         m->blocks[0].proj.b && m->blocks[0].fc2.b && m->blocks[0].proj.n == m->dim && m->blocks[0].fc2.n == m->dim && m->dim % 8 == 0;
+}
+inline bool decode_tall_rows(const md_text_model* m, int64_t rows, int q_len) { return q_len == 1 && rows > 64 && rows <= 128 && decode_tall_model(m); }
 
 md_status gemm(const void* a, int64_t lda, const md_linear& lin, void* c, int64_t ldc, int m, int epi,
                const void* r, int64_t ldr, int res_row_mod, int store_pad, hipStream_t s,
@@ -161,7 +173,8 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
   }
   // decode regime: split-K scratch shared by the layer's four linears (stream-ordered)
   size_t sk = 0;
-  if (M <= 64) {
+  const bool tall = decode_tall_rows(m, (int64_t)M, q_len);
+  if (M <= 64 || tall) {
     const md_text_block& b0 = m->blocks[0];
     sk = std::max(std::max(md_gemm_workspace_bytes(&b0.qkv, (int)M, 0), md_gemm_workspace_bytes(&b0.proj, (int)M, 0)),
                   std::max(md_gemm_workspace_bytes(&b0.fc1, (int)M, 1), md_gemm_workspace_bytes(&b0.fc2, (int)M, 0)));
@@ -171,7 +184,7 @@ TextWs text_layout(const md_text_model* m, int batch, int q_len, void* base) {
   w.splitk = a.take(sk);
   w.part_a = w.part_b = nullptr;
   w.part_ld = w.part_stride = 0;
-  if (M <= 64) {
+  if (M <= 64 || tall) {
     const md_text_block& b0 = m->blocks[0];
     w.part_ld = ((int64_t)m->dim + 3) / 4 * 4;
     w.part_stride = (int64_t)M * w.part_ld;
@@ -393,8 +406,8 @@ extern "C" md_status md_vision_project_grid(const md_vit_model* m, const void* g
 extern "C" size_t md_text_workspace_bytes(const md_text_model* m, int32_t batch, int32_t q_len) {
   if (!m || !m->blocks || batch <= 0 || q_len <= 0) return 0;
   size_t need = text_layout(m, batch, q_len, nullptr).total;
-  // decode steps of more than 64 sequences run as blocks of 64 (the decode regime's row limit)
-  if (q_len == 1 && batch > 64) need = std::max(need, text_layout(m, 64, 1, nullptr).total);
+  // decode steps of more than 64 (128) sequences run as blocks of 64 (128: decode_tall_model) rows
+  if (q_len == 1 && batch > 64) need = std::max(need, std::max(text_layout(m, 64, 1, nullptr).total, text_layout(m, std::min(batch, 128), 1, nullptr).total));
   return need;
 }
 
@@ -414,12 +427,15 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
   MD_CHECK_ARG(batch > 0 && q_len > 0 && m->dim % m->n_heads == 0);
   MD_CHECK_ARG(tile_policy_ok(m->tile_policy));
   TilePolicyScope tile_scope(m->tile_policy);
-  if (q_len == 1 && batch > 64) {
-    // A decode step over more than 64 sequences: blocks of 64 rows, each through the decode-regime
-    // kernels (weight-streaming GEMMs, launch-boundary split-K, fused block tail).  The weights are
+  // the e4m3 copy of the KV cache (fp8 mode) keeps the 64-row blocks: its attention kernel is part of an opt-in mode tuned there
+  const bool tall_ok = decode_tall_model(m) && !(kv->k8 && kv->v8);
+  const int block_rows = tall_ok ? 128 : 64;
+  if (q_len == 1 && batch > block_rows) {
+    // A decode step over more sequences than the decode regime takes in one pass: blocks of 64 (128) rows, each through the
+    // decode-regime kernels (weight-streaming GEMMs, launch-boundary split-K, fused block tail).  The weights are
     // streamed once per block; the big-tile kernels this replaces ran the step ~1.5x slower at 128 rows.
-    for (int b0 = 0; b0 < batch; b0 += 64) {
-      const int nb = std::min(64, batch - b0);
+    for (int b0 = 0; b0 < batch; b0 += block_rows) {
+      const int nb = std::min(block_rows, batch - b0);
       md_kv_cache sub = *kv;
       sub.k = (char*)kv->k + (int64_t)b0 * kv->batch_stride * 2;
       sub.v = (char*)kv->v + (int64_t)b0 * kv->batch_stride * 2;
@@ -456,8 +472,10 @@ extern "C" md_status md_text_forward(const md_text_model* m, const void* x_in, v
   // decode regime (<= 64 rows): launch-boundary split-K for proj / fc2 + fused block tail.
   // A function of the row count only, like the choice of GEMM kernel.  MD_TEXT_TAIL=0: A/B runs.
   static const bool tail_allowed = [] { const char* e = getenv("MD_TEXT_TAIL"); return !(e && e[0] == '0'); }();
-  const bool tail_fused = tail_allowed && M <= 64 && D % 8 == 0 && m->blocks[0].proj.b && m->blocks[0].fc2.b &&
+  const bool tall = tall_ok && decode_tall_rows(m, M, q_len);   // 65 .. 128 rows of a decode step: one pass (decode_tall_model)
+  const bool tail_fused = tail_allowed && (M <= 64 || tall) && D % 8 == 0 && m->blocks[0].proj.b && m->blocks[0].fc2.b &&
                           m->blocks[0].proj.n == D && m->blocks[0].fc2.n == D;
+  TilePolicyScope tall_scope(tall ? MD_TILE_DECODE_TALL : t_tile_policy);
 
   // Prefill: RoPE + KV write in the epilogue of the fused qkv|fc1 GEMM (MD_EPI_QKV_ROPE) when the four-wave kernel takes the
   // shape: MHA, head_dim 64, rot_dim 32, slab offsets in 32 bits.  Per-row positions / slab offsets once per forward.
@@ -798,7 +816,15 @@ extern "C" md_status md_decode_step(const md_text_model* m, const int32_t* token
   const size_t tws_bytes = workspace_bytes - a.off;
   MD_TRY(md_embed_tokens(tokens, m->wte, m->dim, x, m->dim, batch, m->dim, s));
   MD_TRY(md_text_forward(m, x, x, batch, 1, pos, kv, tws, tws_bytes, s));
-  MD_TRY(md_lm_head(m, x, batch, 1, logits, ld_logits, lmws, md_lm_head_workspace_bytes(m, batch), s));
+  if (decode_tall_rows(m, batch, 1) && !(kv->k8 && kv->v8)) {
+    // the step's lm_head at 65 .. 128 rows: the by-shape config of the same MFMA family as the <= 64-row regime (never the
+    // pinned four-wave kernel: a sequence must get the same logits in a step of 128 as in a step of 64)
+    md_text_model tallm = *m;
+    tallm.tile_policy = MD_TILE_DECODE_TALL;
+    MD_TRY(md_lm_head(&tallm, x, batch, 1, logits, ld_logits, lmws, md_lm_head_workspace_bytes(m, batch), s));
+  } else {
+    MD_TRY(md_lm_head(m, x, batch, 1, logits, ld_logits, lmws, md_lm_head_workspace_bytes(m, batch), s));
+  }
   return md_argmax_advance(logits, ld_logits, batch, m->vocab, suppress_id, next, pos, s);
 }
 

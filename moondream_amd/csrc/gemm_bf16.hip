@@ -691,6 +691,10 @@ md_status launch_epi(const GemmK& k, int tile, hipStream_t stream) {
                             : launch_cfg<64, 64, 2, 1, EPI, false, 4, 128, 0, 2>(k, stream);
       return k.slices > 1 ? launch_cfg<64, 64, 2, 1, EPI, true, 4, 64, 0, 2>(k, stream)
                           : launch_cfg<64, 64, 2, 1, EPI, false, 4, 64, 0, 2>(k, stream);
+    // round 6 (probe): the decode-regime config with a 128-row tile -- four compute waves x 32 rows + the two DMA helpers; one
+    // weight panel per 128 rows instead of one per 64.  Same K order per output element as 16.
+    case 21: return k.slices > 1 ? launch_cfg<128, 64, 4, 1, EPI, true, 4, 64, 0, 2>(k, stream)
+                                 : launch_cfg<128, 64, 4, 1, EPI, false, 4, 64, 0, 2>(k, stream);
     default: return launch_cfg<128, 128, 2, 2, EPI>(k, stream);
   }
 }
@@ -733,6 +737,10 @@ int pick_tile(int M, int n_store, int K, int policy) {
   // the 256x256 kernel (16x16x32 MFMAs; the small-shape configs below multiply with 32x32x16: equal to fp32 rounding, not
   // bitwise), so that a sequence gets the same bits alone and in a batch
   if (policy == MD_TILE_PINNED && M > 64) return knobs().w4 ? 20 : 11;
+  // MD_TILE_DECODE_TALL: 65 .. 128 rows of a decode step -- the 128 x 64 weight-streaming tile (21), except for the widest layers
+  // (lm_head: 800 column panels keep every CU busy with the 128 x 128 two-stage config, measured 57 vs 73 us); every config
+  // involved multiplies with 32x32x16 in the same K order as the 64-row decode configs
+  if (policy == MD_TILE_DECODE_TALL && M > 64 && M <= 128 && n_store < 16384) return 21;
   // Single-image regime (1458 ViT rows / 735 decoder rows; every config named here multiplies with 32x32x16 in the same K
   // order: the choice never changes a bit).
   //  * at most 128 tiles of 128 x 128 and a long K (proj / fc2 of both towers): half the chip is idle whatever the tile and the
@@ -813,7 +821,7 @@ md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse*
   k.partial_ld = k.partial_slice_stride = 0;
   k.nt = knobs().nt;  // decode regime: non-temporal weight stream (kernel-level +2..10 %, nothing end to end)
   hipStream_t s = (hipStream_t)stream;
-  MD_CHECK_ARG(a->tile_policy == MD_TILE_BY_SHAPE || a->tile_policy == MD_TILE_PINNED);
+  MD_CHECK_ARG(a->tile_policy == MD_TILE_BY_SHAPE || a->tile_policy == MD_TILE_PINNED || a->tile_policy == MD_TILE_DECODE_TALL);
   int tile = pick_tile(k.M, k.n_store, k.K, a->tile_policy);
   k.slices = 1;
   k.slabs = nullptr;
@@ -869,11 +877,14 @@ md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse*
     const long tiles = (long)((k.M + 255) / 256) * ((k.n_store + 255) / 256);
     if (knobs().persist && tiles > 256) tile = 15;
   }
-  if (a->m <= 64 && !forced) {
-    tile = decode_cfg();
+  const bool tall = (tile == 21 && a->m > 64 && a->m <= 128 && !forced);  // MD_TILE_DECODE_TALL: the 128-row weight-streaming tile
+  if ((a->m <= 64 || tall) && !forced) {
+    if (!tall) tile = decode_cfg();
+    // in-launch split-K exactly where the 64-row regime splits (a function of the layer shape): the same slices, the same
+    // slab summation order -- a row gets the same bits in a 128-row launch as in a 64-row one
     const int sl = decode_slices(k.n_store, k.K);
     const size_t tiles = (k.n_store + decode_bn() - 1) / decode_bn();
-    const size_t need = TICKET_BYTES + tiles * sl * decode_slab_floats() * sizeof(float);
+    const size_t need = TICKET_BYTES + tiles * sl * (tall ? 128 * 64 : decode_slab_floats()) * sizeof(float);
     if (sl > 1 && a->splitk_ws != nullptr && a->splitk_ws_bytes >= need && tiles * 4 <= TICKET_BYTES) {
       k.slices = sl;
       k.tickets = (unsigned*)a->splitk_ws;
@@ -886,7 +897,7 @@ md_status gemm_dispatch(const md_gemm_args* a, void* stream, const md_rope_fuse*
   const bool prof = g_prof_on;
   if (prof) {
     if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return MD_ERR_LAUNCH;
-    rec.kind = a->m <= 64 ? 1 : 0;
+    rec.kind = (a->m <= 64 || (a->tile_policy == MD_TILE_DECODE_TALL && a->m <= 128)) ? 1 : 0;   // a weight stream
     rec.work = rec.kind ? 2.0 * (double)a->lin.n * (double)a->lin.k           // bf16 weight bytes, logical n, k
                         : 2.0 * a->m * (double)a->lin.n * (double)a->lin.k;  // algorithmic flops
     rec.rd = 2.0 * ((double)a->m * a->lin.k_pad + (double)a->lin.n_pad * a->lin.k_pad +
@@ -924,7 +935,7 @@ extern "C" int32_t md_gemm_partial_slices(const md_linear* lin) {
 namespace {
 md_status fill_partial(GemmK& k, const void* a, int64_t lda, const md_linear* lin, int32_t m, float* partial,
                        int64_t ld_partial, int64_t slice_stride) {
-  MD_CHECK_ARG(a && lin && lin->w && partial && m > 0 && m <= 64);
+  MD_CHECK_ARG(a && lin && lin->w && partial && m > 0 && m <= 128);  // (65 .. 128 rows: the 128 x 64 tile, round 6)
   MD_CHECK_ARG(lin->k_pad % BK == 0 && lin->k_pad >= lin->k && lin->n % 8 == 0 && lin->n_pad % 64 == 0);
   MD_CHECK_ARG(lda >= lin->k_pad && lda % 8 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)lin->w & 15) == 0);
   MD_CHECK_ARG(ld_partial >= lin->n && ld_partial % 4 == 0 && ((uintptr_t)partial & 15) == 0);
@@ -942,7 +953,7 @@ md_status fill_partial(GemmK& k, const void* a, int64_t lda, const md_linear* li
   k.n_store = lin->n;
   k.K = lin->k_pad;
   k.res_row_mod = 0;
-  k.tiles_m = (m + 63) / 64;
+  k.tiles_m = 1;
   k.tiles_n = (lin->n + 63) / 64;
   k.group_m = 8;
   k.gelu_from = 0;
@@ -990,7 +1001,8 @@ extern "C" md_status md_gemm_partial_f32(const void* a, int64_t lda, const md_li
   ProfScope prof;
   if (prof.begin(2.0 * (double)lin->n * (double)lin->k, s) != MD_OK) return MD_ERR_LAUNCH;
   const int cfg = decode_cfg();
-  const md_status st = (cfg == 17 || cfg == 18) ? launch_cfg<64, 64, 2, 2, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
+  const md_status st = m > 64 ? launch_cfg<128, 64, 4, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
+                       : (cfg == 17 || cfg == 18) ? launch_cfg<64, 64, 2, 2, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
                        : (cfg == 16 || cfg == 19) ? launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>(k, s)
                                                   : launch_cfg<64, 64, 2, 1, MD_EPI_BIAS, true, 4>(k, s);
   prof.end();
@@ -1012,27 +1024,32 @@ extern "C" md_status md_gemm_partial_f32_pair(const void* a0, int64_t lda0, cons
   // (64-wide slices here whatever the config: 64 KiB of ring = TWO workgroups per CU, and the pair makes 512)
   const int cfg = decode_cfg();
   const bool four = cfg == 17 || cfg == 18, helpers = four || cfg == 16 || cfg == 19;
-  const int NT = four ? 384 : helpers ? 256 : 128;
-  auto fn = four ? gemm_pair_kernel<64, 64, 2, 2, MD_EPI_BIAS, true, 4, 64, 0, 2>
+  // 65 .. 128 rows (round 6): one 128 x 64 tile per weight panel -- four compute waves x 32 rows + the two DMA helpers, 96 KiB
+  // of ring (one workgroup per CU); the same K slices and the same K order per output element as the 64-row configs
+  const bool tall = m > 64;
+  const int NT = tall ? 384 : four ? 384 : helpers ? 256 : 128;
+  const int lds_used = tall ? 4 * (128 + 64) * 64 * 2 : lds;
+  auto fn = tall ? gemm_pair_kernel<128, 64, 4, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
+            : four ? gemm_pair_kernel<64, 64, 2, 2, MD_EPI_BIAS, true, 4, 64, 0, 2>
             : helpers ? gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
                       : gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;
-  MD_TRY(md_ensure_dynamic_lds((const void*)fn, lds));
+  MD_TRY(md_ensure_dynamic_lds((const void*)fn, lds_used));
   ProfScope prof;
   if (prof.begin(2.0 * ((double)lin0->n * lin0->k + (double)lin1->n * lin1->k), s) != MD_OK) return MD_ERR_LAUNCH;
   const int gx = std::max(pair.g[0].tiles_m * pair.g[0].tiles_n, pair.g[1].tiles_m * pair.g[1].tiles_n);
   const int gy = std::max(pair.g[0].slices, pair.g[1].slices);
-  hipLaunchKernelGGL(fn, dim3(gx, gy, 2), dim3(NT), lds, s, pair);
+  hipLaunchKernelGGL(fn, dim3(gx, gy, 2), dim3(NT), lds_used, s, pair);
   prof.end();
   return md_launch_status();
 }
 
 extern "C" size_t md_gemm_workspace_bytes(const md_linear* lin, int32_t m, int32_t store_pad_cols) {
-  if (!lin || m > 64) return 0;
+  if (!lin || m > 128) return 0;   // (65 .. 128 rows: what a MD_TILE_DECODE_TALL launch needs; other policies ignore the workspace there)
   const int n_store = store_pad_cols ? lin->n_pad : lin->n;
   const int sl = decode_slices(n_store, lin->k_pad);
   if (sl == 1) return 0;
   const size_t tiles = (n_store + decode_bn() - 1) / decode_bn();
-  return TICKET_BYTES + tiles * sl * decode_slab_floats() * sizeof(float);
+  return TICKET_BYTES + tiles * sl * (m > 64 ? 128 * 64 : decode_slab_floats()) * sizeof(float);
 }
 
 bool md_gemm_knob_rope_fuse() { return knobs().rope_fuse != 0; }

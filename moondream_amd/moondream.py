@@ -1295,7 +1295,8 @@ class MoondreamModel:
 
     def batch_generate_ids_pipelined(self, batches, max_tokens: int = DEFAULT_MAX_TOKENS, ignore_eos: bool = False):
         """Generator over an iterable of (images, prompt-id lists) batches; yields each batch's greedy ids in order, one
-        batch late.  Two HIP streams: the MFMA-bound encode (vision + prefill) of batch k+1 on one, the HBM-bound lockstep
+        decode group late (a group = two consecutive batches of <= 64 sequences decoded as ONE lockstep of <= 128 -- round 6,
+        ``pair_decode`` -- or one batch).  Two HIP streams: the MFMA-bound encode (vision + prefill) of batch k+1 on one, the HBM-bound lockstep
         decode of batch k on a second, higher-priority one, over disjoint KV-slab slot groups and disjoint workspaces.
 
           * The two streams' kernels DO overlap on the GPU (profiles/r04_pipelined_engine_streams_ab.txt: 50-86 % of a
@@ -1321,6 +1322,12 @@ class MoondreamModel:
             if st is not None:
                 self._drain_staged(st)
 
+    # Round 6: the decode of TWO consecutive batches runs as one lockstep decode (<= 128 sequences) when the library takes that
+    # many rows in one pass over the weights (md_decode_step: 65 .. 128 rows on the 128 x 64 weight-streaming tile, same bits as
+    # two passes of 64): 2.07 instead of 2.46 ms per token and 64 sequences at 2B.  Each batch is still encoded on its own
+    # (launches of 64 images: what BASELINE's batch=64 names), results are still yielded per batch and in order, one PAIR late.
+    pair_decode = os.environ.get("MD_PIPE_PAIR", "1") not in ("0", "")
+
     def _pipelined_loop(self, it, cur, staged, pending, max_tokens, ignore_eos):
         tk = self.config.tokenizer
         eos = tk.eos_id
@@ -1330,35 +1337,48 @@ class MoondreamModel:
         group = 0
         self._pipe_staged = staged
         while cur is not None:
-            images, prompts = cur
-            images = list(images)
-            b = len(images)
-            assert b == len(prompts) and b > 0 and len({len(p) for p in prompts}) == 1
-            self._ensure_batch(2 * b)
+            b = len(cur[0])
+            pair = self.pair_decode and 2 * b <= 128 and not bool(self.w.text.fp8) and self._kv8_scales is None
+            cap = 2 * b if pair else b            # slots of one group: two groups alternate (encode into one, decode from the other)
+            self._ensure_batch(2 * cap)
             self._select_kernels(b)
-            slot0 = group * b
+            base = group * cap
             group ^= 1
-            nxt = next(it, None)
+            firsts, p1s, sizes = [], [], []
             with torch.inference_mode():
                 run_s.wait_stream(torch.cuda.current_stream(self._device))
+                while True:
+                    images, prompts = cur
+                    images = list(images)
+                    nb = len(images)
+                    assert nb == len(prompts) and nb > 0 and len({len(p) for p in prompts}) == 1
+                    slot0 = base + sum(sizes)
+                    nxt = next(it, None)
+                    with torch.cuda.stream(run_s):
+                        img_emb = self._run_vision_encoder_batch(images, staged=staged)
+                        # this batch's crops are cut and queued for upload: the pool is free for the next batch's tiling
+                        staged = self._pipe_staged = self._stage_crops(list(nxt[0])) if nxt is not None else None
+                        if self.fused_prefill:  # [bos | image | prompt] in one decoder pass, as in _prepare_sequences
+                            # assembled in a PREALLOCATED arena (one per batch shape; stream-ordered reuse on run_s: the previous
+                            # pass has read it before these copies run) instead of a fresh torch.cat per step; the BOS column is
+                            # written once
+                            n_img, n_pr = img_emb.shape[1], len(prompts[0])
+                            x = self._prefill_arena(nb, 1 + n_img + n_pr, tk.bos_id)
+                            x[:, 1 : 1 + n_img].copy_(img_emb)
+                            x[:, 1 + n_img :].copy_(self._embed(torch.tensor(prompts, dtype=torch.int32)))
+                            logits = self._lm_head(self._text_forward(x, 0, slot0))
+                            p1 = x.shape[1]
+                        else:
+                            pos = self._prefill_images(img_emb, slot0)
+                            logits, _, p1 = self._prefill_prompts(prompts, pos, slot0)
+                        firsts.append(self._pick(logits, 0.0, 0.0))
+                    p1s.append(p1)
+                    sizes.append(nb)
+                    cur = nxt
+                    if not pair or len(sizes) == 2 or cur is None or len(cur[0]) != b:
+                        break
                 with torch.cuda.stream(run_s):
-                    img_emb = self._run_vision_encoder_batch(images, staged=staged)
-                    # this batch's crops are cut and queued for upload: the pool is free for the next batch's tiling
-                    staged = self._pipe_staged = self._stage_crops(list(nxt[0])) if nxt is not None else None
-                    if self.fused_prefill:  # [bos | image | prompt] in one decoder pass, as in _prepare_sequences
-                        # assembled in a PREALLOCATED arena (one per batch shape; stream-ordered reuse on run_s: the previous
-                        # step's pass has read it before this step's copies run) instead of a fresh torch.cat per step; the
-                        # BOS column is written once
-                        n_img, n_pr = img_emb.shape[1], len(prompts[0])
-                        x = self._prefill_arena(b, 1 + n_img + n_pr, tk.bos_id)
-                        x[:, 1 : 1 + n_img].copy_(img_emb)
-                        x[:, 1 + n_img :].copy_(self._embed(torch.tensor(prompts, dtype=torch.int32)))
-                        logits = self._lm_head(self._text_forward(x, 0, slot0))
-                        p1 = x.shape[1]
-                    else:
-                        pos = self._prefill_images(img_emb, slot0)
-                        logits, _, p1 = self._prefill_prompts(prompts, pos, slot0)
-                    first = self._pick(logits, 0.0, 0.0)
+                    first = firsts[0] if len(firsts) == 1 else torch.cat(firsts)
                     if dec_s is not run_s:
                         ev = torch.cuda.Event()
                         ev.record(run_s)
@@ -1366,7 +1386,8 @@ class MoondreamModel:
                     if dec_s is not run_s:
                         dec_s.wait_event(ev)
                         first.record_stream(dec_s)
-                    hist = self._decode_greedy(first, p1, max_tokens, tk.answer_id, slot0, None, check_every=16, allow_b1=False)
+                    pos1 = p1s[0] if len(set(p1s)) == 1 else [p for p, n in zip(p1s, sizes) for _ in range(n)]
+                    hist = self._decode_greedy(first, pos1, max_tokens, tk.answer_id, base, None, check_every=16, allow_b1=False)
                     # ids -> PINNED host memory behind the last decode step (a ``.tolist()`` at collection time is a
                     # synchronous copy on the default stream: it waits for everything queued on the device)
                     if self.pipeline_streams == 3:  # measurement only: rounds 1-3's collection (synchronous copy on the default stream)
@@ -1376,12 +1397,11 @@ class MoondreamModel:
                         hist_host.copy_(hist, non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(dec_s)
-            pending.append((hist_host, done, b))
+            pending.append((hist_host, done, sizes))
             if len(pending) > 1:
-                yield self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
-            cur = nxt
+                yield from self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
         while pending:
-            yield self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
+            yield from self._collect(pending.pop(0), None if ignore_eos else eos, max_tokens)
 
     def _prefill_arena(self, b: int, t: int, bos_id: int) -> torch.Tensor:
         """bf16 [b, t, D] buffer of the pipelined engine's fused prefill input, column 0 = the BOS embedding."""
@@ -1405,14 +1425,18 @@ class MoondreamModel:
             return torch.empty(shape, dtype=torch.int32, pin_memory=True)
 
     def _collect(self, item, eos, max_tokens):
-        hist, done, b = item
+        """One decoded group -> the id lists of its batches, in order (a generator: one item per batch)."""
+        hist, done, sizes = item
         done.synchronize()
         cols = hist.t().tolist()
         if hist.device.type == "cpu" and hist.is_pinned():
             self.__dict__.setdefault("_pinned_id_free", {}).setdefault(tuple(hist.shape), []).append(hist)
-        if b == 1:
+        if sum(sizes) == 1:
             self._check_b1_barriers()
-        return [self._truncate(cols[i], eos, max_tokens) for i in range(b)]
+        i0 = 0
+        for n in sizes:
+            yield [self._truncate(cols[i], eos, max_tokens) for i in range(i0, i0 + n)]
+            i0 += n
 
     @staticmethod
     def _sampling_kwargs(settings: Optional[dict]) -> dict:

@@ -604,6 +604,35 @@ def test_rowwise_add_and_gelu_kernels():
     compare("gelu", out, torch.nn.functional.gelu(a.float(), approximate="tanh").to(BF16), 3e-3, 2e-2)
 
 
+def test_decode_step_of_128_sequences_is_one_pass_with_the_bits_of_two_passes_of_64(tiny):
+    """Round 6: a decode step of 65 .. 128 sequences streams the weights ONCE (128 x 64 weight-streaming tile for the fused
+    qkv|fc1 layer, 128-row K-slice partials + fused tail for proj / fc2, by-shape lm_head) instead of once per block of 64.
+    Same K order per output element: ids, the step's logits and the K / V rows it writes equal, bit for bit, those of the
+    same sequences decoded in batches of 64 -- also for a ragged 100 (one tall pass) and 160 (128 + 32)."""
+    g, cfg, sd, model = tiny
+    pr = g["img0.cap.prompt"].tolist()
+    imgs = [synth.synthetic_image(i, int(g["seed"])) for i in range(160)]
+    n = 6
+    ref = []
+    for i0 in range(0, 160, 64):
+        part = imgs[i0 : i0 + 64]
+        ref += model.batch_generate_ids(part, [pr] * len(part), max_tokens=n, ignore_eos=True)
+    kv_ref = None
+    for b in (128, 100, 160):
+        got = model.batch_generate_ids(imgs[:b], [pr] * b, max_tokens=n, ignore_eos=True)
+        assert got == ref[:b], (b, [i for i in range(b) if got[i] != ref[i]][:5])
+    # logits and cache rows of one step: 128 rows at once vs 64 + 64
+    p0 = 730 + len(pr)
+    model.batch_generate_ids(imgs[:128], [pr] * 128, max_tokens=2, ignore_eos=True)
+    k128, lg128 = model._kv_k[:, :128, :, p0 : p0 + 2].clone(), model._decode_logits(128)[:128].clone()
+    model.batch_generate_ids(imgs[:64], [pr] * 64, max_tokens=2, ignore_eos=True)
+    k_a, lg_a = model._kv_k[:, :64, :, p0 : p0 + 2].clone(), model._decode_logits(64)[:64].clone()
+    model.batch_generate_ids(imgs[64:128], [pr] * 64, max_tokens=2, ignore_eos=True)
+    k_b, lg_b = model._kv_k[:, :64, :, p0 : p0 + 2].clone(), model._decode_logits(64)[:64].clone()
+    assert torch.equal(k128[:, :64], k_a) and torch.equal(k128[:, 64:], k_b)
+    assert torch.equal(lg128[:64], lg_a) and torch.equal(lg128[64:], lg_b)
+
+
 # ------------------------------------------------------------------ per-layer drift profile (round 6)
 def _layer_profile(model, cfg, g):
     """HIP activation after every ViT block k (as post_ln(x_k): md_vit_encode with the block list cut after block k) and after

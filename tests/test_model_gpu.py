@@ -1260,6 +1260,30 @@ def mutation_sensitivity(model, cfg, g, images, imgs64, pr, gb):
         assert failed, f"no parity gate noticed: {what}"
     failed, rep, act = gates()  # restored
     assert not failed, (failed, rep["parity_note"], act)
+    # A SYSTEMATIC fault -- the kind a mis-indexed head in the attention kernel or a wrong V stride in the cache would be -- DOES
+    # move the ids of the conditioned checkpoint (a local one does not, by construction: DESIGN section 2): in EVERY decoder block
+    # the proj input columns of head (l mod 32) and of the next head are swapped.
+    t = cfg.text
+    hd = t.dim // t.n_heads
+    keeps = []
+    try:
+        for l in range(t.n_layers):
+            w = model.w._text_packed[l]["proj"].w
+            keeps.append(w.clone())
+            h0, h1 = (l % t.n_heads) * hd, ((l + 1) % t.n_heads) * hd
+            a, b = w[:, h0 : h0 + hd].clone(), w[:, h1 : h1 + hd].clone()
+            w[:, h0 : h0 + hd], w[:, h1 : h1 + hd] = b, a
+        torch.cuda.synchronize()
+        failed, rep, act = gates()
+    finally:
+        for l, k in enumerate(keeps):
+            model.w._text_packed[l]["proj"].w.copy_(k)
+        torch.cuda.synchronize()
+    print(f"mutation [every decoder block: two heads' proj input columns swapped]: gates tripped {failed}; ids {rep['parity_exact']}/64 identical, "
+          f"max |logit err| {rep['parity_max_logit_err']:.3f}, wide-margin teacher-forced decisions that differ {rep['parity_tf_decisions_violations']}")
+    assert "ids report" in failed and rep["parity_exact"] < 32 and rep["parity_tf_decisions_violations"] > 100, (failed, rep["parity_exact"])
+    failed, rep, act = gates()  # restored
+    assert not failed, (failed, rep["parity_note"], act)
 
 
 def test_int4_checkpoint_streams_its_own_weights_in_decode():

@@ -198,6 +198,8 @@ class ReferenceBinding:
 
         key = id(lora)
         if key not in self.loras:
+            if len(self.loras) >= 4:   # a loader that hands out a fresh dict per call must not grow this without bound
+                self.loras.pop(next(iter(self.loras)))
             self.loras[key] = (lora, PackedLora(self.config, lora, self.packed.device))  # keeps the dict alive: id() stays unique
         return self.loras[key][1]
 

@@ -1288,7 +1288,8 @@ class MoondreamModel:
     def _streams(self):
         st = getattr(self, "_pipe_streams", None)
         if st is None:
-            st = self._pipe_streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device, priority=-1))
+            prio = int(os.environ.get("MD_PIPE_DECODE_PRIORITY", "-1"))   # (A/B knob; -1 = high priority, the default)
+            st = self._pipe_streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device, priority=prio))
         return st
 
     pipeline_streams = int(os.environ.get("MD_PIPE_STREAMS", "2"))  # 2: decode on its own (priority) stream; 1: encode and decode in order on one stream

@@ -198,7 +198,7 @@ class ReferenceBinding:
 
         key = id(lora)
         if key not in self.loras:
-            if len(self.loras) >= 4:   # a loader that hands out a fresh dict per call must not grow this without bound
+            if len(self.loras) >= 5:   # (the reference caches 5 variants, lora.py:54) a loader that hands out fresh dicts must not grow this without bound
                 self.loras.pop(next(iter(self.loras)))
             self.loras[key] = (lora, PackedLora(self.config, lora, self.packed.device))  # keeps the dict alive: id() stays unique
         return self.loras[key][1]

@@ -57,3 +57,15 @@ def test_reference_runs_on_one_slab_and_struct_addresses_it(ref):
     slab_k[:, 0].zero_()
     model.load_encoded_image(enc)
     assert torch.equal(slab_k[0, 0:1, :, :730], enc.caches[0][0])
+
+
+def test_bind_reference_has_no_cpu_path(ref):
+    """The drop-in (moondream_amd.integration.bind_reference) fails LOUDLY on a model that is not on a GPU -- there is no CPU
+    fallback behind the seam -- and leaves the reference's own methods in place."""
+    from moondream_amd import _lib
+    from moondream_amd.integration import bind_reference
+
+    g, cfg, model, ref_md, mg = ref
+    with pytest.raises(_lib.MoondreamHipError):
+        bind_reference(model)
+    assert "_mi355x" not in model.__dict__ and getattr(model._prefill, "__module__", "") != "moondream_amd.integration"

@@ -1028,8 +1028,10 @@ extern "C" md_status md_gemm_partial_f32_pair(const void* a0, int64_t lda0, cons
   // of ring (one workgroup per CU); the same K slices and the same K order per output element as the 64-row configs
   const bool tall = m > 64;
   const int NT = tall ? 384 : four ? 384 : helpers ? 256 : 128;
-  const int lds_used = tall ? 4 * (128 + 64) * 64 * 2 : lds;
-  auto fn = tall ? gemm_pair_kernel<128, 64, 4, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
+  static const int tall_stages = [] { const char* e = getenv("MD_TALL_PAIR_STAGES"); return e ? atoi(e) : 3; }();   // 3 stages = 72 KiB of ring: TWO workgroups per CU, all 512 of the pair resident at once (18.6 us against 20.3 with 4 stages; MD_TALL_PAIR_STAGES=4: A/B)
+  const int lds_used = tall ? tall_stages * (128 + 64) * 64 * 2 : lds;
+  auto fn = tall ? (tall_stages == 3 ? gemm_pair_kernel<128, 64, 4, 1, MD_EPI_BIAS, true, 3, 64, 0, 2>
+                                     : gemm_pair_kernel<128, 64, 4, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>)
             : four ? gemm_pair_kernel<64, 64, 2, 2, MD_EPI_BIAS, true, 4, 64, 0, 2>
             : helpers ? gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4, 64, 0, 2>
                       : gemm_pair_kernel<64, 64, 2, 1, MD_EPI_BIAS, true, 4>;

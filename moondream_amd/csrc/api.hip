@@ -47,7 +47,7 @@ inline bool tile_policy_ok(int p) { return p == MD_TILE_BY_SHAPE || p == MD_TILE
 // Round 6: a decode step (q_len 1) of 65 .. 128 sequences as ONE pass over the weights -- the fused qkv|fc1 GEMM on the 128 x 64
 // weight-streaming tile, proj / fc2 as K-slice partials of 128 rows + the fused tail, lm_head on its by-shape config -- instead of
 // two passes of 64 rows.  Same K order per output element as the 64-row regime: a sequence gets the same bits either way.
-// Measured (tools/bench_decode_gemm_m128.py): qkv|fc1 19.8 us vs 2 x 16.4, pair 20.3 vs 2 x 13.7, lm_head 57 vs 2 x 54.
+// Measured (tools/bench_decode_gemm_m128.py): qkv|fc1 19.8 us vs 2 x 16.4, pair 18.6 (3-stage ring) vs 2 x 13.7, lm_head 57 vs 2 x 54.
 // MD_DECODE_TALL=0: the round-5 behaviour (blocks of 64).  Not with the fp8 weight stream attached (its kernels are <= 64 rows).
 inline bool decode_tall_model(const md_text_model* m) {
   static const bool allowed = [] { const char* e = getenv("MD_DECODE_TALL"); return !(e && e[0] == '0'); }();
